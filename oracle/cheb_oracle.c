@@ -1,0 +1,497 @@
+/*
+ * cheb_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ * See cheb_oracle.h for scope, pinning and the FFTW definitions restated here.
+ * Build: make -C oracle   (gcc -O2 -fopenmp, no external libraries)
+ */
+#include "cheb_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.14159265358979323846 /* chebyshev.h:10 */
+static const long double PI_L = 3.14159265358979323846264338327950288L;
+
+/* ------------------------------------------------------------------------- */
+/* Transform plan: tables shared read-only by all lines of one sweep.         */
+/* N = number of intervals; both REDFT00 on N+1 points and RODFT00 on N-1     */
+/* points are real-symmetric DFTs of logical length 2N (FFTW manual).         */
+/* ------------------------------------------------------------------------- */
+typedef struct { double re, im; } cpx;
+
+typedef struct {
+  int N;
+  int use_fft;       /* fast path: complex FFT of length N, else table summation */
+  int nf, fac[40];   /* radix, remaining length pairs (smallest prime first)       */
+  cpx *tw;           /* e^{-2 pi i t/N}, t < N                                    */
+  cpx *half;         /* e^{-i pi k/N},  k <= N                                    */
+  double *ctab, *stab;        /* cos/sin(pi t/N), t < 2N (double, table-summation fallback) */
+  long double *ctabl, *stabl; /* cos/sin(pi t/N), t < 2N (long double, ORC_DIRECT)          */
+} xplan;
+
+static void xplan_free(xplan *p) {
+  if (!p) return;
+  free(p->tw); free(p->half); free(p->ctab); free(p->ctabl); free(p->stab); free(p->stabl); free(p);
+}
+
+static xplan *xplan_make(int N, int mode) {
+  xplan *p = (xplan *)calloc(1, sizeof(xplan));
+  p->N = N;
+  if (mode == ORC_DIRECT) {
+    p->ctabl = (long double *)malloc(sizeof(long double) * 2 * (size_t)N);
+    p->stabl = (long double *)malloc(sizeof(long double) * 2 * (size_t)N);
+    for (int t = 0; t < 2 * N; t++) { p->ctabl[t] = cosl(PI_L * t / N); p->stabl[t] = sinl(PI_L * t / N); }
+    return p;
+  }
+  /* factorise N */
+  int n = N, maxf = 1;
+  for (int f = 2; n > 1;) {
+    if (n % f == 0) { p->fac[2 * p->nf] = f; n /= f; p->fac[2 * p->nf + 1] = n; p->nf++; if (f > maxf) maxf = f; }
+    else { f++; if ((long)f * f > n) f = n; }
+  }
+  p->use_fft = (N >= 8 && maxf <= 32);
+  if (p->use_fft) {
+    p->tw = (cpx *)malloc(sizeof(cpx) * (size_t)N);
+    p->half = (cpx *)malloc(sizeof(cpx) * (size_t)(N + 1));
+    for (int t = 0; t < N; t++) {
+      long double a = -2.0L * PI_L * t / N;
+      p->tw[t].re = (double)cosl(a); p->tw[t].im = (double)sinl(a);
+    }
+    for (int k = 0; k <= N; k++) {
+      long double a = -PI_L * k / N;
+      p->half[k].re = (double)cosl(a); p->half[k].im = (double)sinl(a);
+    }
+  } else {
+    p->ctab = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    p->stab = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    for (int t = 0; t < 2 * N; t++) { p->ctab[t] = (double)cosl(PI_L * t / N); p->stab[t] = (double)sinl(PI_L * t / N); }
+  }
+  return p;
+}
+
+/* Mixed-radix decimation-in-time complex FFT, generic butterflies. */
+static void fft_work(const xplan *p, cpx *out, const cpx *in, long fstride, const int *fac) {
+  const int r = fac[0], m = fac[1], N = p->N;
+  cpx scratch[32]; /* radices are <= 32 when use_fft is set */
+  if (m == 1) {
+    for (int q = 0; q < r; q++) out[q] = in[q * fstride];
+  } else {
+    for (int q = 0; q < r; q++) fft_work(p, out + (long)q * m, in + q * fstride, fstride * r, fac + 2);
+  }
+  for (int u = 0; u < m; u++) {
+    for (int q = 0; q < r; q++) scratch[q] = out[u + (long)q * m];
+    for (int q1 = 0; q1 < r; q1++) {
+      const long k = u + (long)q1 * m;
+      double sr = scratch[0].re, si = scratch[0].im;
+      long tix = 0;
+      const long step = (fstride * k) % N;
+      for (int q = 1; q < r; q++) {
+        tix += step; if (tix >= N) tix -= N;
+        const cpx w = p->tw[tix];
+        sr += scratch[q].re * w.re - scratch[q].im * w.im;
+        si += scratch[q].re * w.im + scratch[q].im * w.re;
+      }
+      out[k].re = sr; out[k].im = si;
+    }
+  }
+}
+
+/* Real DFT of length 2N of xt (real), returned as X_k, k = 0..N, via one
+ * complex FFT of length N.  buf must hold 2N + 64 cpx. */
+static void rdft2N(const xplan *p, const double *xt, cpx *X, cpx *buf) {
+  const int N = p->N;
+  cpx *z = buf, *Z = buf + N;
+  for (int m = 0; m < N; m++) { z[m].re = xt[2 * m]; z[m].im = xt[2 * m + 1]; }
+  fft_work(p, Z, z, 1, p->fac);
+  for (int k = 0; k <= N; k++) {
+    const cpx a = Z[k % N], b = Z[(N - k) % N];
+    const double evr = 0.5 * (a.re + b.re), evi = 0.5 * (a.im - b.im);
+    const double dr = a.re - b.re, di = a.im + b.im; /* a - conj(b) */
+    const double odr = 0.5 * di, odi = -0.5 * dr;    /* (a-conj b)/(2i) */
+    const cpx w = p->half[k];
+    X[k].re = evr + w.re * odr - w.im * odi;
+    X[k].im = evi + w.re * odi + w.im * odr;
+  }
+}
+
+typedef struct { double *xt; cpx *X; cpx *buf; } xscratch;
+static void xscratch_init(xscratch *s, int N) {
+  s->xt = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+  s->X = (cpx *)malloc(sizeof(cpx) * (size_t)(N + 1));
+  s->buf = (cpx *)malloc(sizeof(cpx) * (2 * (size_t)N + 64));
+}
+static void xscratch_free(xscratch *s) { free(s->xt); free(s->X); free(s->buf); }
+
+/* FFTW manual REDFT00 on n = N+1 points. */
+static void redft00_line(const xplan *p, xscratch *s, const double *in, long is, double *out, long os) {
+  const int N = p->N;
+  if (p->ctabl) {
+    for (int k = 0; k <= N; k++) {
+      long double acc = 0.0L;
+      for (int j = 1; j < N; j++) acc += (long double)in[j * is] * p->ctabl[((long)j * k) % (2 * N)];
+      acc = (long double)in[0] + ((k & 1) ? -1.0L : 1.0L) * (long double)in[(long)N * is] + 2.0L * acc;
+      out[k * os] = (double)acc;
+    }
+  } else if (p->use_fft) {
+    double *xt = s->xt;
+    for (int j = 0; j <= N; j++) xt[j] = in[j * is];
+    for (int j = 1; j < N; j++) xt[2 * N - j] = in[j * is];
+    rdft2N(p, xt, s->X, s->buf);
+    for (int k = 0; k <= N; k++) out[k * os] = s->X[k].re;
+  } else {
+    for (int k = 0; k <= N; k++) {
+      double acc = 0.0;
+      for (int j = 1; j < N; j++) acc += in[j * is] * p->ctab[((long)j * k) % (2 * N)];
+      out[k * os] = in[0] + ((k & 1) ? -1.0 : 1.0) * in[(long)N * is] + 2.0 * acc;
+    }
+  }
+}
+
+/* FFTW manual RODFT00 on n = N-1 points. */
+static void rodft00_line(const xplan *p, xscratch *s, const double *in, long is, double *out, long os) {
+  const int N = p->N, n = N - 1;
+  if (n <= 0) return;
+  if (p->ctabl) {
+    for (int k = 0; k < n; k++) {
+      long double acc = 0.0L;
+      for (int j = 0; j < n; j++) acc += (long double)in[j * is] * p->stabl[((long)(j + 1) * (k + 1)) % (2 * N)];
+      out[k * os] = (double)(2.0L * acc);
+    }
+  } else if (p->use_fft) {
+    double *xt = s->xt;
+    xt[0] = 0.0; xt[N] = 0.0;
+    for (int j = 0; j < n; j++) { xt[j + 1] = in[j * is]; xt[2 * N - 1 - j] = -in[j * is]; }
+    rdft2N(p, xt, s->X, s->buf);
+    for (int k = 1; k <= n; k++) out[(k - 1) * os] = -s->X[k].im;
+  } else {
+    for (int k = 0; k < n; k++) {
+      double acc = 0.0;
+      for (int j = 0; j < n; j++) acc += in[j * is] * p->stab[((long)(j + 1) * (k + 1)) % (2 * N)];
+      out[k * os] = 2.0 * acc;
+    }
+  }
+}
+
+int orc_redft00(int n, const double *in, long is, double *out, long os, int mode) {
+  if (n < 2) return 1;
+  xplan *p = xplan_make(n - 1, mode);
+  xscratch s; xscratch_init(&s, n - 1);
+  redft00_line(p, &s, in, is, out, os);
+  xscratch_free(&s); xplan_free(p);
+  return 0;
+}
+
+int orc_rodft00(int n, const double *in, long is, double *out, long os, int mode) {
+  if (n < 1) return 1;
+  xplan *p = xplan_make(n + 1, mode);
+  xscratch s; xscratch_init(&s, n + 1);
+  rodft00_line(p, &s, in, is, out, os);
+  xscratch_free(&s); xplan_free(p);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* chebyshev.c:89-138 argument checks + stride convention (:107-120).         */
+/* ------------------------------------------------------------------------- */
+static int cheb_geom(int rank, int tr, const int *dims, long *ntot, int *P, long *inner, long *outer) {
+  if (rank < 1 || !(0 <= tr && tr < rank)) return 2;      /* chebyshev.c:106 */
+  long tot = 1, in = 1, out = 1;
+  for (int r = 0; r < rank; r++) {
+    if (dims[r] < 1) return 3;
+    tot *= dims[r];
+    if (r > tr) in *= dims[r];
+    if (r < tr) out *= dims[r];
+  }
+  if (tot < 2) return 1;                                  /* chebyshev.c:98  */
+  if (dims[tr] < 2) return 1;
+  *ntot = tot; *P = dims[tr]; *inner = in; *outer = out;
+  return 0;
+}
+
+int orc_cheb_mult(int rank, int tr, const int *dims, const double *x, double *y, int mode, int nthreads) {
+  long ntot, inner, outer; int P;
+  int err = cheb_geom(rank, tr, dims, &ntot, &P, &inner, &outer);
+  if (err) return err;
+  const int n = P - 1;                                    /* chebyshev.c:154 */
+  const long ts = inner;                                  /* tdim.is         */
+  const long nlines = outer * inner;
+  double *work = (double *)malloc(sizeof(double) * (size_t)ntot); /* chebyshev.c:102 */
+  xplan *p = xplan_make(n, mode);
+  if (nthreads < 1) nthreads = 1;
+  const double N = (double)n;
+  const double pin = ORC_PI / N;                          /* chebyshev.c:183 */
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    xscratch s; xscratch_init(&s, n);
+    /* pass 1: forward REDFT00, x -> work (chebyshev.c:157) */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long l = 0; l < nlines; l++) {
+      const long off = (l / inner) * P * inner + (l % inner);
+      redft00_line(p, &s, x + off, ts, work + off, ts);
+    }
+    /* pass 2: coefficient scaling and endpoint sums (chebyshev.c:162-179) */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long l = 0; l < nlines; l++) {
+      const long offset = (l / inner) * P * inner + (l % inner);
+      const long ix0 = offset, ixn = offset + n * ts;
+      y[ix0] = 0.0; y[ixn] = 0.0;
+      double sgn = 1.0;
+      for (int i = 1; i < n; i++) {
+        const long ix = offset + i * ts;
+        const double I = (double)i;
+        work[ix] *= I;
+        y[ix0] += I * work[ix];
+        y[ixn] += sgn * I * work[ix];
+        sgn = -sgn;
+      }
+      y[ix0] = 0.5 * work[ixn] * N + y[ix0] / n;
+      y[ixn] = y[ixn] / N + 0.5 * sgn * N * work[ixn];
+    }
+    /* pass 3: backward RODFT00 on n-1 points, work+os -> y+is (chebyshev.c:181) */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long l = 0; l < nlines; l++) {
+      const long off = (l / inner) * P * inner + (l % inner);
+      rodft00_line(p, &s, work + off + ts, ts, y + off + ts, ts);
+    }
+    /* pass 4: metric scaling (chebyshev.c:186-193) */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long l = 0; l < nlines; l++) {
+      const long offset = (l / inner) * P * inner + (l % inner);
+      for (int i = 1; i < n; i++) {
+        const long ix = offset + i * ts;
+        const double I = (double)i;
+        const double c = cos(I * pin);
+        y[ix] /= 2 * n * sqrt(1.0 - c * c);
+      }
+    }
+    xscratch_free(&s);
+  }
+  xplan_free(p);
+  free(work);
+  return 0;
+}
+
+int orc_cheb_mult_truth(int rank, int tr, const int *dims, const double *x, double *y) {
+  long ntot, inner, outer; int P;
+  int err = cheb_geom(rank, tr, dims, &ntot, &P, &inner, &outer);
+  if (err) return err;
+  const int n = P - 1;
+  const long ts = inner, nlines = outer * inner;
+  long double *Y = (long double *)malloc(sizeof(long double) * (size_t)(n + 1));
+  long double *ct = (long double *)malloc(sizeof(long double) * 2 * (size_t)n);
+  long double *st = (long double *)malloc(sizeof(long double) * 2 * (size_t)n);
+  for (int t = 0; t < 2 * n; t++) { ct[t] = cosl(PI_L * t / n); st[t] = sinl(PI_L * t / n); }
+  for (long l = 0; l < nlines; l++) {
+    const long off = (l / inner) * P * inner + (l % inner);
+    const double *u = x + off; double *v = y + off;
+    for (int k = 0; k <= n; k++) {
+      long double acc = 0.0L;
+      for (int j = 1; j < n; j++) acc += (long double)u[j * ts] * ct[((long)j * k) % (2 * n)];
+      Y[k] = (long double)u[0] + ((k & 1) ? -1.0L : 1.0L) * (long double)u[(long)n * ts] + 2.0L * acc;
+    }
+    long double y0 = 0.0L, yn = 0.0L, sgn = 1.0L;
+    for (int k = 1; k < n; k++) {
+      Y[k] *= k;
+      y0 += k * Y[k]; yn += sgn * k * Y[k]; sgn = -sgn;
+    }
+    v[0] = (double)(0.5L * Y[n] * n + y0 / n);
+    v[(long)n * ts] = (double)(yn / n + 0.5L * sgn * n * Y[n]);
+    for (int j = 1; j < n; j++) {
+      long double acc = 0.0L;
+      for (int k = 1; k < n; k++) acc += Y[k] * st[((long)j * k) % (2 * n)];
+      v[j * ts] = (double)(2.0L * acc / (2.0L * n * st[j]));
+    }
+  }
+  free(Y); free(ct); free(st);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* elliptic.C:372-434 SetupBC: local / global(interior) / dirichlet(boundary) */
+/* index sets in BlockIt (row-major) order.                                   */
+/* ------------------------------------------------------------------------- */
+long orc_local_size(int d, const int *dims) { long n = 1; for (int i = 0; i < d; i++) n *= dims[i]; return n; }
+long orc_global_size(int d, const int *dims) { long n = 1; for (int i = 0; i < d; i++) n *= (dims[i] > 2 ? dims[i] - 2 : 0); return n; }
+long orc_dirichlet_size(int d, const int *dims) { return orc_local_size(d, dims) - orc_global_size(d, dims); }
+
+/* ixL[l] = global index or -1 on the boundary (elliptic.C:399-407). */
+static int *build_ixL(int d, const int *dims, long N) {
+  int *ixL = (int *)malloc(sizeof(int) * (size_t)N);
+  int ind[16] = {0};
+  long g = 0;
+  for (long l = 0; l < N; l++) {
+    int bdy = 0;
+    for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == dims[j] - 1) bdy = 1;
+    ixL[l] = bdy ? -1 : (int)g++;
+    for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
+  }
+  return ixL;
+}
+
+static void par_for_pointwise(long N, int nthreads, void (*body)(long, long, void *), void *ctx) {
+  /* tiny helper so the pointwise passes honour nthreads too */
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+  for (int t = 0; t < nthreads; t++) {
+    long lo = N * t / nthreads, hi = N * (t + 1) / nthreads;
+    body(lo, hi, ctx);
+  }
+}
+
+typedef struct { int d; long N; const double *eta, *deta, *u, *gradu0; double *w; } flux_ctx;
+static void flux_body(long lo, long hi, void *vc) {
+  flux_ctx *c = (flux_ctx *)vc;
+  for (long i = lo; i < hi; i++)
+    for (int k = 0; k < c->d; k++) {               /* elliptic.C:319-323 */
+      double *uk = c->w + (long)(1 + k) * c->N;
+      uk[i] = c->eta[i] * uk[i] + c->deta[i] * c->u[i] * c->gradu0[(long)k * c->N + i];
+    }
+}
+
+typedef struct { long N; double *a; const double *b; } axpy_ctx;
+static void axpym1_body(long lo, long hi, void *vc) {
+  axpy_ctx *c = (axpy_ctx *)vc;
+  for (long i = lo; i < hi; i++) c->a[i] += -1.0 * c->b[i]; /* VecAXPY(w0,-1,t) elliptic.C:333 */
+}
+
+static int cheb_dims_dir(int d, const int *dims, int k, const double *x, double *y, int mode, int nthreads) {
+  return orc_cheb_mult(d, k, dims, x, y, mode, nthreads);  /* MatCreateCheb(comm,d,i,dim,...) elliptic.C:269-271 */
+}
+
+int orc_elliptic_mult(int d, const int *dims, const double *eta, const double *deta,
+                      const double *gradu0, const double *U, double *V, int mode, int nthreads) {
+  if (d < 1 || d > 10) return 4;
+  const long N = orc_local_size(d, dims);
+  int *ixL = build_ixL(d, dims, N);
+  double *w = (double *)malloc(sizeof(double) * (size_t)N * (2 + d));  /* c->w[2+d] elliptic.C:260,263 */
+  double *w0 = w;
+  int err = 0;
+  /* scatter GL then DL with dirichlet0 == 0 (elliptic.C:305-308) */
+  for (long l = 0; l < N; l++) w0[l] = ixL[l] >= 0 ? U[ixL[l]] : 0.0;
+  for (int k = 0; k < d && !err; k++) err = cheb_dims_dir(d, dims, k, w0, w + (long)(1 + k) * N, mode, nthreads);
+  flux_ctx fc = { d, N, eta, deta, w0, gradu0, w };
+  if (!err) par_for_pointwise(N, nthreads, flux_body, &fc);
+  memset(w0, 0, sizeof(double) * (size_t)N);             /* VecZeroEntries elliptic.C:330 */
+  double *t = w + (long)(1 + d) * N;
+  for (int k = 0; k < d && !err; k++) {                  /* elliptic.C:331-334 */
+    err = cheb_dims_dir(d, dims, k, w + (long)(1 + k) * N, t, mode, nthreads);
+    axpy_ctx ac = { N, w0, t };
+    par_for_pointwise(N, nthreads, axpym1_body, &ac);
+  }
+  for (long l = 0; l < N; l++) if (ixL[l] >= 0) V[ixL[l]] = w0[l];  /* scatter LG :336 */
+  free(w); free(ixL);
+  return err;
+}
+
+int orc_elliptic_function(int d, const int *dims, double gamma, double exponent,
+                          const double *dirichlet, const double *U, const double *b,
+                          double *rhs, double *eta_o, double *deta_o, double *gradu_o,
+                          int mode, int nthreads) {
+  if (d < 1 || d > 10) return 4;
+  const long N = orc_local_size(d, dims);
+  int *ixL = build_ixL(d, dims, N);
+  double *w = (double *)malloc(sizeof(double) * (size_t)N * (2 + d));
+  double *gradu = (double *)malloc(sizeof(double) * (size_t)N * d);
+  double *eta = (double *)malloc(sizeof(double) * (size_t)N);
+  double *deta = (double *)malloc(sizeof(double) * (size_t)N);
+  double *w0 = w;
+  int err = 0;
+  long dd = 0;
+  for (long l = 0; l < N; l++) {                          /* elliptic.C:490-493 */
+    if (ixL[l] >= 0) w0[l] = U[ixL[l]];
+    else { w0[l] = dirichlet ? dirichlet[dd] : 0.0; dd++; }
+  }
+  for (int k = 0; k < d && !err; k++) err = cheb_dims_dir(d, dims, k, w0, gradu + (long)k * N, mode, nthreads); /* :497-499 */
+  for (long i = 0; i < N; i++) {                          /* elliptic.C:507-513 */
+    eta[i] = 1.0 + gamma * pow(w0[i], exponent);
+    deta[i] = exponent * gamma * pow(w0[i], exponent - 1.0);
+    for (int k = 0; k < d; k++) w[(long)(1 + k) * N + i] = eta[i] * gradu[(long)k * N + i];
+  }
+  memset(w0, 0, sizeof(double) * (size_t)N);
+  double *t = w + (long)(1 + d) * N;
+  for (int k = 0; k < d && !err; k++) {                  /* elliptic.C:521-524 */
+    err = cheb_dims_dir(d, dims, k, w + (long)(1 + k) * N, t, mode, nthreads);
+    for (long i = 0; i < N; i++) w0[i] += -1.0 * t[i];
+  }
+  for (long l = 0; l < N; l++) if (ixL[l] >= 0) rhs[ixL[l]] = w0[l];
+  const long G = orc_global_size(d, dims);
+  if (b) for (long g = 0; g < G; g++) rhs[g] += -1.0 * b[g];  /* VecAXPY(rhs,-1,b) :530 */
+  if (eta_o) memcpy(eta_o, eta, sizeof(double) * (size_t)N);
+  if (deta_o) memcpy(deta_o, deta, sizeof(double) * (size_t)N);
+  if (gradu_o) memcpy(gradu_o, gradu, sizeof(double) * (size_t)N * d);
+  free(w); free(gradu); free(eta); free(deta); free(ixL);
+  return err;
+}
+
+int orc_elliptic_exact(int d, const int *dims, int exact, double gamma, double exponent,
+                       double cos_scale, double *u, double *u2, double *dirichlet) {
+  if (d < 1 || d > 10) return 4;
+  const long N = orc_local_size(d, dims);
+  int *ixL = build_ixL(d, dims, N);
+  int ind[16] = {0};
+  double s = 0.5;                                         /* elliptic.C:605-610 */
+  if (exact == 0 || exact == 3) s *= cos_scale;
+  long dd = 0;
+  for (long l = 0; l < N; l++) {
+    double x[16];
+    for (int j = 0; j < d; j++) x[j] = cos(ind[j] * ORC_PI / (dims[j] - 1)); /* elliptic.C:279 */
+    double v = 0.0, w = 0.0, z;
+    switch (exact) {
+      case 0: {                                           /* elliptic.C:620-632 */
+        v = 1.0; w = 0.0;
+        for (int j = 0; j < d; j++) v *= cos(s * ORC_PI * x[j]);
+        const double eta = 1.0 + gamma * pow(v, exponent);
+        const double deta = (fabs(exponent) < 1e-10) ? 0.0 : gamma * exponent * pow(v, exponent - 1.0);
+        for (int j = 0; j < d; j++) {
+          double dv = 1.0;
+          for (int k = 0; k < d; k++) dv *= (k == j) ? -s * ORC_PI * sin(s * ORC_PI * x[k]) : cos(s * ORC_PI * x[k]);
+          const double d2v = -(s * ORC_PI) * (s * ORC_PI) * v;
+          w += deta * dv * dv + eta * d2v;
+        }
+        w = -w;
+      } break;
+      case 1:                                             /* elliptic.C:633-643 */
+        v = 1.0; w = 0.0;
+        for (int j = 0; j < d; j++) {
+          v *= (1 - x[j]) * (1 + x[j]);
+          z = 1.0;
+          for (int k = 0; k < d; k++) if (k != j) z *= 2.0 * (1 - x[k]) * (1 + x[k]);
+          w += z;
+        }
+        break;
+      case 2:                                             /* elliptic.C:644-655 */
+        v = 1.0; w = 0.0;
+        for (int j = 0; j < d; j++) {
+          v *= pow(x[j], 4 + j);
+          z = 1.0;
+          for (int k = 0; k < d; k++) {
+            if (k == j) z *= (4 + k) * (3 + k) * pow(x[k], 2 + k);
+            else z *= pow(x[k], 4 + k);
+          }
+          w -= z;
+        }
+        break;
+      default:
+        free(ixL); return 5;
+    }
+    if (ixL[l] >= 0) { if (u) u[ixL[l]] = v; if (u2) u2[ixL[l]] = w; }
+    else { if (dirichlet) dirichlet[dd] = v; dd++; }
+    for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
+  }
+  free(ixL);
+  return 0;
+}
