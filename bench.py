@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- spectral matvecs/s of the 3-D Chebyshev Poisson operator apply on MI355X.
+
+One "step" = one MatMult_Elliptic (elliptic.C:297-339) on the -dim P,P,P grid with the linear
+Poisson state (gamma = 0: eta == 1, deta == 0), global in/out vectors resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W            (N = 1: whole 256^3 grid on one GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+                                                           (N > 1: the same 256^3 grid slab-split
+                                                            over N ranks, RCCL all-to-all transposes;
+                                                            strong scaling)
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (cheb_sweep_kernel) with the
+algorithmic bytes of SURVEY 8(d): 112 B/point per matvec = 6 sweep launches; `cpu_baseline`
+times the CPU oracle (a port of the reference's pass structure; FFTW/PETSc are not installed)
+on this box's host cores, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK = 78.6e12   # flop/s, v_mfma_f64_16x16x4_f64 dense peak (= FP64 vector peak)
+BYTES_PER_POINT = 112.0    # six-sweep Poisson matvec
+SEED = 20240229
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=256, help="points per dimension P (BASELINE: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(P, threads):
+    """Oracle (port of chebyshev.c + MatMult_Elliptic pass structure) on the host: one matvec."""
+    import numpy as np
+    import oracle_lib as orc
+    dims = (P, P, P)
+    _, G, _ = orc.sizes(dims)
+    U = np.random.default_rng(SEED).standard_normal(G)
+    t0 = time.perf_counter()
+    orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "matvecs/s", "cores": threads, "kind": "port",
+            "sample": "1 full %d^3 Poisson matvec (6 ChebMult + pointwise passes), oracle FAST path, %.1f s" % (P, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    sp = ge.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    P = args.size
+    dims = (P, P, P)
+    if world == 1:
+        op = sp.EllipticOp(dims)
+        g = torch.Generator(device="cuda").manual_seed(SEED)
+        U = torch.randn(op.global_size, dtype=torch.float64, device="cuda", generator=g)
+        V = torch.empty_like(U)
+        step = lambda: op.mult(U, V)
+        launches_per_step = 6
+        parallelism = "single"
+    else:
+        dsp = ge.load_dist()
+        op = dsp.DistPoissonOp(dims, backend=dsp.HipBackend(sp))
+        U = op.random_input(SEED)
+        V = torch.empty_like(U)
+        step = lambda: op.mult(U, V)
+        launches_per_step = 6
+        parallelism = "slab%d+all2all" % world
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = t.item()
+    assert torch.isfinite(V).all()
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = args.steps / wall
+        npts = float(P) ** 3
+        # dominant kernel: cheb_sweep_kernel, 6 launches per matvec on torch's current stream, timed
+        # with HIP events around the K steps; algorithmic bytes per launch = 112*P^3/6
+        launch_s = (dev_ms * 1e-3) / (args.steps * launches_per_step)
+        alg_bytes_launch = BYTES_PER_POINT * npts / 6.0 / world
+        achieved = alg_bytes_launch / launch_s
+        flops_launch = float(P) * npts / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
+        out = {
+            "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
+            "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D Poisson MatMult_Elliptic -dim %d,%d,%d (gamma=0), global N(0,1) input seed %d" % (P, P, P, SEED),
+                       "P": P, "parallelism": parallelism, "launches_per_step": launches_per_step},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "cheb_sweep_kernel", "avg_launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "mfma_f64_tflops": flops_launch / launch_s / 1e12,
+                         "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},
+            "device_ms_per_step": dev_ms / args.steps,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

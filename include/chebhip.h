@@ -1,0 +1,118 @@
+/*
+ * chebhip.h -- C ABI of libchebhip.so: the MI355X (gfx950) implementation of
+ * the matrix-free Chebyshev spectral operator apply of jedbrown/spectral-petsc.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference
+ * interface it replaces (file:line relative to the reference tree).  The
+ * PETSc-level symbols of chebyshev.h:27-34 (MatCreateCheb / ChebMult /
+ * ChebDestroy ...) are a thin adapter over these calls: see
+ * adapter/chebyshev_petsc.c and INTEGRATION.md.
+ *
+ * Conventions
+ *  - all data IEEE float64; tensors row-major, LAST listed dim fastest
+ *    (chebyshev.c:107-120); grid index i along a dim is x_i = cos(i pi/(P-1)).
+ *  - *_dev pointers are device (HBM) pointers; `stream` is a hipStream_t passed
+ *    as void* (NULL = default stream).  Device-pointer calls are asynchronous
+ *    on that stream; *_host calls stage through device memory and return after
+ *    the result is in the host buffer.
+ *  - every call returns 0 on success or a CHEBHIP_ERR_* code; nothing throws or
+ *    exits across the ABI.  chebhip_last_error() returns a message for the
+ *    calling thread's most recent failure.
+ *  - a handle may be used from one host thread at a time (the reference's ctx
+ *    is likewise non-reentrant: one mutable work buffer, chebyshev.h:23).
+ *  - there is NO CPU fallback: without a usable HIP device the create calls
+ *    fail with CHEBHIP_ERR_DEVICE.
+ */
+#ifndef CHEBHIP_H
+#define CHEBHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  CHEBHIP_OK = 0,
+  CHEBHIP_ERR_SIZE = 1,     /* n < 2              (chebyshev.c:18,98)  -> PETSC_ERR_USER */
+  CHEBHIP_ERR_TDIM = 2,     /* tr out of range    (chebyshev.c:106)    -> PETSC_ERR_USER */
+  CHEBHIP_ERR_DIMS = 3,     /* bad dims / product (chebyshev.c:122)    -> PETSC_ERR_USER */
+  CHEBHIP_ERR_ARG = 4,      /* NULL handle/pointer, unsupported value  -> PETSC_ERR_ARG_WRONG */
+  CHEBHIP_ERR_DEVICE = 5,   /* HIP runtime failure / no device         -> PETSC_ERR_LIB */
+  CHEBHIP_ERR_MEMORY = 6    /* allocation failure                      -> PETSC_ERR_MEM */
+};
+
+const char *chebhip_last_error(void);
+/* Library/ABI version (major*100 + minor) and the offload arch it was built for. */
+int chebhip_version(void);
+const char *chebhip_arch(void);
+
+/* ------------------------------------------------------------------------- */
+/* Kernel level: the N-D Chebyshev derivative (chebyshev.h:18-24,31-34).      */
+/* ------------------------------------------------------------------------- */
+typedef struct cheb_plan cheb_plan;
+
+/* Replaces MatCreateCheb (chebyshev.c:89-138) and, for rank 1, MatCreateChebD1
+ * (chebyshev.c:8-33).  dims is copied.  Errors as chebyshev.c:98,106,122. */
+int cheb_plan_create(int rank, int tr, const int *dims, cheb_plan **out);
+
+/* Replaces ChebMult (chebyshev.c:142-199) / ChebD1Mult (:37-71):
+ * y = d/dx_tr x.  x and y are distinct N-element arrays, x is not modified. */
+int cheb_apply(cheb_plan *plan, const double *x_dev, double *y_dev, void *stream);
+int cheb_apply_host(cheb_plan *plan, const double *x_host, double *y_host);
+
+/* Replaces ChebDestroy (chebyshev.c:223-235) / ChebD1Destroy (:75-85). */
+int cheb_plan_destroy(cheb_plan *plan);
+
+/* Number of elements N = prod(dims) the plan was created for. */
+long cheb_plan_size(const cheb_plan *plan);
+
+/* ------------------------------------------------------------------------- */
+/* Operator level: the scalar elliptic MatShell (elliptic.C:78-86,250-293).   */
+/* Vectors at this boundary are the reference's GLOBAL vectors: interior      */
+/* nodes only, row-major (SetupBC, elliptic.C:372-434).  All work vectors     */
+/* (w[2+d], gradu[d], eta, deta) live in HBM inside the handle.               */
+/* ------------------------------------------------------------------------- */
+typedef struct ell_op ell_op;
+
+/* Replaces MatCreate_Elliptic (elliptic.C:250-293) with the homogeneous
+ * Dirichlet boundary function DirichletBdy (:468-476); 1 <= d <= 10 as the
+ * driver allows (elliptic.C:137).  State after create: eta = 1, deta = 0
+ * (elliptic.C:265-266), gradu = 0, dirichlet values = 0. */
+int ell_op_create(int d, const int *dims, ell_op **out);
+int ell_op_destroy(ell_op *op);                       /* MatDestroy_Elliptic, elliptic.C:343-368 */
+
+long ell_op_local_size(const ell_op *op);             /* N  = prod dims                 */
+long ell_op_global_size(const ell_op *op);            /* g  = prod (dims-2): MatShell n */
+long ell_op_dirichlet_size(const ell_op *op);         /* N - g                          */
+
+/* Replaces MatMult_Elliptic (elliptic.C:297-339): V = A(eta,deta,gradu) U. */
+int ell_op_mult(ell_op *op, const double *U_dev, double *V_dev, void *stream);
+int ell_op_mult_host(ell_op *op, const double *U_host, double *V_host);
+
+/* Replaces FormFunction (elliptic.C:481-533): rhs = F(U) - b, and refreshes the
+ * operator state eta, deta, gradu used by later ell_op_mult calls.  b may be
+ * NULL (treated as 0). */
+int ell_op_function(ell_op *op, double gamma, double exponent, const double *U_dev,
+                    const double *b_dev, double *rhs_dev, void *stream);
+int ell_op_function_host(ell_op *op, double gamma, double exponent, const double *U_host,
+                         const double *b_host, double *rhs_host);
+
+/* Sets c->dirichlet (elliptic.C:462,667-668): compact boundary values in
+ * BlockIt (row-major) order, ell_op_dirichlet_size() doubles, HOST pointer. */
+int ell_op_set_dirichlet(ell_op *op, const double *values_host);
+
+/* Copies operator state to the host for inspection: which = 0 eta, 1 deta,
+ * 2+k gradu[k] (each N doubles). */
+int ell_op_get_state(ell_op *op, int which, double *dst_host);
+/* Overwrites operator state from the host (same `which` codes). */
+int ell_op_set_state(ell_op *op, int which, const double *src_host);
+
+/* ------------------------------------------------------------------------- */
+/* Instrumentation (the reference has none: SURVEY 5.1).                      */
+/* ------------------------------------------------------------------------- */
+/* Number of sweep-kernel launches issued by this process so far. */
+long chebhip_launch_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference interface over the C ABI of libchebhip.so.
+
+The product is the C-ABI shared library (include/chebhip.h); this module is the
+thin ctypes binding the tests and bench.py use, shaped after the reference's
+operator interface:
+
+  ChebPlan(dims, tr).mult(x, y)        <-> MatCreateCheb / ChebMult / ChebDestroy
+                                           (chebyshev.h:31-34, chebyshev.c:89-235)
+  EllipticOp(dims).mult(U, V)          <-> MatCreate_Elliptic / MatMult_Elliptic
+                                           (elliptic.C:250-339)
+  EllipticOp.function(U, b, rhs, ...)  <-> FormFunction (elliptic.C:481-533)
+
+Device vectors are torch.float64 CUDA(HIP) tensors; torch is used only for
+device memory and streams.  There is no CPU fallback: if libchebhip.so is
+missing or no GPU is usable, construction raises.
+
+The directory name carries a hyphen, so import it with `load()` from
+__graft_entry__.py (importlib by path) rather than `import`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchebhip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+# every symbol include/chebhip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "chebhip_last_error", "chebhip_version", "chebhip_arch", "chebhip_launch_count",
+    "cheb_plan_create", "cheb_apply", "cheb_apply_host", "cheb_plan_destroy", "cheb_plan_size",
+    "ell_op_create", "ell_op_destroy", "ell_op_local_size", "ell_op_global_size",
+    "ell_op_dirichlet_size", "ell_op_mult", "ell_op_mult_host", "ell_op_function",
+    "ell_op_function_host", "ell_op_set_dirichlet", "ell_op_get_state", "ell_op_set_state",
+]
+
+
+class ChebhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("chebhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile libchebhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library; fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ChebhipError(-1, "libchebhip.so not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.chebhip_last_error.restype = C.c_char_p
+        L.chebhip_arch.restype = C.c_char_p
+        L.chebhip_launch_count.restype = C.c_long
+        L.cheb_plan_create.argtypes = [C.c_int, C.c_int, ip, C.POINTER(vp)]
+        L.cheb_apply.argtypes = [vp, vp, vp, vp]
+        L.cheb_apply_host.argtypes = [vp, dp, dp]
+        L.cheb_plan_destroy.argtypes = [vp]
+        L.cheb_plan_size.argtypes = [vp]
+        L.cheb_plan_size.restype = C.c_long
+        L.ell_op_create.argtypes = [C.c_int, ip, C.POINTER(vp)]
+        L.ell_op_destroy.argtypes = [vp]
+        for f in (L.ell_op_local_size, L.ell_op_global_size, L.ell_op_dirichlet_size):
+            f.argtypes = [vp]
+            f.restype = C.c_long
+        L.ell_op_mult.argtypes = [vp, vp, vp, vp]
+        L.ell_op_mult_host.argtypes = [vp, dp, dp]
+        L.ell_op_function.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.ell_op_function_host.argtypes = [vp, C.c_double, C.c_double, dp, dp, dp]
+        L.ell_op_set_dirichlet.argtypes = [vp, dp]
+        L.ell_op_get_state.argtypes = [vp, C.c_int, dp]
+        L.ell_op_set_state.argtypes = [vp, C.c_int, dp]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise ChebhipError(rc, lib().chebhip_last_error().decode())
+
+
+def _ints(v):
+    return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def _np_dp(a):
+    import numpy as np
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _dev_ptr(t, n):
+    import torch
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    assert t.numel() == n, "expected %d elements, got %d" % (n, t.numel())
+    return t.data_ptr()
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ChebPlan:
+    """y = d/dx_tr x on a row-major tensor of shape dims (MatCreateCheb, chebyshev.c:89-138)."""
+
+    def __init__(self, dims, tr):
+        self.dims = tuple(int(d) for d in dims)
+        self.tr = int(tr)
+        h = C.c_void_p()
+        _chk(lib().cheb_plan_create(len(self.dims), self.tr, _ints(self.dims), C.byref(h)))
+        self._h = h
+        self.size = lib().cheb_plan_size(h)
+
+    def mult(self, x, y):
+        """ChebMult (chebyshev.c:142-199) on device tensors, asynchronous on torch's current stream."""
+        _chk(lib().cheb_apply(self._h, _dev_ptr(x, self.size), _dev_ptr(y, self.size), _stream()))
+        return y
+
+    def mult_host(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.size
+        y = np.empty_like(x)
+        _chk(lib().cheb_apply_host(self._h, _np_dp(x), _np_dp(y)))
+        return y
+
+    def destroy(self):
+        if self._h:
+            lib().cheb_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class EllipticOp:
+    """The scalar elliptic MatShell (MatCreate_Elliptic, elliptic.C:250-293)."""
+
+    def __init__(self, dims):
+        self.dims = tuple(int(d) for d in dims)
+        h = C.c_void_p()
+        _chk(lib().ell_op_create(len(self.dims), _ints(self.dims), C.byref(h)))
+        self._h = h
+        self.local_size = lib().ell_op_local_size(h)
+        self.global_size = lib().ell_op_global_size(h)
+        self.dirichlet_size = lib().ell_op_dirichlet_size(h)
+
+    def mult(self, U, V):
+        """MatMult_Elliptic (elliptic.C:297-339) on device tensors of global_size."""
+        _chk(lib().ell_op_mult(self._h, _dev_ptr(U, self.global_size), _dev_ptr(V, self.global_size), _stream()))
+        return V
+
+    def mult_host(self, U):
+        import numpy as np
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        assert U.size == self.global_size
+        V = np.empty_like(U)
+        _chk(lib().ell_op_mult_host(self._h, _np_dp(U), _np_dp(V)))
+        return V
+
+    def function(self, U, b, rhs, gamma=0.0, exponent=2.0):
+        """FormFunction (elliptic.C:481-533) on device tensors; b may be None."""
+        bp = _dev_ptr(b, self.global_size) if b is not None else None
+        _chk(lib().ell_op_function(self._h, gamma, exponent, _dev_ptr(U, self.global_size), bp,
+                                   _dev_ptr(rhs, self.global_size), _stream()))
+        return rhs
+
+    def function_host(self, U, b=None, gamma=0.0, exponent=2.0):
+        import numpy as np
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        rhs = np.empty_like(U)
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float64)
+            bp = _np_dp(b)
+        _chk(lib().ell_op_function_host(self._h, gamma, exponent, _np_dp(U), bp, _np_dp(rhs)))
+        return rhs
+
+    def set_dirichlet(self, values):
+        import numpy as np
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        assert values.size == self.dirichlet_size
+        _chk(lib().ell_op_set_dirichlet(self._h, _np_dp(values)))
+
+    def get_state(self, which):
+        import numpy as np
+        out = np.empty(self.local_size)
+        _chk(lib().ell_op_get_state(self._h, which, _np_dp(out)))
+        return out
+
+    def set_state(self, which, values):
+        import numpy as np
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        assert values.size == self.local_size
+        _chk(lib().ell_op_set_state(self._h, which, _np_dp(values)))
+
+    def destroy(self):
+        if self._h:
+            lib().ell_op_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

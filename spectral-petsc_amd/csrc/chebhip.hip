@@ -1,0 +1,430 @@
+// chebhip.hip -- C ABI of libchebhip.so (see include/chebhip.h) and the small pointwise kernels
+// that sit between sweeps.  All heavy arithmetic is in sweep.hip.
+#include "../../include/chebhip.h"
+#include "sweep.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace chebhip;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char *chebhip_last_error(void) { return g_err.c_str(); }
+extern "C" int chebhip_version(void) { return 100; }
+extern "C" const char *chebhip_arch(void) { return "gfx950"; }
+extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
+
+static int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(CHEBHIP_ERR_DEVICE, "no usable HIP device (%s); libchebhip has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-level plan (MatCreateCheb / ChebMult / ChebDestroy, chebyshev.c:89-235)
+// ---------------------------------------------------------------------------------------------
+struct cheb_plan {
+  int rank = 0, tr = 0;
+  std::vector<int> dims;
+  long N = 0;
+  unsigned inner = 1, ncols = 0;
+  DiffMat mat;
+  double *hx = nullptr, *hy = nullptr;  // staging for the host-pointer path
+};
+
+static int check_geom(int rank, int tr, const int *dims, long *N, unsigned *inner) {
+  if (!dims || rank < 1 || rank > 16) return fail(CHEBHIP_ERR_DIMS, "rank = %d must be in 1..16", rank);
+  if (!(0 <= tr && tr < rank)) return fail(CHEBHIP_ERR_TDIM, "tdim out of range");              // chebyshev.c:106
+  long n = 1, in = 1;
+  for (int r = 0; r < rank; r++) {
+    if (dims[r] < 1) return fail(CHEBHIP_ERR_DIMS, "dims[%d] = %d must be >= 1", r, dims[r]);
+    n *= dims[r];
+    if (r > tr) in *= dims[r];
+    if (n > 0x7fffffffL) return fail(CHEBHIP_ERR_DIMS, "tensor of more than 2^31-1 points");
+  }
+  if (n < 2 || dims[tr] < 2) return fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 2", n);       // chebyshev.c:18,98
+  if (dims[tr] > 256)
+    return fail(CHEBHIP_ERR_ARG, "dims[tr] = %d: this build keeps the differentiation matrix in registers and supports <= 256 points per line", dims[tr]);
+  *N = n; *inner = (unsigned)in;
+  return 0;
+}
+
+extern "C" int cheb_plan_create(int rank, int tr, const int *dims, cheb_plan **out) {
+  if (!out) return fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  long N; unsigned inner;
+  int rc = check_geom(rank, tr, dims, &N, &inner);
+  if (rc) return rc;
+  if ((rc = require_device())) return rc;
+  cheb_plan *p = new (std::nothrow) cheb_plan;
+  if (!p) return fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  p->rank = rank; p->tr = tr; p->dims.assign(dims, dims + rank);
+  p->N = N; p->inner = inner; p->ncols = (unsigned)(N / dims[tr]);
+  hipError_t e = diffmat_create(dims[tr], &p->mat);
+  if (e != hipSuccess) { delete p; return fail(CHEBHIP_ERR_DEVICE, "diffmat_create: %s", hipGetErrorString(e)); }
+  *out = p;
+  return 0;
+}
+
+extern "C" long cheb_plan_size(const cheb_plan *p) { return p ? p->N : -1; }
+
+extern "C" int cheb_apply(cheb_plan *p, const double *x, double *y, void *stream) {
+  if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct (as every ChebMult call site)");
+  SweepParams sp = {};
+  sp.ncols = p->ncols; sp.inner = p->inner;
+  sp.in0 = x; sp.out = y; sp.alpha = 1.0;
+  sp.in_mode = IN_PLAIN; sp.out_mode = OUT_STORE;
+  HIPCHK(sweep_launch(p->mat, sp, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int cheb_apply_host(cheb_plan *p, const double *x, double *y) {
+  if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  const size_t bytes = (size_t)p->N * sizeof(double);
+  if (!p->hx) { HIPCHK(hipMalloc((void **)&p->hx, bytes)); HIPCHK(hipMalloc((void **)&p->hy, bytes)); }
+  HIPCHK(hipMemcpy(p->hx, x, bytes, hipMemcpyHostToDevice));
+  int rc = cheb_apply(p, p->hx, p->hy, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(y, p->hy, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int cheb_plan_destroy(cheb_plan *p) {
+  if (!p) return 0;
+  diffmat_destroy(&p->mat);
+  if (p->hx) (void)hipFree(p->hx);
+  if (p->hy) (void)hipFree(p->hy);
+  delete p;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise kernels of the elliptic callbacks
+// ---------------------------------------------------------------------------------------------
+// w0 = VecScatter(GL)(U) then VecScatter(DL)(dirichlet): elliptic.C:486-493.
+__global__ void k_gather_bc(long N, const int *__restrict__ ixL, const double *__restrict__ U,
+                            const double *__restrict__ dirloc, double *__restrict__ w0) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const int g = ixL[i];
+    w0[i] = g >= 0 ? U[g] : (dirloc ? dirloc[i] : 0.0);
+  }
+}
+
+// eta = 1 + gamma u^e, deta = e gamma u^(e-1): elliptic.C:508-509.
+__global__ void k_coeff(long N, double gamma, double expo, const double *__restrict__ u,
+                        double *__restrict__ eta, double *__restrict__ deta) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const double v = u[i];
+    eta[i] = 1.0 + gamma * pow(v, expo);
+    deta[i] = expo * gamma * pow(v, expo - 1.0);
+  }
+}
+
+__global__ void k_fill(long N, double v, double *__restrict__ a) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) a[i] = v;
+}
+
+// rhs -= b : VecAXPY(rhs,-1,b) elliptic.C:530
+__global__ void k_axpy(long N, double alpha, const double *__restrict__ x, double *__restrict__ y) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
+static inline unsigned pw_grid(long N) { long g = (N + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+// ---------------------------------------------------------------------------------------------
+// operator level: MatElliptic (elliptic.C:78-86)
+// ---------------------------------------------------------------------------------------------
+enum CoeffMode { COEFF_UNIT = 0, COEFF_FULL = 1 };
+
+struct ell_op {
+  int d = 0;
+  std::vector<int> dims;
+  long N = 0, G = 0;
+  std::map<int, DiffMat> mats;          // one matrix per distinct extent
+  std::vector<unsigned> inner, ncols;   // per direction
+  std::vector<int *> gcol;              // per direction: device [ncols_k]
+  std::vector<long> gstride;            // per direction, in the global (interior) layout
+  int *ixL = nullptr;                   // device [N]: global index or -1 (c->isL, elliptic.C:426)
+  std::vector<double *> g;              // d work vectors: gradients / fluxes (c->w[1..d])
+  double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
+  double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
+  std::vector<double *> gradu;          // c->gradu[d], lazily allocated
+  double *eta = nullptr, *deta = nullptr, *dirloc = nullptr;
+  CoeffMode mode = COEFF_UNIT;
+  double *hU = nullptr, *hV = nullptr, *hB = nullptr;  // staging for host-pointer calls
+};
+
+static int ell_alloc_state(ell_op *op) {
+  const size_t bytes = (size_t)op->N * sizeof(double);
+  if (!op->w0) HIPCHK(hipMalloc((void **)&op->w0, bytes));
+  if (!op->eta) {
+    HIPCHK(hipMalloc((void **)&op->eta, bytes));
+    HIPCHK(hipMalloc((void **)&op->deta, bytes));
+    hipLaunchKernelGGL(k_fill, dim3(pw_grid(op->N)), dim3(256), 0, nullptr, op->N, 1.0, op->eta);   // VecSet(eta,1) elliptic.C:265
+    HIPCHK(hipMemset(op->deta, 0, bytes));                                                           // VecSet(deta,0) :266
+  }
+  if (op->gradu.empty()) {
+    op->gradu.assign(op->d, nullptr);
+    for (int k = 0; k < op->d; k++) {
+      HIPCHK(hipMalloc((void **)&op->gradu[k], bytes));
+      HIPCHK(hipMemset(op->gradu[k], 0, bytes));
+    }
+  }
+  return 0;
+}
+
+extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
+  if (!out) return fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!dims || d < 1 || d > 10) return fail(CHEBHIP_ERR_DIMS, "d = %d must be in 1..10 (elliptic.C:137)", d);
+  long N = 1, G = 1;
+  for (int k = 0; k < d; k++) {
+    long nk; unsigned ik;
+    int rc = check_geom(d, k, dims, &nk, &ik);
+    if (rc) return rc;
+    N *= dims[k]; G *= (dims[k] > 2 ? dims[k] - 2 : 0);
+  }
+  int rc = require_device();
+  if (rc) return rc;
+  ell_op *op = new (std::nothrow) ell_op;
+  if (!op) return fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  op->d = d; op->dims.assign(dims, dims + d); op->N = N; op->G = G;
+  // from here on failures go through ell_op_destroy
+#define OPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ell_op_destroy(op); \
+    return fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+  for (int k = 0; k < d; k++)
+    if (!op->mats.count(dims[k])) { DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m; }
+  // SetupBC (elliptic.C:372-434): ixL in BlockIt order; interior strides of the global vector
+  std::vector<long> gs(d, 1);
+  for (int k = d - 2; k >= 0; k--) gs[k] = gs[k + 1] * (dims[k + 1] - 2);
+  {
+    std::vector<int> ixL((size_t)N);
+    std::vector<int> ind(d, 0);
+    long g = 0;
+    for (long l = 0; l < N; l++) {
+      bool bdy = false;
+      for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == dims[j] - 1) bdy = true;
+      ixL[l] = bdy ? -1 : (int)g++;
+      for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
+    }
+    OPCHK(hipMalloc((void **)&op->ixL, (size_t)N * sizeof(int)));
+    OPCHK(hipMemcpy(op->ixL, ixL.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
+  }
+  op->inner.resize(d); op->ncols.resize(d); op->gcol.assign(d, nullptr); op->gstride = gs;
+  for (int k = 0; k < d; k++) {
+    unsigned in = 1; for (int r = k + 1; r < d; r++) in *= dims[r];
+    op->inner[k] = in; op->ncols[k] = (unsigned)(N / dims[k]);
+    // line c of direction k <-> multi-index over the other dims (row-major, dim k removed)
+    std::vector<int> tab(op->ncols[k]);
+    std::vector<int> ind(d, 0);
+    for (unsigned c = 0; c < op->ncols[k]; c++) {
+      bool interior = true; long gi = 0;
+      for (int r = 0; r < d; r++) {
+        if (r == k) continue;
+        if (ind[r] == 0 || ind[r] == dims[r] - 1) interior = false;
+        gi += (long)(ind[r] - 1) * gs[r];
+      }
+      tab[c] = (interior && dims[k] > 2) ? (int)gi : -1;
+      for (int r = d - 1; r >= 0; r--) { if (r == k) continue; if (++ind[r] < dims[r]) break; ind[r] = 0; }
+    }
+    OPCHK(hipMalloc((void **)&op->gcol[k], tab.size() * sizeof(int)));
+    OPCHK(hipMemcpy(op->gcol[k], tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  op->g.assign(d, nullptr);
+  for (int k = 0; k < d; k++) OPCHK(hipMalloc((void **)&op->g[k], (size_t)N * sizeof(double)));
+  OPCHK(hipMalloc((void **)&op->W, (size_t)N * sizeof(double)));
+#undef OPCHK
+  *out = op;
+  return 0;
+}
+
+extern "C" int ell_op_destroy(ell_op *op) {
+  if (!op) return 0;
+  for (auto &kv : op->mats) diffmat_destroy(&kv.second);
+  for (auto p : op->gcol) if (p) (void)hipFree(p);
+  for (auto p : op->g) if (p) (void)hipFree(p);
+  for (auto p : op->gradu) if (p) (void)hipFree(p);
+  double *singles[] = {op->W, op->w0, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
+  for (double *p : singles) if (p) (void)hipFree(p);
+  if (op->ixL) (void)hipFree(op->ixL);
+  delete op;
+  return 0;
+}
+
+extern "C" long ell_op_local_size(const ell_op *op) { return op ? op->N : -1; }
+extern "C" long ell_op_global_size(const ell_op *op) { return op ? op->G : -1; }
+extern "C" long ell_op_dirichlet_size(const ell_op *op) { return op ? op->N - op->G : -1; }
+
+// Divergence half shared by MatMult and FormFunction: out_global = -sum_k D_k f_k (+ optional -b).
+// in_mode selects how f_k is formed from op->g[k] / src[k] on load.
+static int ell_divergence(ell_op *op, int in_mode, double *const *src, double *out_global, hipStream_t st) {
+  const int d = op->d;
+  for (int k = 0; k < d; k++) {
+    SweepParams sp = {};
+    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+    sp.in0 = src[k]; sp.in1 = op->eta; sp.in2 = op->deta; sp.in3 = op->w0;
+    sp.in4 = op->gradu.empty() ? nullptr : op->gradu[k];
+    sp.in_mode = in_mode; sp.alpha = -1.0;                       // VecAXPY(w0,-1,.) elliptic.C:333
+    if (k == d - 1) {                                            // last term also does VecScatter LG (:336)
+      sp.out_mode = OUT_ACC_SCATTER; sp.out = out_global; sp.acc = (d > 1) ? op->W : nullptr;
+      sp.gcol = op->gcol[k]; sp.gstride = op->gstride[k];
+    } else if (k == 0) {                                         // 0 + (-1) t0
+      sp.out_mode = OUT_STORE; sp.out = op->W;
+    } else {
+      sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W;
+    }
+    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  }
+  return 0;
+}
+
+extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
+  if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (op->G == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int d = op->d;
+  if (op->mode == COEFF_UNIT) {
+    // eta == 1, deta == 0: f_k = g_k exactly; the gather is folded into the gradient loads
+    for (int k = 0; k < d; k++) {
+      SweepParams sp = {};
+      sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+      sp.in0 = U; sp.in_mode = IN_GATHER; sp.gcol = op->gcol[k]; sp.gstride = op->gstride[k];
+      sp.out = op->g[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+      HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+    }
+    return ell_divergence(op, IN_PLAIN, op->g.data(), V, st);
+  }
+  // general coefficients: the flux needs the local input w0 (elliptic.C:321)
+  hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U,
+                     (const double *)nullptr, op->w0);                          // dirichlet0 == 0
+  for (int k = 0; k < d; k++) {
+    SweepParams sp = {};
+    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+    sp.in0 = op->w0; sp.in_mode = IN_PLAIN; sp.out = op->g[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  }
+  return ell_divergence(op, IN_FLUX_FULL, op->g.data(), V, st);
+}
+
+extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const double *U,
+                               const double *b, double *rhs, void *stream) {
+  if (!op || !U || !rhs) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ell_alloc_state(op);
+  if (rc) return rc;
+  const int d = op->d;
+  hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U,
+                     (const double *)op->dirloc, op->w0);                        // elliptic.C:486-493
+  for (int k = 0; k < d; k++) {                                                 // gradu[k] = D_k w0 (:497-499)
+    SweepParams sp = {};
+    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+    sp.in0 = op->w0; sp.in_mode = IN_PLAIN; sp.out = op->gradu[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  }
+  hipLaunchKernelGGL(k_coeff, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, gamma, exponent,
+                     (const double *)op->w0, op->eta, op->deta);                 // :508-509
+  // eta stays exactly 1 and deta exactly 0 only when gamma == 0 and no pow() can produce inf/nan
+  const bool unit = (gamma == 0.0) && (exponent == std::floor(exponent)) && exponent >= 1.0;
+  op->mode = unit ? COEFF_UNIT : COEFF_FULL;
+  if (op->G == 0) return 0;
+  rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);               // w = eta*gradu (:511), :521-528
+  if (rc) return rc;
+  if (b) hipLaunchKernelGGL(k_axpy, dim3(pw_grid(op->G)), dim3(256), 0, st, op->G, -1.0, b, rhs);  // :530
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int ell_stage(ell_op *op) {
+  const size_t gb = (size_t)(op->G > 0 ? op->G : 1) * sizeof(double);
+  if (!op->hU) { HIPCHK(hipMalloc((void **)&op->hU, gb)); HIPCHK(hipMalloc((void **)&op->hV, gb)); HIPCHK(hipMalloc((void **)&op->hB, gb)); }
+  return 0;
+}
+
+extern "C" int ell_op_mult_host(ell_op *op, const double *U, double *V) {
+  if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  int rc = ell_stage(op); if (rc) return rc;
+  const size_t gb = (size_t)op->G * sizeof(double);
+  HIPCHK(hipMemcpy(op->hU, U, gb, hipMemcpyHostToDevice));
+  if ((rc = ell_op_mult(op, op->hU, op->hV, nullptr))) return rc;
+  HIPCHK(hipMemcpy(V, op->hV, gb, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int ell_op_function_host(ell_op *op, double gamma, double exponent, const double *U,
+                                    const double *b, double *rhs) {
+  if (!op || !U || !rhs) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  int rc = ell_stage(op); if (rc) return rc;
+  const size_t gb = (size_t)op->G * sizeof(double);
+  HIPCHK(hipMemcpy(op->hU, U, gb, hipMemcpyHostToDevice));
+  if (b) HIPCHK(hipMemcpy(op->hB, b, gb, hipMemcpyHostToDevice));
+  if ((rc = ell_op_function(op, gamma, exponent, op->hU, b ? op->hB : nullptr, op->hV, nullptr))) return rc;
+  HIPCHK(hipMemcpy(rhs, op->hV, gb, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int ell_op_set_dirichlet(ell_op *op, const double *values) {
+  if (!op || !values) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  // expand the compact BlockIt-ordered boundary vector (elliptic.C:399-403) to the local layout
+  std::vector<double> loc((size_t)op->N, 0.0);
+  std::vector<int> ind(op->d, 0);
+  long dd = 0;
+  for (long l = 0; l < op->N; l++) {
+    bool bdy = false;
+    for (int j = 0; j < op->d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) bdy = true;
+    if (bdy) loc[l] = values[dd++];
+    for (int j = op->d - 1; j >= 0; j--) { if (++ind[j] < op->dims[j]) break; ind[j] = 0; }
+  }
+  if (!op->dirloc) HIPCHK(hipMalloc((void **)&op->dirloc, (size_t)op->N * sizeof(double)));
+  HIPCHK(hipMemcpy(op->dirloc, loc.data(), (size_t)op->N * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int ell_state_ptr(ell_op *op, int which, double **p) {
+  int rc = ell_alloc_state(op);
+  if (rc) return rc;
+  if (which == 0) *p = op->eta;
+  else if (which == 1) *p = op->deta;
+  else if (which >= 2 && which < 2 + op->d) *p = op->gradu[which - 2];
+  else return fail(CHEBHIP_ERR_ARG, "which = %d out of range", which);
+  return 0;
+}
+
+extern "C" int ell_op_get_state(ell_op *op, int which, double *dst) {
+  if (!op || !dst) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(dst, p, (size_t)op->N * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int ell_op_set_state(ell_op *op, int which, const double *src) {
+  if (!op || !src) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
+  HIPCHK(hipMemcpy(p, src, (size_t)op->N * sizeof(double), hipMemcpyHostToDevice));
+  op->mode = COEFF_FULL;
+  return 0;
+}

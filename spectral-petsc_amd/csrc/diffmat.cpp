@@ -1,0 +1,91 @@
+// diffmat.cpp -- Chebyshev collocation differentiation matrix on the Gauss-Lobatto nodes
+// x_i = cos(i pi/n), split by parity and laid out as f64 MFMA operand fragments.
+//
+// The reference never forms this matrix: chebyshev.c:142-199 applies it as
+// DCT-I -> (times k) -> DST-I -> /(2n sin) plus two endpoint sums.  In exact arithmetic
+// that chain IS multiplication by D below (the derivative of the degree-n interpolant at
+// the nodes), so y = D x reproduces ChebMult to rounding.  P = 256 and 128 make the
+// logical FFT length 2(P-1) = 510 = 2*3*5*17 and 254 = 2*127, hostile to butterflies; a
+// dense product on the matrix cores, halved by the centro-antisymmetry of D, is both
+// faster on gfx950 and more accurate (see DESIGN.md "Why dense").
+//
+// Parity split (n = P-1, H = ceil(P/2)); for j < H with 2j != n:
+//     e_j = x_j + x_{n-j},  o_j = x_j - x_{n-j};   self-paired middle (2j == n): e_j = x_j, o_j = 0
+//     ME[i][j] = (D[i][j] + D[i][n-j]) / 2   (middle column: D[i][j])
+//     MO[i][j] = (D[i][j] - D[i][n-j]) / 2   (middle column: 0)
+// and because D[n-i][n-j] = -D[i][j]:
+//     y_i = (ME e)_i + (MO o)_i,      y_{n-i} = (MO o)_i - (ME e)_i,     i < H.
+#include "sweep.h"
+#include <cmath>
+#include <vector>
+
+namespace chebhip {
+
+static const long double PI_L = 3.14159265358979323846264338327950288L;
+
+// D[i][j] in long double.  Off-diagonal: (c_i/c_j) (-1)^(i+j) / (x_i - x_j) with
+// x_i - x_j = -2 sin((i+j) pi/2n) sin((i-j) pi/2n) (no cancellation); diagonal from the
+// closed forms  D00 = (2n^2+1)/6 = -Dnn,  Dii = -x_i / (2 sin^2(i pi/n)).
+static long double dentry(int i, int j, int n) {
+  if (i == j) {
+    if (i == 0) return (2.0L * n * n + 1.0L) / 6.0L;
+    if (i == n) return -(2.0L * n * n + 1.0L) / 6.0L;
+    long double s = sinl(PI_L * i / n);
+    return -cosl(PI_L * i / n) / (2.0L * s * s);
+  }
+  long double ci = (i == 0 || i == n) ? 2.0L : 1.0L;
+  long double cj = (j == 0 || j == n) ? 2.0L : 1.0L;
+  long double sgn = ((i + j) & 1) ? -1.0L : 1.0L;
+  long double dx = -2.0L * sinl(PI_L * (i + j) / (2.0L * n)) * sinl(PI_L * (i - j) / (2.0L * n));
+  return (ci / cj) * sgn / dx;
+}
+
+void diffmat_dense_host(int P, double *D) {
+  const int n = P - 1;
+  for (int i = 0; i < P; i++)
+    for (int j = 0; j < P; j++) D[(size_t)i * P + j] = (double)dentry(i, j, n);
+}
+
+hipError_t diffmat_create(int P, DiffMat *out) {
+  const int n = P - 1;
+  const int H = (P + 1) / 2;
+  int KS = 4;
+  while (4 * KS < H) KS *= 2;
+  const int MTP = KS / 4;
+  const size_t cnt = (size_t)MTP * KS * 64;
+  std::vector<double> fe(cnt, 0.0), fo(cnt, 0.0);
+  for (int mt = 0; mt < MTP; mt++)
+    for (int s = 0; s < KS; s++)
+      for (int l = 0; l < 64; l++) {
+        const int i = mt * 16 + (l & 15);  // output row held by this lane
+        const int j = 4 * s + (l >> 4);    // reduction index
+        if (i >= H || j >= H) continue;
+        long double me, mo;
+        if (2 * j == n) { me = dentry(i, j, n); mo = 0.0L; }
+        else {
+          const long double a = dentry(i, j, n), b = dentry(i, n - j, n);
+          me = 0.5L * (a + b); mo = 0.5L * (a - b);
+        }
+        fe[((size_t)mt * KS + s) * 64 + l] = (double)me;
+        fo[((size_t)mt * KS + s) * 64 + l] = (double)mo;
+      }
+  DiffMat m;
+  m.P = P; m.H = H; m.KS = KS; m.MTP = MTP;
+  hipError_t e = hipMalloc((void **)&m.fragE, cnt * sizeof(double));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void **)&m.fragO, cnt * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(m.fragE); return e; }
+  e = hipMemcpy(m.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(m.fragE); (void)hipFree(m.fragO); return e; }
+  *out = m;
+  return hipSuccess;
+}
+
+void diffmat_destroy(DiffMat *m) {
+  if (m->fragE) (void)hipFree(m->fragE);
+  if (m->fragO) (void)hipFree(m->fragO);
+  m->fragE = m->fragO = nullptr;
+}
+
+}  // namespace chebhip

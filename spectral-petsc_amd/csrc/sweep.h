@@ -1,0 +1,57 @@
+// sweep.h -- internal interface between the C-ABI layer and the gfx950 sweep kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace chebhip {
+
+// How one element of the line being differentiated is produced on load.
+enum InMode : int {
+  IN_PLAIN = 0,     // v = in0[a]
+  IN_GATHER = 1,    // v = interior ? in0_global[g] : 0            (VecScatter GL + dirichlet0, elliptic.C:305-308)
+  IN_FLUX_ETA = 2,  // v = in1[a] * in0[a]                         (eta * g, elliptic.C:511)
+  IN_FLUX_FULL = 3  // v = in1[a]*in0[a] + in2[a]*in3[a]*in4[a]    (eta*g + deta*u*du0, elliptic.C:321)
+};
+
+// What happens to one element r of the derivative on store.
+enum OutMode : int {
+  OUT_STORE = 0,        // out[a] = alpha*r
+  OUT_ACC = 1,          // out[a] = acc[a] + alpha*r               (VecAXPY, elliptic.C:333)
+  OUT_ACC_SCATTER = 2   // interior: out_global[g] = (acc ? acc[a] : 0) + alpha*r   (+ VecScatter LG, elliptic.C:336)
+};
+
+struct SweepParams {
+  int P;              // points along the transform dim
+  int H;              // ceil(P/2): even/odd half length
+  unsigned ncols;     // number of lines = N / P
+  unsigned inner;     // stride (elements) of the transform dim in the local layout
+  const double *in0, *in1, *in2, *in3, *in4;
+  double *out;
+  const double *acc;
+  const int *gcol;    // [ncols] global index of the (j=1) node of a line, -1 for boundary lines
+  long gstride;       // stride of the transform dim in the global (interior) layout
+  double alpha;
+  int in_mode, out_mode;
+  const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
+  unsigned ntiles;
+};
+
+// Host description of the even/odd split differentiation matrices for P points.
+struct DiffMat {
+  int P = 0, H = 0;
+  int KS = 0;          // k-steps of 4 (power of two >= 4 for the register-resident kernel)
+  int MTP = 0;         // padded m-tiles of 16 rows = KS/4
+  double *fragE = nullptr, *fragO = nullptr;  // device, [MTP][KS][64]
+};
+
+// Builds (in long double) and uploads the fragment-ordered matrices.  Returns hipSuccess or error.
+hipError_t diffmat_create(int P, DiffMat *out);
+void diffmat_destroy(DiffMat *m);
+// Host-side dense differentiation matrix (row-major P x P), for tests and the adapter.
+void diffmat_dense_host(int P, double *D);
+
+// Launches one sweep.  jfast selects the line-contiguous tiling.
+hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+
+long sweep_launch_count();
+
+}  // namespace chebhip

@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: libchebhip.so builds for gfx950, loads, and exports
+every symbol include/chebhip.h declares; argument errors follow chebyshev.c:98,106,122; and
+without a GPU the create calls fail loudly (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as ge
+
+sp = ge.load()
+
+
+@pytest.fixture(scope="module")
+def L():
+    ge.build()
+    return sp.lib()
+
+
+def _declared_functions():
+    txt = open(os.path.join(sp.INCLUDE_DIR, "chebhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", txt)))
+
+
+def test_header_symbols_exported(L):
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "libchebhip.so does not export %s" % n
+    assert sorted(sp.ABI_SYMBOLS) == names
+
+
+def test_version_arch(L):
+    assert L.chebhip_version() >= 100
+    assert L.chebhip_arch() == b"gfx950"
+
+
+def test_code_object_is_gfx950():
+    blob = open(sp.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"cheb_sweep_kernel" in blob
+
+
+def test_argument_errors(L):
+    """chebyshev.c:98 (n<2), :106 (tr range), bad dims -> distinct nonzero codes, checked before any device use."""
+    h = C.c_void_p()
+    ints = lambda v: (C.c_int * len(v))(*v)
+    assert L.cheb_plan_create(2, 2, ints([4, 4]), C.byref(h)) == 2
+    assert b"tdim out of range" in L.chebhip_last_error()
+    assert L.cheb_plan_create(2, -1, ints([4, 4]), C.byref(h)) == 2
+    assert L.cheb_plan_create(1, 0, ints([1]), C.byref(h)) == 1
+    assert b"must be >= 2" in L.chebhip_last_error()
+    assert L.cheb_plan_create(2, 0, ints([4, 0]), C.byref(h)) == 3
+    assert L.ell_op_create(0, ints([4]), C.byref(h)) == 3
+    assert L.ell_op_create(11, ints([4] * 11), C.byref(h)) == 3
+    assert L.cheb_apply(None, None, None, None) == 4
+    assert L.ell_op_mult(None, None, None, None) == 4
+    assert h.value is None
+
+
+def test_no_cpu_fallback(L):
+    """On a box without a GPU the product refuses to run instead of silently computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = L.cheb_plan_create(1, 0, (C.c_int * 1)(8), C.byref(h))
+    assert rc == 5 and h.value is None
+    assert b"no CPU fallback" in L.chebhip_last_error()
+    with pytest.raises(sp.ChebhipError):
+        sp.EllipticOp((8, 8))

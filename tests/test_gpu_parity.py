@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C ABI, against the committed golden vectors and the CPU oracle on the same seeded inputs.
+
+Tolerances (float64, stated per BASELINE.md / SURVEY 7.4):
+  white-noise inputs : ||y - y_ref||_2 / ||y_ref||_2 <= 1e-10   (observed ~1e-13)
+  smooth fields      : each path is compared with the analytic answer, and the HIP error
+                       must not exceed a small multiple of the oracle's own error."""
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+import oracle_lib as orc
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+sp = ge.load()
+TOL = 1e-10
+SEED = 20240229
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def gpu_cheb(x, tr):
+    plan = sp.ChebPlan(x.shape, tr)
+    xd = dev(x)
+    yd = torch.full_like(xd, float("nan"))
+    plan.mult(xd, yd)
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), torch.from_numpy(np.ascontiguousarray(x)))  # input untouched
+    plan.destroy()
+    return yd.cpu().numpy()
+
+
+def _cases(g):
+    out = []
+    for k in g:
+        if k.startswith("cheb_") and "_tr" in k:
+            tag, kind, tr = k[5:].rsplit("_", 2)
+            out.append((tag, kind, int(tr[2:])))
+    return sorted(out)
+
+
+def test_native_library_loaded():
+    L = sp.lib()
+    assert L.chebhip_arch() == b"gfx950"
+    before = L.chebhip_launch_count()
+    gpu_cheb(np.ones((4, 4)), 0)
+    assert L.chebhip_launch_count() == before + 1
+
+
+def test_cheb_golden(cheb_golden):
+    n = 0
+    for tag, kind, tr in _cases(cheb_golden):
+        x = cheb_golden["cheb_%s_%s_in" % (tag, kind)]
+        ref = cheb_golden["cheb_%s_%s_tr%d" % (tag, kind, tr)]
+        y = gpu_cheb(x, tr)
+        assert np.isfinite(y).all(), (tag, kind, tr)
+        assert relerr(y, ref) < TOL, (tag, kind, tr, relerr(y, ref))
+        n += 1
+    assert n > 40
+
+
+def test_cheb_host_pointer_path(cheb_golden):
+    x = cheb_golden["cheb_8x7x5_rand_in"]
+    for tr in range(3):
+        plan = sp.ChebPlan(x.shape, tr)
+        y = plan.mult_host(x)
+        assert relerr(y, cheb_golden["cheb_8x7x5_rand_tr%d" % tr]) < TOL
+
+
+SHAPES = [
+    (2,), (3,), (4,), (16,), (17,), (31,), (100,), (255,), (256,),
+    (2, 2), (3, 5), (32, 32), (33, 17), (7, 256), (256, 7), (129, 130),
+    (5, 6, 7), (16, 16, 16), (33, 32, 31), (31, 33, 35), (64, 64, 64), (2, 200, 3), (130, 20, 10),
+    (8, 7, 5, 3), (20, 18, 16, 3), (3, 4, 5, 6, 7), (64, 64, 3), (40, 48, 56, 3),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_cheb_random_vs_oracle(shape):
+    rng = np.random.default_rng(SEED + sum(shape))
+    x = rng.standard_normal(shape)
+    for tr in range(len(shape)):
+        if shape[tr] < 2:
+            continue
+        y = gpu_cheb(x, tr)
+        ref = orc.cheb_mult(x, tr, orc.FAST, nthreads=8)
+        assert relerr(y, ref) < TOL, (shape, tr, relerr(y, ref))
+
+
+@pytest.mark.parametrize("shape,tr", [((128, 128, 128), 0), ((128, 128, 128), 1), ((128, 128, 128), 2),
+                                      ((256, 64, 40), 0), ((40, 256, 64), 1), ((40, 64, 256), 2)])
+def test_cheb_large_vs_oracle(shape, tr):
+    rng = np.random.default_rng(SEED)
+    x = rng.standard_normal(shape)
+    y = gpu_cheb(x, tr)
+    ref = orc.cheb_mult(x, tr, orc.FAST, nthreads=16)
+    assert relerr(y, ref) < TOL
+
+
+@pytest.mark.parametrize("dims", [(33, 32, 31), (64, 64, 64)])
+def test_cheb_exp_known_answer(dims):
+    """cheb.c:73-112 on the GPU: d/dx_d (e^x+e^y+e^z) = e^{x_d}; HIP error <= 4x oracle error + eps."""
+    grids = np.meshgrid(*[np.cos(np.arange(p) * np.pi / (p - 1)) for p in dims], indexing="ij")
+    u = sum(np.exp(g) for g in grids)
+    for tr in range(3):
+        truth = np.exp(grids[tr])
+        e_gpu = np.abs(gpu_cheb(u, tr) - truth).max()
+        e_orc = np.abs(orc.cheb_mult(u, tr, orc.FAST, 8) - truth).max()
+        assert e_gpu < 4 * e_orc + 1e-13, (tr, e_gpu, e_orc)
+        assert e_gpu < 1e-10
+
+
+def test_cheb_1d_known_answer():
+    """cheb.c:66-71,95-103 (ChebD1Mult = rank-1 plan)."""
+    for m1 in (5, 16, 24):
+        x = np.cos(np.arange(m1) * np.pi / (m1 - 1))
+        y = gpu_cheb(np.exp(x), 0)
+        ref = orc.cheb_mult(np.exp(x), 0, orc.DIRECT)
+        assert relerr(y, ref) < 1e-12
+
+
+def test_linearity_full_size():
+    """Size-independent property at the BASELINE size: D(a x + b z) = a D x + b D z, 256^3, every axis."""
+    torch.manual_seed(SEED)
+    shape = (256, 256, 256)
+    x = torch.randn(shape, dtype=torch.float64, device="cuda")
+    z = torch.randn(shape, dtype=torch.float64, device="cuda")
+    y1, y2, y3 = (torch.empty_like(x) for _ in range(3))
+    for tr in range(3):
+        plan = sp.ChebPlan(shape, tr)
+        plan.mult(x, y1)
+        plan.mult(z, y2)
+        plan.mult(2.0 * x - 3.0 * z, y3)
+        torch.cuda.synchronize()
+        num = torch.linalg.norm((2.0 * y1 - 3.0 * y2 - y3).ravel()).item()
+        den = torch.linalg.norm(y3.ravel()).item()
+        assert num / den < 1e-12
+        # constants differentiate to zero, x_tr to one
+        plan.mult(torch.ones_like(x), y1)
+        torch.cuda.synchronize()
+        assert y1.abs().max().item() < 1e-9
+        plan.destroy()
+
+
+def test_polynomial_exactness_full_size():
+    """d/dx of x^5 sampled on the 256-point CGL grid is 5x^4 to rounding (degree < P)."""
+    P = 256
+    xg = np.cos(np.arange(P) * np.pi / (P - 1))
+    for tr in range(3):
+        shp = [1, 1, 1]
+        shp[tr] = P
+        f = np.broadcast_to((xg ** 5).reshape(shp), (P, 64, 64) if tr == 0 else ((64, P, 64) if tr == 1 else (64, 64, P)))
+        y = gpu_cheb(np.ascontiguousarray(f), tr)
+        truth = np.broadcast_to((5 * xg ** 4).reshape(shp), f.shape)
+        assert np.abs(y - truth).max() < 2e-8   # ||D||~P^2 amplifies eps
+
+
+# ----------------------------------------------------------------------------------------------
+# operator level
+# ----------------------------------------------------------------------------------------------
+def test_elliptic_golden(ell_golden):
+    g = ell_golden
+    for dims in [(8, 6), (32, 32), (9, 8, 7)]:
+        tag = "x".join(str(s) for s in dims)
+        op = sp.EllipticOp(dims)
+        U = g["ell_%s_U" % tag]
+        Ud = dev(U)
+        Vd = torch.full_like(Ud, float("nan"))
+        op.mult(Ud, Vd)
+        torch.cuda.synchronize()
+        assert relerr(Vd.cpu().numpy(), g["ell_%s_mult_lin" % tag]) < TOL
+        assert relerr(op.mult_host(U), g["ell_%s_mult_lin" % tag]) < TOL
+        # FormFunction on the -exact 2 field with gamma = 4, exponent = 2
+        op.set_dirichlet(g["ell_%s_exact2_dirichlet" % tag])
+        rhs = op.function_host(g["ell_%s_exact2_u" % tag], g["ell_%s_exact2_b" % tag], 4.0, 2.0)
+        scale = np.abs(g["ell_%s_exact2_b" % tag]).max()
+        assert np.abs(rhs - g["ell_%s_fn_rhs" % tag]).max() < 1e-9 * scale
+        assert relerr(op.get_state(0), g["ell_%s_fn_eta" % tag]) < 1e-14
+        assert relerr(op.get_state(1), g["ell_%s_fn_deta" % tag]) < 1e-14
+        for k in range(len(dims)):
+            assert relerr(op.get_state(2 + k), g["ell_%s_fn_gradu" % tag][k]) < 1e-10
+        # Jacobian apply with the nonlinear state left behind by FormFunction
+        assert relerr(op.mult_host(U), g["ell_%s_mult_nl" % tag]) < TOL
+        op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(32, 32), (5, 4), (3, 3), (40,), (64, 64, 64), (20, 18, 16), (6, 5, 4, 3), (33, 70, 9)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_elliptic_mult_vs_oracle(dims):
+    """MatMult_Elliptic, linear Poisson state (config 1 is -dim 32,32)."""
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED)
+    U = rng.standard_normal(op.global_size)
+    V = op.mult_host(U)
+    ref = orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=8)
+    assert relerr(V, ref) < TOL
+    op.destroy()
+
+
+def test_elliptic_mult_128_vs_oracle():
+    """BASELINE config 2: 3-D Poisson -dim 128,128,128."""
+    dims = (128, 128, 128)
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED)
+    U = rng.standard_normal(op.global_size)
+    V = op.mult_host(U)
+    ref = orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=16)
+    assert relerr(V, ref) < TOL
+    op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(24, 20), (12, 11, 10)])
+def test_elliptic_nonlinear_vs_oracle(dims):
+    """FormFunction + Jacobian apply with gamma != 0 (elliptic.C:481-533, 297-339)."""
+    op = sp.EllipticOp(dims)
+    u, u2, dv = orc.elliptic_exact(dims, 0, gamma=4.0, exponent=2.0, cos_scale=3.0)
+    op.set_dirichlet(dv)
+    rhs = op.function_host(u, u2, 4.0, 2.0)
+    rhs_o, eta, deta, gradu = orc.elliptic_function(dims, u, u2, dv, 4.0, 2.0, mode=orc.FAST)
+    assert np.abs(rhs - rhs_o).max() < 1e-9 * np.abs(u2).max()
+    rng = np.random.default_rng(SEED)
+    U = rng.standard_normal(op.global_size)
+    V = op.mult_host(U)
+    ref = orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST)
+    assert relerr(V, ref) < TOL
+    op.destroy()
+
+
+def test_elliptic_exact_residual():
+    """elliptic.C:193-209 with -exact 2: the residual of the polynomial exact solution is ~0."""
+    dims = (12, 11, 10)
+    op = sp.EllipticOp(dims)
+    u, u2, dv = orc.elliptic_exact(dims, 2)
+    op.set_dirichlet(dv)
+    rhs = op.function_host(u, u2, 0.0, 2.0)
+    assert np.abs(rhs).max() < 1e-9 * np.abs(u2).max()
+    op.destroy()
+
+
+def test_elliptic_symmetry_full_size():
+    """Property at BASELINE config 3 size (256^3): linearity and definiteness of the Poisson matvec:
+    <U, A U> > 0 and A(aU + bZ) = aAU + bAZ."""
+    dims = (256, 256, 256)
+    op = sp.EllipticOp(dims)
+    torch.manual_seed(SEED)
+    U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+    Z = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+    AU, AZ, AC = (torch.empty_like(U) for _ in range(3))
+    op.mult(U, AU)
+    op.mult(Z, AZ)
+    op.mult(0.5 * U + 2.0 * Z, AC)
+    torch.cuda.synchronize()
+    assert torch.isfinite(AC).all()
+    num = torch.linalg.norm(0.5 * AU + 2.0 * AZ - AC).item()
+    assert num / torch.linalg.norm(AC).item() < 1e-12
+    assert torch.dot(U, AU).item() > 0
+    op.destroy()
