@@ -33,6 +33,8 @@ extern "C" const char *chebhip_last_error(void) { return g_err.c_str(); }
 extern "C" int chebhip_version(void) { return 100; }
 extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
+// Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
+extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
 
 static int require_device() {
   int n = 0;

@@ -33,6 +33,7 @@ struct SweepParams {
   int in_mode, out_mode;
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
   unsigned ntiles;
+  int ablate;         // profiling only (see sweep_set_ablate); 0 in production
 };
 
 // Host description of the even/odd split differentiation matrices for P points.
@@ -53,5 +54,6 @@ void diffmat_dense_host(int P, double *D);
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 
 long sweep_launch_count();
+void sweep_set_ablate(int bits);
 
 }  // namespace chebhip

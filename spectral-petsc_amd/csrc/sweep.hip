@@ -8,43 +8,44 @@
 //  - the two parity halves of D (ME, MO: H x H, H = ceil(P/2)) live in REGISTERS for the
 //    lifetime of a workgroup: wave w of 8 owns the 16 output rows of m-tile (w % MTP) and
 //    keeps their 2*KS MFMA operand fragments (128 VGPRs at P = 256);
-//  - workgroups are persistent (grid = #CUs) and walk tiles of NT lines; per tile the
-//    workgroup loads the lines from HBM, forms e = x_j + x_{n-j}, o = x_j - x_{n-j} on the
-//    fly and parks them in LDS (64 KiB);
+//  - workgroups are persistent (grid = #CUs) and walk tiles of NT lines; the lines of tile
+//    t+1 are loaded from HBM into registers while the MFMA chains of tile t run, then split
+//    into e = x_j + x_{n-j}, o = x_j - x_{n-j} and parked in the other half of a
+//    double-buffered LDS tile (2 x 64 KiB);
 //  - each wave runs v_mfma_f64_16x16x4_f64 chains over the LDS tile and stores
 //    y_i = a_i + b_i and y_{n-i} = b_i - a_i straight from the accumulators.
 //  - two tilings: COLFAST (inner stride >= 16: neighbouring lanes = neighbouring lines,
 //    matrix is the A operand) and JFAST (inner stride small, e.g. 1 or the d interleaved
 //    Stokes components: neighbouring lanes = neighbouring points of a line, matrix is the B
 //    operand so that the 16 lanes of an accumulator row are 16 consecutive outputs of a line).
+//
+// A wave issues about one vector instruction per 4-5 cycles, so everything that is not an
+// MFMA is kept off the per-element path: offsets are 32-bit and tile-invariant, the mode
+// switches are hoisted around the unrolled loops, LDS fragment reads run one group ahead.
 #include "sweep.h"
 #include <atomic>
+#include <type_traits>
 
 namespace chebhip {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef unsigned u32;
 
 static std::atomic<long> g_launches{0};
+static int g_ablate = 0;   // profiling only: bit0 no global loads, bit1 no stores, bit2 no MFMA, bit3 no LDS park
 long sweep_launch_count() { return g_launches.load(); }
+void sweep_set_ablate(int bits) { g_ablate = bits; }
 
-__device__ __forceinline__ double fetch_in(const SweepParams &p, long a, int j, int gb) {
-  switch (p.in_mode) {
-    case IN_PLAIN: return p.in0[a];
-    case IN_GATHER: return (gb >= 0 && j >= 1 && j <= p.P - 2) ? p.in0[(long)gb + (long)(j - 1) * p.gstride] : 0.0;
-    case IN_FLUX_ETA: return p.in1[a] * p.in0[a];
-    default: return p.in1[a] * p.in0[a] + p.in2[a] * p.in3[a] * p.in4[a];
-  }
-}
+template <int M> using mode_c = std::integral_constant<int, M>;
 
-__device__ __forceinline__ void emit_out(const SweepParams &p, long a, int i, int gb, double r) {
-  switch (p.out_mode) {
-    case OUT_STORE: p.out[a] = p.alpha * r; break;
-    case OUT_ACC: p.out[a] = p.acc[a] + p.alpha * r; break;
-    default:
-      if (gb >= 0 && i >= 1 && i <= p.P - 2)
-        p.out[(long)gb + (long)(i - 1) * p.gstride] = (p.acc ? p.acc[a] : 0.0) + p.alpha * r;
-      break;
-  }
+// One input element at local element offset `a` (point j of its line; gb = global index of the
+// line's j = 1 node in the interior vector, or -1).
+template <int MODE>
+__device__ __forceinline__ double fetch_in(const SweepParams &p, u32 a, int j, int gb) {
+  if (MODE == IN_PLAIN) return p.in0[a];
+  if (MODE == IN_GATHER) return (gb >= 0 && j >= 1 && j <= p.P - 2) ? p.in0[(long)gb + (long)(j - 1) * p.gstride] : 0.0;
+  if (MODE == IN_FLUX_ETA) return p.in1[a] * p.in0[a];
+  return p.in1[a] * p.in0[a] + p.in2[a] * p.in3[a] * p.in4[a];
 }
 
 template <int KS, bool JFAST>
@@ -56,15 +57,19 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
   constexpr int NT = 16 * NG * NSUB;               // lines per tile: 32, 64, 64, 128
   constexpr int LDJ = HP + 2;                      // JFAST row pitch: == 2 (mod 32) -> conflict-free b64 reads
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
-  __shared__ double smem[2 * LDS_ELEMS];
-  double *sE = smem, *sO = smem + LDS_ELEMS;
+  constexpr int ITEMS = HP * NT / 512;             // (j-pair, line) slots per thread per tile
+  constexpr int CH = ITEMS / NSUB;                 // slots per chunk (one chunk rides under one sub-tile)
+  constexpr int QSTEP = JFAST ? 512 / HP : 512 / NT;  // line step (JFAST) / j-pair step (COLFAST) between slots
+  __shared__ double smem[4 * LDS_ELEMS];           // two buffers of (E, O)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mt = w % MTP, ng = w / MTP;
+  const int kq = lane >> 4, l16 = lane & 15;
   const int nn = p.P - 1, H = p.H;
-  const unsigned inner = p.inner, ncols = p.ncols;
-  const long lineLen = (long)p.P * inner;
+  const u32 inner = p.inner, ncols = p.ncols;
+  const u32 lineLen = (u32)p.P * inner;
   const bool need_g = (p.in_mode == IN_GATHER) || (p.out_mode == OUT_ACC_SCATTER);
+  const int ablate = p.ablate;
 
   // Matrix fragments -> registers (coalesced 512 B per wave load).
   double ae[KS], ao[KS];
@@ -73,99 +78,207 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
     ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
     ao[s] = p.fragO[((long)(mt * KS + s)) * 64 + lane];
   }
+  // Retire the fragment loads here: otherwise the compiler's wait-count pass keeps them "pending"
+  // around the tile loop and threads vmcnt(62..0) waits through the MFMA chain, which would also
+  // drain the prefetch of the next tile mid-chain.  0x0F70 = vmcnt(0) only.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
-  for (unsigned tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const unsigned c0 = tile * NT;
-    // ---------------- load: HBM -> (e, o) -> LDS ----------------
+  // ---- tile geometry -------------------------------------------------------------------------
+  // COLFAST: a tile is NT consecutive lines q0..q0+NT-1 of ONE outer block o (tiles never
+  //          straddle blocks, so a line's offset is uniform base + lane term: no per-lane divide).
+  // JFAST  : a tile is NT consecutive lines c of the flattened (outer, inner) line index.
+  const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;    // tiles per outer block (COLFAST)
+
+  // loader slots of this thread
+  const int ld_n = JFAST ? tid / HP : tid % NT;          // first line slot (JFAST) / line (COLFAST)
+  const int ld_j = JFAST ? tid % HP : tid / NT;          // j-pair (JFAST) / first j-pair slot (COLFAST)
+  const int ld_lds0 = JFAST ? ld_n * LDJ + ld_j : ld_j * NT + (ld_n ^ ((ld_j & 1) << 4));
+  constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;   // QSTEP even -> swizzle parity unchanged
+
+  double rj[CH], rm[CH];                   // x_j and x_{n-j} of the chunk in flight
+
+  // Issue the loads of chunk `chunk` of tile `tile` into rj/rm.
+  auto issue_loads = [&](auto MODE, u32 tile, int chunk) {
+    constexpr int IM = decltype(MODE)::value;
     if (!JFAST) {
-      const int n = tid % NT;
-      const unsigned c = c0 + n;
-      const bool cv = c < ncols;
-      long base = 0; int gb = -1;
-      if (cv) { base = (long)(c / inner) * lineLen + (c % inner); if (need_g) gb = p.gcol[c]; }
-      for (int jp = tid / NT; jp < HP; jp += 512 / NT) {
-        double e = 0.0, o = 0.0;
+      const u32 o = tile / tpo, q0 = (tile - o * tpo) * NT;
+      const u32 q = q0 + ld_n;
+      const bool cv = q < inner;
+      const u32 base = o * lineLen + q;
+      int gb = -1;
+      if (IM == IN_GATHER && cv) gb = p.gcol[o * inner + q];
+#pragma unroll
+      for (int s = 0; s < CH; s++) {
+        const int jp = ld_j + (chunk * CH + s) * QSTEP;
+        const int jm = nn - jp;
+        double xj = 0.0, xm = 0.0;
         if (cv && jp < H) {
-          const int jm = nn - jp;
-          const double xj = fetch_in(p, base + (long)jp * inner, jp, gb);
-          if (jm != jp) { const double xm = fetch_in(p, base + (long)jm * inner, jm, gb); e = xj + xm; o = xj - xm; }
-          else e = xj;
+          xj = fetch_in<IM>(p, base + (u32)jp * inner, jp, gb);
+          if (jm != jp) xm = fetch_in<IM>(p, base + (u32)jm * inner, jm, gb);
         }
-        const int idx = jp * NT + (n ^ ((jp & 1) << 4));   // odd rows swap 16-column halves: bank spread
-        sE[idx] = e; sO[idx] = o;
+        rj[s] = xj; rm[s] = xm;
       }
     } else {
-      const int jp = tid % HP;
-      const int jm = nn - jp;
-      for (int n = tid / HP; n < NT; n += 512 / HP) {
-        const unsigned c = c0 + n;
-        double e = 0.0, o = 0.0;
+      const int jp = ld_j, jm = nn - jp;
+#pragma unroll
+      for (int s = 0; s < CH; s++) {
+        const u32 c = tile * NT + ld_n + (chunk * CH + s) * QSTEP;
+        double xj = 0.0, xm = 0.0;
         if (c < ncols && jp < H) {
-          const long base = (long)(c / inner) * lineLen + (c % inner);
-          const int gb = need_g ? p.gcol[c] : -1;
-          const double xj = fetch_in(p, base + (long)jp * inner, jp, gb);
-          if (jm != jp) { const double xm = fetch_in(p, base + (long)jm * inner, jm, gb); e = xj + xm; o = xj - xm; }
-          else e = xj;
+          const u32 base = (inner == 1) ? c * lineLen : (c / inner) * lineLen + (c % inner);
+          const int gb = (IM == IN_GATHER) ? p.gcol[c] : -1;
+          xj = fetch_in<IM>(p, base + (u32)jp * inner, jp, gb);
+          if (jm != jp) xm = fetch_in<IM>(p, base + (u32)jm * inner, jm, gb);
         }
-        sE[n * LDJ + jp] = e; sO[n * LDJ + jp] = o;
+        rj[s] = xj; rm[s] = xm;
       }
     }
-    __syncthreads();
+  };
+  auto issue_loads_any = [&](u32 tile, int chunk) {
+    if (ablate & 1) {
+#pragma unroll
+      for (int s = 0; s < CH; s++) { rj[s] = 1.0 + s; rm[s] = 0.5; }
+      return;
+    }
+    switch (p.in_mode) {
+      case IN_PLAIN: issue_loads(mode_c<IN_PLAIN>{}, tile, chunk); break;
+      case IN_GATHER: issue_loads(mode_c<IN_GATHER>{}, tile, chunk); break;
+      case IN_FLUX_ETA: issue_loads(mode_c<IN_FLUX_ETA>{}, tile, chunk); break;
+      default: issue_loads(mode_c<IN_FLUX_FULL>{}, tile, chunk); break;
+    }
+  };
 
-    // ---------------- compute + store ----------------
+  // Parity split of the chunk in registers -> LDS buffer `buf`.  For the self-paired middle
+  // point (2j == n) xm was left 0, so e = x_j; o is forced to 0 there.
+  auto park_chunk = [&](int buf, int chunk) {
+    double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
+    const bool mid = JFAST && (2 * ld_j == nn);
+#pragma unroll
+    for (int s = 0; s < CH; s++) {
+      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
+      const bool m2 = JFAST ? mid : (2 * (ld_j + (chunk * CH + s) * QSTEP) == nn);
+      dE[idx] = rj[s] + rm[s];
+      dO[idx] = m2 ? 0.0 : rj[s] - rm[s];
+    }
+  };
+
+  // compute-side invariants of this lane
+  const int i0 = mt * 16 + (JFAST ? l16 : kq);        // output row of accumulator element r: i0 + (JFAST ? 0 : 4r)
+
+  u32 tile = blockIdx.x;
+  if (tile < p.ntiles) {
+#pragma unroll 1
+    for (int ch = 0; ch < NSUB; ch++) { issue_loads_any(tile, ch); park_chunk(0, ch); }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const u32 nxt = tile + gridDim.x;
+    const bool has_next = nxt < p.ntiles;
+    const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
+    // tile base (COLFAST): uniform
+    const u32 t_o = tile / tpo, t_q0 = (tile - t_o * tpo) * NT;
 #pragma unroll 1
     for (int sub = 0; sub < NSUB; sub++) {
+      if (has_next) issue_loads_any(nxt, sub);             // in flight during this sub-tile's MFMA chain
       const int nb = (ng * NSUB + sub) * 16;
-      v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
-      const int kq = lane >> 4, nl = nb + (lane & 15);
+
+      // ---- where this lane's 4 accumulator rows go ----
+      u32 ob[4];        // element offset of output (line, i = 0)
+      bool ov[4];
+      int og[4];
+      double accv[8];
 #pragma unroll
-      for (int s = 0; s < KS; s++) {
-        const int k = 4 * s + kq;
-        double be, bo;
+      for (int r = 0; r < 4; r++) {
+        bool lv; u32 b; u32 cidx;
         if (!JFAST) {
-          const int idx = k * NT + (nl ^ ((k & 1) << 4));
-          be = sE[idx]; bo = sO[idx];
-          ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[s], be, ce, 0, 0, 0);   // rows = outputs i, cols = lines
-          co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[s], bo, co, 0, 0, 0);
+          const u32 q = t_q0 + nb + l16;
+          lv = q < inner; b = t_o * lineLen + q; cidx = t_o * inner + q;
+          ov[r] = lv && (i0 + 4 * r < H);
         } else {
-          const int idx = nl * LDJ + k;
-          be = sE[idx]; bo = sO[idx];
-          ce = __builtin_amdgcn_mfma_f64_16x16x4f64(be, ae[s], ce, 0, 0, 0);   // rows = lines, cols = outputs i
-          co = __builtin_amdgcn_mfma_f64_16x16x4f64(bo, ao[s], co, 0, 0, 0);
+          const u32 c = tile * NT + nb + 4 * r + kq;
+          lv = c < ncols; cidx = c;
+          b = (inner == 1) ? c * lineLen : (c / inner) * lineLen + (c % inner);
+          ov[r] = lv && (i0 < H);
+        }
+        ob[r] = b;
+        og[r] = -1;
+        accv[2 * r] = 0.0; accv[2 * r + 1] = 0.0;
+        if (ov[r]) {
+          if (need_g) og[r] = p.gcol[cidx];
+          if (p.out_mode != OUT_STORE && p.acc) {          // VecAXPY operand: fetched ahead of the MFMA chain
+            const int i = i0 + (JFAST ? 0 : 4 * r);
+            accv[2 * r] = p.acc[b + (u32)i * inner];
+            accv[2 * r + 1] = p.acc[b + (u32)(nn - i) * inner];
+          }
         }
       }
-      // accumulator element r of a lane: row = 4*r + (lane >> 4), col = lane & 15
-      if (!JFAST) {
-        const unsigned c = c0 + nb + (lane & 15);
-        if (c < ncols) {
-          const long base = (long)(c / inner) * lineLen + (c % inner);
-          const int gb = need_g ? p.gcol[c] : -1;
+
+      // ---- MFMA chains; LDS fragment reads run one group (2 k-steps) ahead ----
+      v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
+      const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
+      const double *fE = sE + frag, *fO = sO + frag;
+      constexpr int KSTR = JFAST ? 4 : 4 * NT;             // LDS stride of one k-step
+      if (ablate & 4) { ce[0] = fE[0]; co[0] = fO[0]; }
+      else {
+        double fb[2][4];
+        fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int i = mt * 16 + 4 * r + kq;
-            if (i < H) {
-              const double a = ce[r], b = co[r];
-              emit_out(p, base + (long)i * inner, i, gb, a + b);
-              if (nn - i != i) emit_out(p, base + (long)(nn - i) * inner, nn - i, gb, b - a);
-            }
+        for (int g = 0; g < KS / 2; g++) {
+          const int cb = g & 1, nbuf = cb ^ 1;
+          if (g + 1 < KS / 2) {
+            fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
+            fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
+          }
+          if (!JFAST) {   // rows = outputs i, cols = lines
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g], fb[cb][2], co, 0, 0, 0);
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g + 1], fb[cb][3], co, 0, 0, 0);
+          } else {        // rows = lines, cols = outputs i
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], ao[2 * g], co, 0, 0, 0);
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], ao[2 * g + 1], co, 0, 0, 0);
           }
         }
-      } else {
-        const int i = mt * 16 + (lane & 15);
+      }
+
+      // ---- stores: accumulator element r of a lane is row 4r + (lane >> 4), col lane & 15 ----
+      if (!(ablate & 2) || ce[0] == 12345.678) {
+        const double alpha = p.alpha;
+        if (p.out_mode == OUT_STORE) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const unsigned c = c0 + nb + 4 * r + kq;
-          if (c < ncols && i < H) {
-            const long base = (long)(c / inner) * lineLen + (c % inner);
-            const int gb = need_g ? p.gcol[c] : -1;
-            const double a = ce[r], b = co[r];
-            emit_out(p, base + (long)i * inner, i, gb, a + b);
-            if (nn - i != i) emit_out(p, base + (long)(nn - i) * inner, nn - i, gb, b - a);
+          for (int r = 0; r < 4; r++) if (ov[r]) {
+            const int i = i0 + (JFAST ? 0 : 4 * r);
+            p.out[ob[r] + (u32)i * inner] = alpha * (ce[r] + co[r]);
+            if (nn - i != i) p.out[ob[r] + (u32)(nn - i) * inner] = alpha * (co[r] - ce[r]);
+          }
+        } else if (p.out_mode == OUT_ACC) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (ov[r]) {
+            const int i = i0 + (JFAST ? 0 : 4 * r);
+            p.out[ob[r] + (u32)i * inner] = accv[2 * r] + alpha * (ce[r] + co[r]);
+            if (nn - i != i) p.out[ob[r] + (u32)(nn - i) * inner] = accv[2 * r + 1] + alpha * (co[r] - ce[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (ov[r] && og[r] >= 0) {
+            const int i = i0 + (JFAST ? 0 : 4 * r);
+            const int im = nn - i;
+            if (i >= 1 && i <= nn - 1) p.out[(long)og[r] + (long)(i - 1) * p.gstride] = accv[2 * r] + alpha * (ce[r] + co[r]);
+            if (im != i && im >= 1 && im <= nn - 1)
+              p.out[(long)og[r] + (long)(im - 1) * p.gstride] = accv[2 * r + 1] + alpha * (co[r] - ce[r]);
           }
         }
+      }
+      if (has_next) {
+        if (!(ablate & 8)) park_chunk(cur ^ 1, sub);
+        else { double t = 0; for (int s = 0; s < CH; s++) t += rj[s] + rm[s]; if (t == 12345.678) park_chunk(cur ^ 1, sub); }
       }
     }
     __syncthreads();
+    cur ^= 1;
   }
 }
 
@@ -173,7 +286,8 @@ template <int KS, bool JFAST>
 static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
   constexpr int MTP = KS / 4, NG = 8 / MTP, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB;
   SweepParams p = p0;
-  p.ntiles = (p.ncols + NT - 1) / NT;
+  if (JFAST) p.ntiles = (p.ncols + NT - 1) / NT;
+  else p.ntiles = (p.ncols / p.inner) * ((p.inner + NT - 1) / NT);
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -190,7 +304,7 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO;
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.ablate = g_ablate;
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);
