@@ -81,7 +81,7 @@ def main():
         U = torch.randn(op.global_size, dtype=torch.float64, device="cuda", generator=g)
         V = torch.empty_like(U)
         step = lambda: op.mult(U, V)
-        launches_per_step = 6
+        launches_per_step = 3
         parallelism = "single"
     else:
         dsp = ge.load_dist()
@@ -89,7 +89,7 @@ def main():
         U = op.random_input(SEED)
         V = torch.empty_like(U)
         step = lambda: op.mult(U, V)
-        launches_per_step = 6
+        launches_per_step = 3
         parallelism = "slab%d+all2all" % world
 
     def barrier():
@@ -122,9 +122,9 @@ def main():
         # dominant kernel: cheb_sweep_kernel, 6 launches per matvec on torch's current stream, timed
         # with HIP events around the K steps; algorithmic bytes per launch = 112*P^3/6
         launch_s = (dev_ms * 1e-3) / (args.steps * launches_per_step)
-        alg_bytes_launch = BYTES_PER_POINT * npts / 6.0 / world
+        alg_bytes_launch = BYTES_PER_POINT * npts / launches_per_step / world
         achieved = alg_bytes_launch / launch_s
-        flops_launch = float(P) * npts / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
+        flops_launch = 6.0 * float(P) * npts / launches_per_step / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
         out = {
             "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
             "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

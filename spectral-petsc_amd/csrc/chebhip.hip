@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -281,8 +282,8 @@ extern "C" long ell_op_local_size(const ell_op *op) { return op ? op->N : -1; }
 extern "C" long ell_op_global_size(const ell_op *op) { return op ? op->G : -1; }
 extern "C" long ell_op_dirichlet_size(const ell_op *op) { return op ? op->N - op->G : -1; }
 
-// Divergence half shared by MatMult and FormFunction: out_global = -sum_k D_k f_k (+ optional -b).
-// in_mode selects how f_k is formed from op->g[k] / src[k] on load.
+// Divergence half of the UNFUSED path (kept for A/B measurements, CHEBHIP_UNFUSED=1):
+// out_global = -sum_k D_k f_k, f_k formed from src[k] on load.
 static int ell_divergence(ell_op *op, int in_mode, double *const *src, double *out_global, hipStream_t st) {
   const int d = op->d;
   for (int k = 0; k < d; k++) {
@@ -304,13 +305,25 @@ static int ell_divergence(ell_op *op, int in_mode, double *const *src, double *o
   return 0;
 }
 
-extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
-  if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (op->G == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
+static bool use_unfused() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("CHEBHIP_UNFUSED"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+// Where the k-th term -D_k f_k of the divergence goes: W = -t0; W -= t_k; out_global = scatter(W - t_{d-1}).
+static void ell_out_chain(ell_op *op, int k, double *out_global, SweepParams *sp) {
+  const int d = op->d;
+  sp->alpha = -1.0;                                              // VecAXPY(w0,-1,.) elliptic.C:333
+  sp->gcol = op->gcol[k]; sp->gstride = op->gstride[k];
+  if (k == d - 1) { sp->out_mode = OUT_ACC_SCATTER; sp->out = out_global; sp->acc = (d > 1) ? op->W : nullptr; }  // + VecScatter LG (:336)
+  else if (k == 0) { sp->out_mode = OUT_STORE; sp->out = op->W; }
+  else { sp->out_mode = OUT_ACC; sp->out = op->W; sp->acc = op->W; }
+}
+
+static int ell_mult_unfused(ell_op *op, const double *U, double *V, hipStream_t st) {
   const int d = op->d;
   if (op->mode == COEFF_UNIT) {
-    // eta == 1, deta == 0: f_k = g_k exactly; the gather is folded into the gradient loads
     for (int k = 0; k < d; k++) {
       SweepParams sp = {};
       sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
@@ -320,7 +333,6 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
     }
     return ell_divergence(op, IN_PLAIN, op->g.data(), V, st);
   }
-  // general coefficients: the flux needs the local input w0 (elliptic.C:321)
   hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U,
                      (const double *)nullptr, op->w0);                          // dirichlet0 == 0
   for (int k = 0; k < d; k++) {
@@ -332,6 +344,26 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   return ell_divergence(op, IN_FLUX_FULL, op->g.data(), V, st);
 }
 
+extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
+  if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (op->G == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (use_unfused()) return ell_mult_unfused(op, U, V, st);
+  // One fused launch per direction: V = scatter( -sum_k D_k( eta D_k w0 + deta w0 du0_k ) ), with
+  // w0 = gather(U) on the fly (VecScatter GL + dirichlet0, elliptic.C:305-308): the gradient and
+  // the flux (elliptic.C:309-323) never leave the chip.
+  for (int k = 0; k < op->d; k++) {
+    SweepParams sp = {};
+    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+    sp.in0 = U; sp.in_mode = IN_GATHER;
+    if (op->mode == COEFF_UNIT) sp.coef_mode = COEF_UNIT;
+    else { sp.coef_mode = COEF_FULL; sp.in1 = op->eta; sp.in2 = op->deta; sp.in4 = op->gradu[k]; }
+    ell_out_chain(op, k, V, &sp);
+    HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st));
+  }
+  return 0;
+}
+
 extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const double *U,
                                const double *b, double *rhs, void *stream) {
   if (!op || !U || !rhs) return fail(CHEBHIP_ERR_ARG, "NULL argument");
@@ -341,20 +373,35 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
   const int d = op->d;
   hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U,
                      (const double *)op->dirloc, op->w0);                        // elliptic.C:486-493
-  for (int k = 0; k < d; k++) {                                                 // gradu[k] = D_k w0 (:497-499)
-    SweepParams sp = {};
-    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
-    sp.in0 = op->w0; sp.in_mode = IN_PLAIN; sp.out = op->gradu[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
-    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
-  }
   hipLaunchKernelGGL(k_coeff, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, gamma, exponent,
                      (const double *)op->w0, op->eta, op->deta);                 // :508-509
   // eta stays exactly 1 and deta exactly 0 only when gamma == 0 and no pow() can produce inf/nan
   const bool unit = (gamma == 0.0) && (exponent == std::floor(exponent)) && exponent >= 1.0;
   op->mode = unit ? COEFF_UNIT : COEFF_FULL;
-  if (op->G == 0) return 0;
-  rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);               // w = eta*gradu (:511), :521-528
-  if (rc) return rc;
+  if (use_unfused()) {
+    for (int k = 0; k < d; k++) {                                               // gradu[k] = D_k w0 (:497-499)
+      SweepParams sp = {};
+      sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+      sp.in0 = op->w0; sp.in_mode = IN_PLAIN; sp.out = op->gradu[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+      HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+    }
+    if (op->G == 0) return 0;
+    rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);             // w = eta*gradu (:511), :521-528
+    if (rc) return rc;
+  } else {
+    // fused: gradu[k] = D_k w0 is stored on the way (:497-499), w_k = eta gradu[k] (:511) feeds the
+    // divergence without leaving the chip (:521-528)
+    for (int k = 0; k < d; k++) {
+      SweepParams sp = {};
+      sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+      sp.in0 = op->w0; sp.in_mode = IN_PLAIN;
+      sp.coef_mode = COEF_ETA; sp.in1 = op->eta; sp.gout = op->gradu[k];
+      ell_out_chain(op, k, rhs, &sp);
+      if (op->G == 0) { sp.out_mode = OUT_STORE; sp.out = op->W; sp.acc = nullptr; }
+      HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st));
+    }
+    if (op->G == 0) return 0;
+  }
   if (b) hipLaunchKernelGGL(k_axpy, dim3(pw_grid(op->G)), dim3(256), 0, st, op->G, -1.0, b, rhs);  // :530
   HIPCHK(hipGetLastError());
   return 0;

@@ -19,6 +19,13 @@ enum OutMode : int {
   OUT_ACC_SCATTER = 2   // interior: out_global[g] = (acc ? acc[a] : 0) + alpha*r   (+ VecScatter LG, elliptic.C:336)
 };
 
+// Pointwise coefficient applied between the two halves of a fused D_k( flux( D_k u ) ) launch.
+enum CoefMode : int {
+  COEF_UNIT = 0,   // f = g                                   (eta == 1, deta == 0)
+  COEF_ETA = 1,    // f = eta * g                             (elliptic.C:511)
+  COEF_FULL = 2    // f = eta * g + deta * u * du0            (elliptic.C:321)
+};
+
 struct SweepParams {
   int P;              // points along the transform dim
   int H;              // ceil(P/2): even/odd half length
@@ -33,6 +40,8 @@ struct SweepParams {
   int in_mode, out_mode;
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
   unsigned ntiles;
+  int coef_mode;      // fused launches only: CoefMode; eta = in1, deta = in2, du0 = in4 (local layout)
+  double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
   int ablate;         // profiling only (see sweep_set_ablate); 0 in production
 };
 
@@ -52,6 +61,12 @@ void diffmat_dense_host(int P, double *D);
 
 // Launches one sweep.  jfast selects the line-contiguous tiling.
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+
+// Launches one fused pair: out (+)= alpha * D( coef( D in ) ) along the plan's dimension.
+// in_mode must be IN_PLAIN or IN_GATHER.
+hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+int sweep_get_ablate();
+void sweep_note_launch();
 
 long sweep_launch_count();
 void sweep_set_ablate(int bits);

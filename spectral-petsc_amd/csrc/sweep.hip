@@ -35,6 +35,8 @@ static std::atomic<long> g_launches{0};
 static int g_ablate = 0;   // profiling only: bit0 no global loads, bit1 no stores, bit2 no MFMA, bit3 no LDS park
 long sweep_launch_count() { return g_launches.load(); }
 void sweep_set_ablate(int bits) { g_ablate = bits; }
+int sweep_get_ablate() { return g_ablate; }
+void sweep_note_launch() { g_launches.fetch_add(1); }
 
 template <int M> using mode_c = std::integral_constant<int, M>;
 
@@ -107,14 +109,19 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
       const u32 base = o * lineLen + q;
       int gb = -1;
       if (IM == IN_GATHER && cv) gb = p.gcol[o * inner + q];
+      // running offsets, made opaque so that the optimiser does not hoist one precomputed
+      // address pair per slot out of the tile loop (that costs ~60 VGPRs and spills)
+      int jp = ld_j + chunk * CH * QSTEP;
+      u32 rel = (u32)jp * inner;
+      const u32 top = base + (u32)nn * inner;
+      asm volatile("" : "+v"(rel), "+v"(jp));
 #pragma unroll
-      for (int s = 0; s < CH; s++) {
-        const int jp = ld_j + (chunk * CH + s) * QSTEP;
+      for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * inner) {
         const int jm = nn - jp;
         double xj = 0.0, xm = 0.0;
         if (cv && jp < H) {
-          xj = fetch_in<IM>(p, base + (u32)jp * inner, jp, gb);
-          if (jm != jp) xm = fetch_in<IM>(p, base + (u32)jm * inner, jm, gb);
+          xj = fetch_in<IM>(p, base + rel, jp, gb);
+          if (jm != jp) xm = fetch_in<IM>(p, top - rel, jm, gb);
         }
         rj[s] = xj; rm[s] = xm;
       }
