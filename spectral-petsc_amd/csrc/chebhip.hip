@@ -169,6 +169,7 @@ struct ell_op {
   long N = 0, G = 0;
   std::map<int, DiffMat> mats;          // one matrix per distinct extent
   std::vector<unsigned> inner, ncols;   // per direction
+  std::vector<unsigned> inner_g, ncols_g; // per direction, in the interior (global-vector) layout
   std::vector<int *> gcol;              // per direction: device [ncols_k]
   std::vector<long> gstride;            // per direction, in the global (interior) layout
   int *ixL = nullptr;                   // device [N]: global index or -1 (c->isL, elliptic.C:426)
@@ -238,6 +239,11 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
     OPCHK(hipMemcpy(op->ixL, ixL.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
   }
   op->inner.resize(d); op->ncols.resize(d); op->gcol.assign(d, nullptr); op->gstride = gs;
+  op->inner_g.resize(d); op->ncols_g.resize(d);
+  for (int k = 0; k < d; k++) {
+    op->inner_g[k] = (unsigned)gs[k];
+    op->ncols_g[k] = dims[k] > 2 ? (unsigned)(G / (dims[k] - 2)) : 0u;
+  }
   for (int k = 0; k < d; k++) {
     unsigned in = 1; for (int r = k + 1; r < d; r++) in *= dims[r];
     op->inner[k] = in; op->ncols[k] = (unsigned)(N / dims[k]);
@@ -349,15 +355,32 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (use_unfused()) return ell_mult_unfused(op, U, V, st);
-  // One fused launch per direction: V = scatter( -sum_k D_k( eta D_k w0 + deta w0 du0_k ) ), with
-  // w0 = gather(U) on the fly (VecScatter GL + dirichlet0, elliptic.C:305-308): the gradient and
-  // the flux (elliptic.C:309-323) never leave the chip.
+  if (op->mode == COEFF_UNIT) {
+    // Linear state (eta == 1, deta == 0; homogeneous Dirichlet rows, elliptic.C:305-308): every
+    // array of the apply lives in the interior layout of the global vectors, so there is no
+    // gather/scatter at all -- lines through boundary nodes carry zeros in and are not read out.
+    // V = -sum_k D_k D_k w0 restricted to the interior, one fused launch per direction.
+    for (int k = 0; k < op->d; k++) {
+      SweepParams sp = {};
+      sp.ncols = op->ncols_g[k]; sp.inner = op->inner_g[k];
+      sp.in0 = U; sp.in_mode = IN_PLAIN; sp.trim = 1; sp.coef_mode = COEF_UNIT;
+      sp.alpha = -1.0;                                             // VecAXPY(w0,-1,.) elliptic.C:333
+      if (k == 0 && op->d > 1) { sp.out_mode = OUT_STORE; sp.out = op->W; }
+      else if (k == 0) { sp.out_mode = OUT_STORE; sp.out = V; }
+      else if (k == op->d - 1) { sp.out_mode = OUT_ACC; sp.out = V; sp.acc = op->W; }
+      else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
+      HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st));
+    }
+    return 0;
+  }
+  // General coefficients: w0 = gather(U) on the fly (VecScatter GL + dirichlet0, elliptic.C:305-308),
+  // V = scatter( -sum_k D_k( eta D_k w0 + deta w0 du0_k ) ); the gradient and the flux
+  // (elliptic.C:309-323) never leave the chip.
   for (int k = 0; k < op->d; k++) {
     SweepParams sp = {};
     sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
     sp.in0 = U; sp.in_mode = IN_GATHER;
-    if (op->mode == COEFF_UNIT) sp.coef_mode = COEF_UNIT;
-    else { sp.coef_mode = COEF_FULL; sp.in1 = op->eta; sp.in2 = op->deta; sp.in4 = op->gradu[k]; }
+    sp.coef_mode = COEF_FULL; sp.in1 = op->eta; sp.in2 = op->deta; sp.in4 = op->gradu[k];
     ell_out_chain(op, k, V, &sp);
     HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st));
   }

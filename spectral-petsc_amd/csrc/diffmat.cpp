@@ -71,11 +71,13 @@ hipError_t diffmat_create(int P, DiffMat *out) {
       }
   DiffMat m;
   m.P = P; m.H = H; m.KS = KS; m.MTP = MTP;
-  hipError_t e = hipMalloc((void **)&m.fragE, cnt * sizeof(double));
+  hipError_t e = hipMalloc((void **)&m.fragE, (cnt + 8) * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMalloc((void **)&m.fragO, cnt * sizeof(double));
   if (e != hipSuccess) { (void)hipFree(m.fragE); return e; }
-  e = hipMemcpy(m.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  m.zero = m.fragE + cnt;
+  e = hipMemset(m.zero, 0, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(m.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(m.fragE); (void)hipFree(m.fragO); return e; }
   *out = m;

@@ -15,6 +15,7 @@
 // registers during stage 1 of tile t and parked into IN during stage 2 (IN is dead by then).
 #include "sweep.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace chebhip {
 
@@ -23,10 +24,20 @@ typedef unsigned u32;
 
 template <int M> using mode_c = std::integral_constant<int, M>;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every
+// wave would wait at each tile boundary for its own prefetch loads and result stores, which
+// serialises the HBM stream with the MFMA phases.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Branch-free fetch with NO use of the loaded value: an invalid slot reads from a zero word
+// (p.zero) instead of being masked afterwards.  Any arithmetic on the value here would make the
+// compiler wait for the load right after issuing it and expose the whole HBM latency.
 template <int MODE>
-__device__ __forceinline__ double fetch_u(const SweepParams &p, u32 a, int j, int gb) {
-  if (MODE == IN_PLAIN) return p.in0[a];
-  return (gb >= 0 && j >= 1 && j <= p.P - 2) ? p.in0[(long)gb + (long)(j - 1) * p.gstride] : 0.0;
+__device__ __forceinline__ double fetch_u(const SweepParams &p, u32 a, int j, int gb, bool ok) {
+  const double *src;
+  if (MODE == IN_PLAIN) src = p.in0 + a;
+  else { ok = ok && gb >= 0 && j >= 1 && j <= p.P - 2; src = p.in0 + ((long)gb + (long)(j - 1) * p.gstride); }
+  return *(ok ? src : p.zero);
 }
 
 template <int KS, bool JFAST, int COEF>
@@ -51,7 +62,12 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
   const int kq = lane >> 4, l16 = lane & 15;
   const int nn = p.P - 1, H = p.H;
   const u32 inner = p.inner, ncols = p.ncols;
-  const u32 lineLen = (u32)p.P * inner;
+  // trim: the arrays hold only the interior points 1..n-1 of every line (and only interior lines):
+  // point j sits at base + (j-1)*inner, points 0 and n are implicit zeros on load and dropped on store.
+  const bool trim = p.trim != 0;
+  const u32 lineLen = (u32)(trim ? p.P - 2 : p.P) * inner;
+  const u32 joff = trim ? inner : 0u;
+  const int jlo = trim ? 1 : 0;
   const bool need_g = (p.in_mode == IN_GATHER) || (p.out_mode == OUT_ACC_SCATTER);
   const int ablate = p.ablate;
 
@@ -62,6 +78,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
     ao[s] = p.fragO[((long)(mt * KS + s)) * 64 + lane];
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see sweep.hip
+  if (p.variant & 1) { if (w < 4) __builtin_amdgcn_s_setprio(2); }
 
   const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
   const int ld_n = JFAST ? tid / HP : tid % NT;
@@ -77,9 +94,9 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
       const u32 o = tile / tpo, q0 = (tile - o * tpo) * NT;
       const u32 q = q0 + ld_n;
       const bool cv = q < inner;
-      const u32 base = o * lineLen + q;
+      const u32 base = o * lineLen + q - joff;
       int gb = -1;
-      if (IM == IN_GATHER && cv) gb = p.gcol[o * inner + q];
+      if (IM == IN_GATHER) gb = p.gcol[cv ? o * inner + q : 0u];
       // running offsets, made opaque so that the optimiser does not hoist one precomputed
       // address pair per slot out of the tile loop (that costs ~60 VGPRs and spills)
       int jp = ld_j + chunk * CH * QSTEP;
@@ -89,26 +106,21 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
 #pragma unroll
       for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * inner) {
         const int jm = nn - jp;
-        double xj = 0.0, xm = 0.0;
-        if (cv && jp < H) {
-          xj = fetch_u<IM>(p, base + rel, jp, gb);
-          if (jm != jp) xm = fetch_u<IM>(p, top - rel, jm, gb);
-        }
-        xj_[s] = xj; xm_[s] = xm;
+        const bool ok = cv && jp < H && jp >= jlo;
+        xj_[s] = fetch_u<IM>(p, base + rel, jp, gb, ok);
+        xm_[s] = fetch_u<IM>(p, top - rel, jm, gb, ok && jm != jp);
       }
     } else {
       const int jp = ld_j, jm = nn - jp;
 #pragma unroll
       for (int s = 0; s < CH; s++) {
         const u32 c = tile * NT + ld_n + (chunk * CH + s) * QSTEP;
-        double xj = 0.0, xm = 0.0;
-        if (c < ncols && jp < H) {
-          const u32 base = (inner == 1) ? c * lineLen : (c / inner) * lineLen + (c % inner);
-          const int gb = (IM == IN_GATHER) ? p.gcol[c] : -1;
-          xj = fetch_u<IM>(p, base + (u32)jp * inner, jp, gb);
-          if (jm != jp) xm = fetch_u<IM>(p, base + (u32)jm * inner, jm, gb);
-        }
-        xj_[s] = xj; xm_[s] = xm;
+        const bool ok = c < ncols && jp < H && jp >= jlo;
+        const u32 cc = ok ? c : 0u;
+        const u32 base = ((inner == 1) ? cc * lineLen : (cc / inner) * lineLen + (cc % inner)) - joff;
+        const int gb = (IM == IN_GATHER) ? p.gcol[cc] : -1;
+        xj_[s] = fetch_u<IM>(p, base + (u32)jp * inner, jp, gb, ok);
+        xm_[s] = fetch_u<IM>(p, base + (u32)jm * inner, jm, gb, ok && jm != jp);
       }
     }
   };
@@ -158,6 +170,10 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
         ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
         co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], ao[2 * g + 1], co, 0, 0, 0);
       }
+      // pin the order "LDS reads of group g+1, then the 4 MFMAs of group g": the reads then
+      // complete under the MFMAs instead of being issued (and waited for) right before their use
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
   };
 
@@ -169,16 +185,16 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
       u32 b, cidx; bool lv;
       if (!JFAST) {
         const u32 q = t_q0 + nb + l16;
-        lv = q < inner; b = t_o * lineLen + q; cidx = t_o * inner + q;
+        lv = q < inner; b = t_o * lineLen + q - joff; cidx = t_o * inner + q;
         ov[r] = lv && (i0 + 4 * r < H);
       } else {
         const u32 c = tile * NT + nb + 4 * r + kq;
         lv = c < ncols; cidx = c;
-        b = (inner == 1) ? c * lineLen : (c / inner) * lineLen + (c % inner);
+        b = ((inner == 1) ? c * lineLen : (c / inner) * lineLen + (c % inner)) - joff;
         ov[r] = lv && (i0 < H);
       }
       ob[r] = b;
-      og[r] = (ov[r] && need_g) ? p.gcol[cidx] : -1;
+      og[r] = need_g ? p.gcol[lv ? cidx : 0u] : -1;   // clamped index, no select on the loaded value
     }
   };
 
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
 #pragma unroll 1
     for (int ch = 0; ch < NSUB; ch++) { issue_loads_any(tile, ch, rj, rm); park_chunk(ch, rj, rm); }
   }
-  __syncthreads();
+  lds_barrier();
   for (; tile < p.ntiles; tile += gridDim.x) {
     const u32 nxt = tile + gridDim.x;
     const bool has_next = nxt < p.ntiles;
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
           double fi = cv[2 * r] * gi, fm = cv[2 * r + 1] * gm;               // eta * g
           if (COEF == COEF_FULL) {                                     // + deta * u * du0 (elliptic.C:321)
             double ui, um;
-            if (p.in_mode == IN_GATHER) { ui = fetch_u<IN_GATHER>(p, ai, i, og[r]); um = fetch_u<IN_GATHER>(p, am, im, og[r]); }
+            if (p.in_mode == IN_GATHER) { ui = fetch_u<IN_GATHER>(p, ai, i, og[r], true); um = fetch_u<IN_GATHER>(p, am, im, og[r], true); }
             else { ui = p.in0[ai]; um = p.in0[am]; }
             fi = fi + p.in2[ai] * ui * p.in4[ai];
             fm = fm + p.in2[am] * um * p.in4[am];
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
         fE_[fidx] = e2; fO_[fidx] = o2;
       }
     }
-    __syncthreads();   // F complete, IN dead
+    lds_barrier();   // F complete, IN dead
 
     // ======================= stage 2: t = D f, out = acc + alpha t =======================
 #pragma unroll 1
@@ -248,14 +264,22 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         accv[2 * r] = 0.0; accv[2 * r + 1] = 0.0;
+        const int i = i0 + (JFAST ? 0 : 4 * r);
+        ov[r] = ov[r] && i >= jlo;                       // trimmed arrays have no slot for points 0 and n
         if (ov[r] && p.out_mode != OUT_STORE && p.acc) {
-          const int i = i0 + (JFAST ? 0 : 4 * r);
           accv[2 * r] = p.acc[ob[r] + (u32)i * inner];
           accv[2 * r + 1] = p.acc[ob[r] + (u32)(nn - i) * inner];
         }
       }
       v4d ce, co;
       chains(fE_, fO_, nb, ce, co);
+      // Refill IN with the next tile BEFORE issuing this sub-tile's stores: the wait in front of
+      // the parity split then covers loads only (vmcnt retires in order, so a wait placed after
+      // the stores would also wait for them to reach memory).
+      if (has_next) {
+        park_chunk(sub, rj, rm);
+        if (sub + 1 < NSUB) issue_loads_any(nxt, sub + 1, rj, rm);
+      }
       if (!(ablate & 2) || ce[0] == 12345.678) {
         const double alpha = p.alpha;
         if (p.out_mode == OUT_STORE) {
@@ -283,12 +307,8 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
           }
         }
       }
-      if (has_next) {                                    // IN is free: refill it with the next tile
-        park_chunk(sub, rj, rm);
-        if (sub + 1 < NSUB) issue_loads_any(nxt, sub + 1, rj, rm);
-      }
     }
-    __syncthreads();   // IN complete, F dead
+    lds_barrier();   // IN complete, F dead
   }
 }
 
@@ -323,7 +343,8 @@ static hipError_t launch_f(const SweepParams &p0, hipStream_t stream) {
 
 hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   if (p.in_mode != IN_PLAIN && p.in_mode != IN_GATHER) return hipErrorInvalidValue;
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.ablate = sweep_get_ablate();
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.ablate = sweep_get_ablate();
+  { static int v = -1; if (v < 0) { const char *e = getenv("CHEBHIP_VARIANT"); v = e ? atoi(e) : 0; } p.variant = v; }
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_f<4, true>(p, stream) : launch_f<4, false>(p, stream);

@@ -39,9 +39,12 @@ struct SweepParams {
   double alpha;
   int in_mode, out_mode;
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
+  const double *zero;           // a few zero doubles in HBM: the source of every masked-off load
   unsigned ntiles;
+  int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
   int coef_mode;      // fused launches only: CoefMode; eta = in1, deta = in2, du0 = in4 (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
+  int variant;        // profiling only: experimental schedule switches (CHEBHIP_VARIANT)
   int ablate;         // profiling only (see sweep_set_ablate); 0 in production
 };
 
@@ -51,6 +54,7 @@ struct DiffMat {
   int KS = 0;          // k-steps of 4 (power of two >= 4 for the register-resident kernel)
   int MTP = 0;         // padded m-tiles of 16 rows = KS/4
   double *fragE = nullptr, *fragO = nullptr;  // device, [MTP][KS][64]
+  double *zero = nullptr;                     // device, 8 zero doubles (tail of the fragE allocation)
 };
 
 // Builds (in long double) and uploads the fragment-ordered matrices.  Returns hipSuccess or error.

@@ -40,14 +40,29 @@ void sweep_note_launch() { g_launches.fetch_add(1); }
 
 template <int M> using mode_c = std::integral_constant<int, M>;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every
+// wave would wait at each tile boundary for its own prefetch loads and result stores, which
+// serialises the HBM stream with the MFMA phases.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One input element at local element offset `a` (point j of its line; gb = global index of the
 // line's j = 1 node in the interior vector, or -1).
+// Branch-free fetch.  For the single-array modes there is NO use of the loaded value here: an
+// invalid slot reads from a zero word (p.zero) instead of being masked afterwards -- arithmetic
+// on the value would make the compiler wait for the load right after issuing it and expose the
+// whole HBM latency.  The flux modes combine several arrays and so do wait at issue.
 template <int MODE>
-__device__ __forceinline__ double fetch_in(const SweepParams &p, u32 a, int j, int gb) {
-  if (MODE == IN_PLAIN) return p.in0[a];
-  if (MODE == IN_GATHER) return (gb >= 0 && j >= 1 && j <= p.P - 2) ? p.in0[(long)gb + (long)(j - 1) * p.gstride] : 0.0;
-  if (MODE == IN_FLUX_ETA) return p.in1[a] * p.in0[a];
-  return p.in1[a] * p.in0[a] + p.in2[a] * p.in3[a] * p.in4[a];
+__device__ __forceinline__ double fetch_in(const SweepParams &p, u32 a, int j, int gb, bool ok) {
+  if (MODE == IN_PLAIN) return *(ok ? p.in0 + a : p.zero);
+  if (MODE == IN_GATHER) {
+    ok = ok && gb >= 0 && j >= 1 && j <= p.P - 2;
+    return *(ok ? p.in0 + ((long)gb + (long)(j - 1) * p.gstride) : p.zero);
+  }
+  const u32 b = ok ? a : 0u;
+  double v;
+  if (MODE == IN_FLUX_ETA) v = p.in1[b] * p.in0[b];
+  else v = p.in1[b] * p.in0[b] + p.in2[b] * p.in3[b] * p.in4[b];
+  return ok ? v : 0.0;
 }
 
 template <int KS, bool JFAST>
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
       const bool cv = q < inner;
       const u32 base = o * lineLen + q;
       int gb = -1;
-      if (IM == IN_GATHER && cv) gb = p.gcol[o * inner + q];
+      if (IM == IN_GATHER) gb = p.gcol[cv ? o * inner + q : 0u];
       // running offsets, made opaque so that the optimiser does not hoist one precomputed
       // address pair per slot out of the tile loop (that costs ~60 VGPRs and spills)
       int jp = ld_j + chunk * CH * QSTEP;
@@ -118,26 +133,21 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
 #pragma unroll
       for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * inner) {
         const int jm = nn - jp;
-        double xj = 0.0, xm = 0.0;
-        if (cv && jp < H) {
-          xj = fetch_in<IM>(p, base + rel, jp, gb);
-          if (jm != jp) xm = fetch_in<IM>(p, top - rel, jm, gb);
-        }
-        rj[s] = xj; rm[s] = xm;
+        const bool ok = cv && jp < H;
+        rj[s] = fetch_in<IM>(p, base + rel, jp, gb, ok);
+        rm[s] = fetch_in<IM>(p, top - rel, jm, gb, ok && jm != jp);
       }
     } else {
       const int jp = ld_j, jm = nn - jp;
 #pragma unroll
       for (int s = 0; s < CH; s++) {
         const u32 c = tile * NT + ld_n + (chunk * CH + s) * QSTEP;
-        double xj = 0.0, xm = 0.0;
-        if (c < ncols && jp < H) {
-          const u32 base = (inner == 1) ? c * lineLen : (c / inner) * lineLen + (c % inner);
-          const int gb = (IM == IN_GATHER) ? p.gcol[c] : -1;
-          xj = fetch_in<IM>(p, base + (u32)jp * inner, jp, gb);
-          if (jm != jp) xm = fetch_in<IM>(p, base + (u32)jm * inner, jm, gb);
-        }
-        rj[s] = xj; rm[s] = xm;
+        const bool ok = c < ncols && jp < H;
+        const u32 cc = ok ? c : 0u;
+        const u32 base = (inner == 1) ? cc * lineLen : (cc / inner) * lineLen + (cc % inner);
+        const int gb = (IM == IN_GATHER) ? p.gcol[cc] : -1;
+        rj[s] = fetch_in<IM>(p, base + (u32)jp * inner, jp, gb, ok);
+        rm[s] = fetch_in<IM>(p, base + (u32)jm * inner, jm, gb, ok && jm != jp);
       }
     }
   };
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
 #pragma unroll 1
     for (int ch = 0; ch < NSUB; ch++) { issue_loads_any(tile, ch); park_chunk(0, ch); }
   }
-  __syncthreads();
+  lds_barrier();
   int cur = 0;
   for (; tile < p.ntiles; tile += gridDim.x) {
     const u32 nxt = tile + gridDim.x;
@@ -251,6 +261,13 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
         }
       }
 
+      // Park the prefetched chunk BEFORE issuing this sub-tile's stores: the wait in front of the
+      // parity split then covers loads only (vmcnt retires in order; after the stores it would
+      // also wait for them to reach memory).
+      if (has_next) {
+        if (!(ablate & 8)) park_chunk(cur ^ 1, sub);
+        else { double t = 0; for (int s = 0; s < CH; s++) t += rj[s] + rm[s]; if (t == 12345.678) park_chunk(cur ^ 1, sub); }
+      }
       // ---- stores: accumulator element r of a lane is row 4r + (lane >> 4), col lane & 15 ----
       if (!(ablate & 2) || ce[0] == 12345.678) {
         const double alpha = p.alpha;
@@ -279,12 +296,8 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
           }
         }
       }
-      if (has_next) {
-        if (!(ablate & 8)) park_chunk(cur ^ 1, sub);
-        else { double t = 0; for (int s = 0; s < CH; s++) t += rj[s] + rm[s]; if (t == 12345.678) park_chunk(cur ^ 1, sub); }
-      }
     }
-    __syncthreads();
+    lds_barrier();
     cur ^= 1;
   }
 }
@@ -311,7 +324,7 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.ablate = g_ablate;
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.ablate = g_ablate;
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Run the matvec in a loop for a few seconds per ablation setting and sample rocm-smi (sclk, power)."""
+import os, subprocess, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+sp = ge.load()
+P = 256
+op = sp.EllipticOp((P, P, P))
+U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+V = torch.empty_like(U)
+L = sp.lib()
+def smi():
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True, timeout=20).stdout
+        keep = [l.strip() for l in out.splitlines() if ("sclk" in l or "Power" in l or "mclk" in l or "fclk" in l or "junction" in l.lower()) and "GPU[0]" in l]
+        return " | ".join(keep)
+    except Exception as e:
+        return "smi failed: %r" % e
+for ab, name in ((0, "full"), (3, "compute only"), (4, "memory only")):
+    L.chebhip_debug_ablate(ab)
+    stop = False
+    res = []
+    def sampler():
+        time.sleep(1.0)
+        while not stop:
+            res.append(smi()); time.sleep(0.7)
+    th = threading.Thread(target=sampler); th.start()
+    t0 = time.time(); n = 0
+    while time.time() - t0 < 5.0:
+        for _ in range(200):
+            op.mult(U, V)
+        torch.cuda.synchronize(); n += 200
+    dt = time.time() - t0
+    stop = True; th.join()
+    print("%-14s %.1f us/matvec" % (name, dt / n * 1e6))
+    for r in res[:4]:
+        print("    ", r)
+L.chebhip_debug_ablate(0)
