@@ -133,6 +133,13 @@ def main():
         launch_s = (dev_ms * 1e-3) / (args.steps * launches_per_step)
         alg_bytes_launch = BYTES_PER_POINT * npts / launches_per_step / world
         achieved = alg_bytes_launch / launch_s
+        traffic = None      # HBM bytes per launch from the committed PMC profile of this kernel/config, if any
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         flops_launch = 6.0 * float(P) * npts / launches_per_step / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
         out = {
             "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
@@ -142,7 +149,7 @@ def main():
             "config": {"workload": "3-D Poisson MatMult_Elliptic -dim %d,%d,%d (gamma=0), global N(0,1) input seed %d" % (P, P, P, SEED),
                        "P": P, "parallelism": parallelism, "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "cheb_fused_kernel", "avg_launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "mfma_f64_tflops": flops_launch / launch_s / 1e12,

@@ -65,6 +65,16 @@ int cheb_plan_destroy(cheb_plan *plan);
 /* Number of elements N = prod(dims) the plan was created for. */
 long cheb_plan_size(const cheb_plan *plan);
 
+/* Slab / pencil building block for the multi-GPU path (no counterpart in the serial reference):
+ * a plan on a tensor that stores only the INTERIOR points of every line along `tr`
+ * (dims[tr] = P-2; the end points are implicit zeros) -- the layout of the reference's global
+ * vectors (SetupBC, elliptic.C:372-434) and of any slab cut from them along another dim. */
+int cheb_plan_create_trimmed(int rank, int tr, const int *dims, cheb_plan **out);
+/* y = acc + alpha * (D_tr D_tr x) at the stored points: one direction of the linear
+ * MatMult_Elliptic (elliptic.C:309-334 with eta = 1, deta = 0).  acc may be NULL, or alias y. */
+int cheb_apply_lap1d(cheb_plan *plan, const double *x_dev, const double *acc_dev, double alpha,
+                     double *y_dev, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Operator level: the scalar elliptic MatShell (elliptic.C:78-86,250-293).   */
 /* Vectors at this boundary are the reference's GLOBAL vectors: interior      */

@@ -29,6 +29,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 ABI_SYMBOLS = [
     "chebhip_last_error", "chebhip_version", "chebhip_arch", "chebhip_launch_count",
     "cheb_plan_create", "cheb_apply", "cheb_apply_host", "cheb_plan_destroy", "cheb_plan_size",
+    "cheb_plan_create_trimmed", "cheb_apply_lap1d",
     "ell_op_create", "ell_op_destroy", "ell_op_local_size", "ell_op_global_size",
     "ell_op_dirichlet_size", "ell_op_mult", "ell_op_mult_host", "ell_op_function",
     "ell_op_function_host", "ell_op_set_dirichlet", "ell_op_get_state", "ell_op_set_state",
@@ -66,6 +67,8 @@ def lib():
         L.chebhip_launch_count.restype = C.c_long
         L.cheb_plan_create.argtypes = [C.c_int, C.c_int, ip, C.POINTER(vp)]
         L.cheb_apply.argtypes = [vp, vp, vp, vp]
+        L.cheb_plan_create_trimmed.argtypes = [C.c_int, C.c_int, ip, C.POINTER(vp)]
+        L.cheb_apply_lap1d.argtypes = [vp, vp, vp, C.c_double, vp, vp]
         L.cheb_apply_host.argtypes = [vp, dp, dp]
         L.cheb_plan_destroy.argtypes = [vp]
         L.cheb_plan_size.argtypes = [vp]
@@ -135,6 +138,35 @@ class ChebPlan:
         assert x.size == self.size
         y = np.empty_like(x)
         _chk(lib().cheb_apply_host(self._h, _np_dp(x), _np_dp(y)))
+        return y
+
+    def destroy(self):
+        if self._h:
+            lib().cheb_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Lap1dPlan:
+    """y = acc + alpha * D_tr D_tr x on an interior-layout tensor (cheb_plan_create_trimmed /
+    cheb_apply_lap1d): one direction of the linear MatMult_Elliptic, usable on slabs and pencils."""
+
+    def __init__(self, dims, tr):
+        self.dims = tuple(int(d) for d in dims)
+        self.tr = int(tr)
+        h = C.c_void_p()
+        _chk(lib().cheb_plan_create_trimmed(len(self.dims), self.tr, _ints(self.dims), C.byref(h)))
+        self._h = h
+        self.size = lib().cheb_plan_size(h)
+
+    def apply(self, x, y, acc=None, alpha=1.0):
+        ap = _dev_ptr(acc, self.size) if acc is not None else None
+        _chk(lib().cheb_apply_lap1d(self._h, _dev_ptr(x, self.size), ap, alpha, _dev_ptr(y, self.size), _stream()))
         return y
 
     def destroy(self):

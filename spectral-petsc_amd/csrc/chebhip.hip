@@ -55,6 +55,7 @@ struct cheb_plan {
   long N = 0;
   unsigned inner = 1, ncols = 0;
   DiffMat mat;
+  bool trimmed = false;                 // created by cheb_plan_create_trimmed
   double *hx = nullptr, *hy = nullptr;  // staging for the host-pointer path
 };
 
@@ -94,9 +95,52 @@ extern "C" int cheb_plan_create(int rank, int tr, const int *dims, cheb_plan **o
 
 extern "C" long cheb_plan_size(const cheb_plan *p) { return p ? p->N : -1; }
 
+// Plan on a tensor that stores only the interior points 1..P-2 of every line along `tr`
+// (dims[tr] = P-2 stored points, the two end points are implicit zeros): the layout of the
+// reference's global vectors (SetupBC, elliptic.C:372-434) and of any slab or pencil cut from them.
+extern "C" int cheb_plan_create_trimmed(int rank, int tr, const int *dims, cheb_plan **out) {
+  if (!out) return fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!dims || rank < 1 || rank > 16) return fail(CHEBHIP_ERR_DIMS, "rank = %d must be in 1..16", rank);
+  if (!(0 <= tr && tr < rank)) return fail(CHEBHIP_ERR_TDIM, "tdim out of range");
+  std::vector<int> full(dims, dims + rank);
+  if (dims[tr] < 1) return fail(CHEBHIP_ERR_SIZE, "dims[tr] = %d stored points but must be >= 1", dims[tr]);
+  full[tr] = dims[tr] + 2;
+  long N; unsigned inner;
+  int rc = check_geom(rank, tr, full.data(), &N, &inner);
+  if (rc) return rc;
+  if ((rc = require_device())) return rc;
+  cheb_plan *p = new (std::nothrow) cheb_plan;
+  if (!p) return fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  p->rank = rank; p->tr = tr; p->dims.assign(dims, dims + rank); p->trimmed = true;
+  p->N = N / full[tr] * dims[tr]; p->inner = inner; p->ncols = (unsigned)(N / full[tr]);
+  hipError_t e = diffmat_create(full[tr], &p->mat);
+  if (e != hipSuccess) { delete p; return fail(CHEBHIP_ERR_DEVICE, "diffmat_create: %s", hipGetErrorString(e)); }
+  *out = p;
+  return 0;
+}
+
+// y = acc + alpha * (D_tr D_tr x) at the stored (interior) points, x extended by zero end points:
+// one direction of the linear MatMult_Elliptic (elliptic.C:309-334 with eta = 1, deta = 0).
+// acc may be NULL (treated as 0) and may alias y.
+extern "C" int cheb_apply_lap1d(cheb_plan *p, const double *x, const double *acc, double alpha,
+                                double *y, void *stream) {
+  if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!p->trimmed) return fail(CHEBHIP_ERR_ARG, "cheb_apply_lap1d needs a plan from cheb_plan_create_trimmed");
+  if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct");
+  SweepParams sp = {};
+  sp.ncols = p->ncols; sp.inner = p->inner;
+  sp.in0 = x; sp.in_mode = IN_PLAIN; sp.trim = 1; sp.coef_mode = COEF_UNIT;
+  sp.alpha = alpha; sp.out = y;
+  if (acc) { sp.out_mode = OUT_ACC; sp.acc = acc; } else sp.out_mode = OUT_STORE;
+  HIPCHK(fused_launch(p->mat, sp, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int cheb_apply(cheb_plan *p, const double *x, double *y, void *stream) {
   if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct (as every ChebMult call site)");
+  if (p->trimmed) return fail(CHEBHIP_ERR_ARG, "plan is trimmed: use cheb_apply_lap1d");
   SweepParams sp = {};
   sp.ncols = p->ncols; sp.inner = p->inner;
   sp.in0 = x; sp.out = y; sp.alpha = 1.0;

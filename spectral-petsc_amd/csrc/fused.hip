@@ -81,6 +81,14 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
   if (p.variant & 1) { if (w < 4) __builtin_amdgcn_s_setprio(2); }
 
   const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
+  // XCD-aware tile walk: workgroups b and b+8 share an XCD (and its L2).  Give each XCD one
+  // contiguous range of tiles and let its CUs take neighbouring tiles at the same time, so that a
+  // 128-B line straddled by two neighbouring row pieces is fetched from HBM once, not once per XCD.
+  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
+  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
+  const u32 t_step = gridDim.x / nxcd;
   const int ld_n = JFAST ? tid / HP : tid % NT;
   const int ld_j = JFAST ? tid % HP : tid / NT;
   const int ld_lds0 = JFAST ? ld_n * LDJ + ld_j : ld_j * NT + (ld_n ^ ((ld_j & 1) << 4));
@@ -198,15 +206,15 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
     }
   };
 
-  u32 tile = blockIdx.x;
-  if (tile < p.ntiles) {
+  u32 tile = t_lo + blockIdx.x / nxcd;
+  if (tile < t_hi) {
 #pragma unroll 1
     for (int ch = 0; ch < NSUB; ch++) { issue_loads_any(tile, ch, rj, rm); park_chunk(ch, rj, rm); }
   }
   lds_barrier();
-  for (; tile < p.ntiles; tile += gridDim.x) {
-    const u32 nxt = tile + gridDim.x;
-    const bool has_next = nxt < p.ntiles;
+  for (; tile < t_hi; tile += t_step) {
+    const u32 nxt = tile + t_step;
+    const bool has_next = nxt < t_hi;
 
     // ======================= stage 1: g = D u, f = coef(g) -> F =======================
 #pragma unroll 1

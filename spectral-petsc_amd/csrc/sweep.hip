@@ -105,6 +105,14 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
   //          straddle blocks, so a line's offset is uniform base + lane term: no per-lane divide).
   // JFAST  : a tile is NT consecutive lines c of the flattened (outer, inner) line index.
   const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;    // tiles per outer block (COLFAST)
+  // XCD-aware tile walk: workgroups b and b+8 share an XCD (and its L2).  Give each XCD one
+  // contiguous range of tiles and let its CUs take neighbouring tiles at the same time, so that a
+  // 128-B line straddled by two neighbouring row pieces is fetched from HBM once, not once per XCD.
+  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
+  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
+  const u32 t_step = gridDim.x / nxcd;
 
   // loader slots of this thread
   const int ld_n = JFAST ? tid / HP : tid % NT;          // first line slot (JFAST) / line (COLFAST)
@@ -182,16 +190,16 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
   // compute-side invariants of this lane
   const int i0 = mt * 16 + (JFAST ? l16 : kq);        // output row of accumulator element r: i0 + (JFAST ? 0 : 4r)
 
-  u32 tile = blockIdx.x;
-  if (tile < p.ntiles) {
+  u32 tile = t_lo + blockIdx.x / nxcd;
+  if (tile < t_hi) {
 #pragma unroll 1
     for (int ch = 0; ch < NSUB; ch++) { issue_loads_any(tile, ch); park_chunk(0, ch); }
   }
   lds_barrier();
   int cur = 0;
-  for (; tile < p.ntiles; tile += gridDim.x) {
-    const u32 nxt = tile + gridDim.x;
-    const bool has_next = nxt < p.ntiles;
+  for (; tile < t_hi; tile += t_step) {
+    const u32 nxt = tile + t_step;
+    const bool has_next = nxt < t_hi;
     const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
     // tile base (COLFAST): uniform
     const u32 t_o = tile / tpo, t_q0 = (tile - t_o * tpo) * NT;

@@ -1,0 +1,138 @@
+"""Slab-partitioned linear Poisson matvec across G ranks (one process per GPU, RCCL over xGMI).
+
+The reference is strictly serial (elliptic.C:262 VecCreateSeq; nk.c:63 refuses size != 1), so
+there is no reference behaviour to copy here except the answer: for any G the result equals the
+G = 1 vector to rounding.
+
+Layout.  Everything lives in the interior layout of the reference's global vector
+(M0, M1, ..) = dims - 2, row-major (SetupBC, elliptic.C:372-434).  Rank r owns the slab of
+interior planes [s0[r], s0[r+1]) along dim 0.  V = -(L0 + L1 + ... ) U with L_k = D_k D_k on
+zero-extended lines (MatMult_Elliptic with eta = 1, deta = 0, elliptic.C:297-339):
+
+  local      W   = -L1 U - L2 U - ...     fused launches on the slab           (cheb_apply_lap1d)
+  exchange   UT  = all-to-all(U)          slab (m0, M1, R) -> pencil (M0, m1, R), split along dim 1
+  pencil     TT  = -L0 UT                 one fused launch on the pencil
+  exchange   T   = all-to-all(TT)         back to the slab
+  combine    V   = W + T
+
+The two exchanges are the only collectives (torch.distributed all_to_all_single = RCCL
+all-to-all; each GPU sends 7 direct xGMI messages).  The forward exchange overlaps the first
+local launch, the backward exchange the last one (separate HIP stream).  The accumulation order
+differs from the serial k = 0,1,2 order (k = 0 arrives last), which changes the result in the
+last bits only.
+
+The local arithmetic is delegated to a backend: HipBackend (the product: C-ABI calls on device
+tensors).  tests/ supplies an oracle-based CPU backend to exercise the exchange logic under gloo.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def split_sizes(n, parts):
+    """Near-equal contiguous split of n planes over `parts` ranks (first n % parts get one more)."""
+    q, r = divmod(n, parts)
+    return [q + (1 if i < r else 0) for i in range(parts)]
+
+
+class HipBackend:
+    """Local arithmetic on device tensors through libchebhip.so (cheb_apply_lap1d)."""
+
+    def __init__(self, sp):
+        self.sp = sp
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._plans = {}
+
+    def lap1d(self, x, shape, axis, out, acc=None, alpha=1.0):
+        key = (tuple(shape), axis)
+        if key not in self._plans:
+            self._plans[key] = self.sp.Lap1dPlan(shape, axis)
+        return self._plans[key].apply(x, out, acc, alpha)
+
+    def side_stream(self):
+        return torch.cuda.Stream()
+
+
+class DistPoissonOp:
+    def __init__(self, dims, backend, group=None):
+        assert len(dims) >= 2, "slab partitioning needs at least two dimensions"
+        self.dims = tuple(int(d) for d in dims)
+        self.M = tuple(d - 2 for d in self.dims)
+        assert min(self.M) >= 1
+        self.backend = backend
+        self.group = group
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        G, M = self.G, self.M
+        self.R = int(np.prod(M[2:])) if len(M) > 2 else 1          # trailing dims flattened
+        self.m0 = split_sizes(M[0], G)
+        self.m1 = split_sizes(M[1], G)
+        self.s0 = np.concatenate([[0], np.cumsum(self.m0)])
+        self.s1 = np.concatenate([[0], np.cumsum(self.m1)])
+        r = self.rank
+        self.slab_shape = (self.m0[r],) + M[1:]
+        self.pencil_shape = (M[0], self.m1[r]) + M[2:]
+        self.local_size = int(np.prod(self.slab_shape))
+        self.pencil_size = int(np.prod(self.pencil_shape))
+        dev = backend.device
+        # forward exchange: slab -> send buffer ordered by destination rank s = block U[:, s1[s]:s1[s+1], :]
+        idx = np.arange(self.local_size, dtype=np.int64).reshape(self.m0[r], M[1], self.R)
+        perm = np.concatenate([idx[:, self.s1[s]:self.s1[s + 1], :].ravel() for s in range(G)])
+        self.fwd_perm = torch.from_numpy(perm).to(dev)
+        self.fwd_send = [self.m0[r] * self.m1[s] * self.R for s in range(G)]
+        self.fwd_recv = [self.m0[s] * self.m1[r] * self.R for s in range(G)]   # lands as the pencil, no unpack
+        # backward exchange: pencil rows s0[s]:s0[s+1] are contiguous -> no pack; unpack by the inverse map
+        inv = np.empty(self.local_size, dtype=np.int64)
+        inv[perm] = np.arange(self.local_size, dtype=np.int64)
+        self.bwd_unperm = torch.from_numpy(inv).to(dev)
+        self.W = torch.empty(self.local_size, dtype=torch.float64, device=dev)
+        self.sendbuf = torch.empty(self.local_size, dtype=torch.float64, device=dev)
+        self.UT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
+        self.TT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
+        self.T = torch.empty(self.local_size, dtype=torch.float64, device=dev)
+        self.comm_stream = backend.side_stream() if G > 1 else None
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def random_input(self, seed):
+        """Rank-local slab of the global N(0,1) vector: every G sees the same global field."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        full = torch.randn(int(np.prod(self.M)), dtype=torch.float64, generator=g).reshape(self.M[0], -1)
+        r = self.rank
+        return full[self.s0[r]:self.s0[r + 1]].reshape(-1).contiguous().to(self.backend.device)
+
+    def _a2a(self, out, inp, out_split, in_split):
+        if self.G == 1:
+            out.copy_(inp)
+        else:
+            dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
+
+    # ---- the matvec ----------------------------------------------------------------------------
+    def mult(self, U, V):
+        be, M = self.backend, self.M
+        d = len(M)
+        cs = self.comm_stream
+        if cs is not None:
+            cur = torch.cuda.current_stream()
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):
+                torch.index_select(U, 0, self.fwd_perm, out=self.sendbuf)
+                self._a2a(self.UT, self.sendbuf, self.fwd_recv, self.fwd_send)
+        else:
+            torch.index_select(U, 0, self.fwd_perm, out=self.sendbuf)
+            self._a2a(self.UT, self.sendbuf, self.fwd_recv, self.fwd_send)
+        # local directions 1..d-1 on the slab (overlap the forward exchange)
+        be.lap1d(U, self.slab_shape, 1, self.W, None, -1.0)
+        if cs is not None:
+            with torch.cuda.stream(cs):
+                be.lap1d(self.UT, self.pencil_shape, 0, self.TT, None, -1.0)
+                self._a2a(self.sendbuf, self.TT, self.fwd_send, self.fwd_recv)   # back: roles of the splits swap
+        else:
+            be.lap1d(self.UT, self.pencil_shape, 0, self.TT, None, -1.0)
+            self._a2a(self.sendbuf, self.TT, self.fwd_send, self.fwd_recv)
+        for k in range(2, d):                                                    # overlap the backward exchange
+            be.lap1d(U, self.slab_shape, k, self.W, self.W, -1.0)
+        if cs is not None:
+            torch.cuda.current_stream().wait_stream(cs)
+        torch.index_select(self.sendbuf, 0, self.bwd_unperm, out=self.T)
+        torch.add(self.W, self.T, out=V)
+        return V

@@ -1,0 +1,91 @@
+"""World-size-2 (and 3) CPU tests of the slab-partitioned Poisson matvec: the exchange logic of
+spectral-petsc_amd/dist.py under the gloo backend, with the local arithmetic supplied by the CPU
+oracle (test-only backend).  The serial reference has no multi-rank code; the requirement is that
+any G reproduces the G = 1 answer to rounding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__ as ge
+import oracle_lib as orc
+
+
+class OracleBackend:
+    """Test-only stand-in for HipBackend: D_k D_k on zero-extended lines via the CPU oracle."""
+    device = torch.device("cpu")
+
+    def lap1d(self, x, shape, axis, out, acc=None, alpha=1.0):
+        a = x.numpy().reshape(shape)
+        pad = [(0, 0)] * len(shape)
+        pad[axis] = (1, 1)
+        full = np.pad(a, pad)
+        g = orc.cheb_mult(full, axis, orc.DIRECT)
+        t = orc.cheb_mult(g, axis, orc.DIRECT)
+        sl = [slice(None)] * len(shape)
+        sl[axis] = slice(1, -1)
+        res = alpha * t[tuple(sl)].reshape(-1)
+        if acc is not None:
+            res = acc.numpy() + res
+        out.copy_(torch.from_numpy(np.ascontiguousarray(res)))
+        return out
+
+    def side_stream(self):
+        return None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dims, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dsp = ge.load_dist()
+        op = dsp.DistPoissonOp(dims, OracleBackend())
+        U = op.random_input(20240229)
+        V = torch.empty_like(U)
+        op.mult(U, V)
+        op.mult(U, V)   # second call: buffers are reusable
+        q.put((rank, int(op.s0[rank]), V.numpy().copy(), U.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, (12, 11, 10)), (3, (9, 10)), (2, (8, 9, 5, 4))])
+def test_slab_matvec_matches_serial(world, dims):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[1])
+    V = np.concatenate([r[2] for r in res])
+    U = np.concatenate([r[3] for r in res])
+    # every rank count sees the same global input
+    g = torch.Generator(device="cpu").manual_seed(20240229)
+    Uref = torch.randn(int(np.prod([d - 2 for d in dims])), dtype=torch.float64, generator=g).numpy()
+    assert np.array_equal(U, Uref)
+    ref = orc.elliptic_mult(dims, Uref, mode=orc.DIRECT)
+    assert np.linalg.norm(V - ref) / np.linalg.norm(ref) < 1e-12
+
+
+def test_split_sizes():
+    dsp = ge.load_dist()
+    assert dsp.split_sizes(254, 8) == [32] * 6 + [31] * 2
+    assert sum(dsp.split_sizes(7, 3)) == 7
