@@ -1,0 +1,142 @@
+/*
+ * chebyshev_petsc.c -- the reference-side binding: the six PETSc symbols of chebyshev.h:27-34 and
+ * the two operator callbacks (MatMult_Elliptic elliptic.C:297, FormFunction elliptic.C:481)
+ * implemented over the C ABI of libchebhip.so (include/chebhip.h).
+ *
+ * NOT compiled in this repository: no PETSc is installed in the build image.  Written against the
+ * current PETSc API (>= 3.19: MatShellSetOperation, VecGetArrayRead, PetscCall); the 2008-era spellings
+ * the reference uses (PetscTruth, MatDestroy(Mat) by value, SETERRQ without comm) differ
+ * only in the macros below.
+ *
+ * Build:  mpicc -c chebyshev_petsc.c -I$PETSC_DIR/include -I$PETSC_DIR/$PETSC_ARCH/include -I../include
+ * Link :  ... chebyshev_petsc.o -L../spectral-petsc_amd -lchebhip $PETSC_LIB     (instead of -lfftw3)
+ */
+#include "chebyshev.h"
+#include "chebhip.h"
+
+static PetscErrorCode cheb_err(int rc) {
+  /* chebhip.h error codes -> PETSc classes (chebyshev.c:18,98,106,122 use PETSC_ERR_USER) */
+  if (!rc) return PETSC_SUCCESS;
+  switch (rc) {
+    case CHEBHIP_ERR_SIZE: case CHEBHIP_ERR_TDIM: case CHEBHIP_ERR_DIMS:
+      SETERRQ(PETSC_COMM_SELF, PETSC_ERR_USER, "%s", chebhip_last_error());
+    case CHEBHIP_ERR_ARG:
+      SETERRQ(PETSC_COMM_SELF, PETSC_ERR_ARG_WRONG, "%s", chebhip_last_error());
+    case CHEBHIP_ERR_MEMORY:
+      SETERRQ(PETSC_COMM_SELF, PETSC_ERR_MEM, "%s", chebhip_last_error());
+    default:
+      SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "%s", chebhip_last_error());
+  }
+}
+
+/* ---- kernel level: MatCreateCheb / ChebMult / ChebDestroy (chebyshev.c:89-235) ---------------- */
+PetscErrorCode MatCreateCheb(MPI_Comm comm, int rank, int tr, int *dims, unsigned flag,
+                             Vec vx, Vec vy, Mat *A) {
+  cheb_plan *plan;
+  PetscInt   n;
+  (void)flag; (void)vy;                       /* FFTW planner flag: ignored; Vecs are size prototypes */
+  PetscFunctionBegin;
+  PetscCall(VecGetSize(vx, &n));
+  PetscCall(cheb_err(cheb_plan_create(rank, tr, dims, &plan)));
+  if (cheb_plan_size(plan) != (long)n) {      /* chebyshev.c:122 */
+    cheb_plan_destroy(plan);
+    SETERRQ(comm, PETSC_ERR_USER, "dimensions do not agree: n = %" PetscInt_FMT " but stride = %ld", n, cheb_plan_size(plan));
+  }
+  PetscCall(MatCreateShell(comm, n, n, n, n, plan, A));
+  PetscCall(MatShellSetOperation(*A, MATOP_MULT, (void (*)(void))ChebMult));
+  PetscCall(MatShellSetOperation(*A, MATOP_DESTROY, (void (*)(void))ChebDestroy));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode ChebMult(Mat A, Vec vx, Vec vy) {
+  cheb_plan         *plan;
+  const PetscScalar *x;
+  PetscScalar       *y;
+  PetscFunctionBegin;
+  PetscCall(MatShellGetContext(A, &plan));
+#if defined(PETSC_HAVE_HIP) && defined(CHEBHIP_USE_DEVICE_VECS)
+  /* VECHIP vectors: no staging, asynchronous on PETSc's stream */
+  PetscCall(VecHIPGetArrayRead(vx, &x));
+  PetscCall(VecHIPGetArrayWrite(vy, &y));
+  PetscCall(cheb_err(cheb_apply(plan, x, y, NULL)));
+  PetscCall(VecHIPRestoreArrayWrite(vy, &y));
+  PetscCall(VecHIPRestoreArrayRead(vx, &x));
+#else
+  /* host Vecs, as the reference's VecGetArray (chebyshev.c:151-152): staged through HBM */
+  PetscCall(VecGetArrayRead(vx, &x));
+  PetscCall(VecGetArray(vy, &y));
+  PetscCall(cheb_err(cheb_apply_host(plan, x, y)));
+  PetscCall(VecRestoreArray(vy, &y));
+  PetscCall(VecRestoreArrayRead(vx, &x));
+#endif
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode ChebDestroy(Mat A) {
+  cheb_plan *plan;
+  PetscFunctionBegin;
+  PetscCall(MatShellGetContext(A, &plan));
+  cheb_plan_destroy(plan);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* rank-1 twins (chebyshev.c:8-85) */
+PetscErrorCode MatCreateChebD1(MPI_Comm comm, Vec vx, Vec vy, unsigned flag, Mat *A) {
+  PetscInt n; int dims[1];
+  PetscFunctionBegin;
+  PetscCall(VecGetSize(vx, &n));
+  dims[0] = (int)n;
+  PetscCall(MatCreateCheb(comm, 1, 0, dims, flag, vx, vy, A));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+PetscErrorCode ChebD1Mult(Mat A, Vec vx, Vec vy) { return ChebMult(A, vx, vy); }
+PetscErrorCode ChebD1Destroy(Mat A) { return ChebDestroy(A); }
+
+/* ---- operator level: what elliptic.C registers at :179 and :289 ------------------------------- */
+/* In elliptic.C the MatElliptic ctx (elliptic.C:78-86) is replaced by one ell_op handle:
+ *
+ *   MatCreate_Elliptic(comm, d, dim, flag, bf, &vG, &A)   (elliptic.C:250-293)
+ *     -> ell_op_create(d, dim, &op); VecCreateSeq(comm, ell_op_global_size(op), &vG);
+ *        MatCreateShell(comm, n, n, n, n, op, &A);
+ *        MatShellSetOperation(A, MATOP_MULT, MatMult_Elliptic_hip);
+ *        MatShellSetOperation(A, MATOP_DESTROY, MatDestroy_Elliptic_hip);
+ */
+PetscErrorCode MatMult_Elliptic_hip(Mat A, Vec U, Vec V) {
+  ell_op            *op;
+  const PetscScalar *u;
+  PetscScalar       *v;
+  PetscFunctionBegin;
+  PetscCall(MatShellGetContext(A, &op));
+  PetscCall(VecGetArrayRead(U, &u));
+  PetscCall(VecGetArray(V, &v));
+  PetscCall(cheb_err(ell_op_mult_host(op, u, v)));      /* or ell_op_mult() on VECHIP arrays */
+  PetscCall(VecRestoreArray(V, &v));
+  PetscCall(VecRestoreArrayRead(U, &u));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+typedef struct { ell_op *op; Vec b; PetscReal gamma, exponent; } AppCtxHip;   /* AppCtx, elliptic.C:88-94 */
+
+PetscErrorCode FormFunction_hip(SNES snes, Vec U, Vec rhs, void *void_ac) {
+  AppCtxHip         *ac = (AppCtxHip *)void_ac;
+  const PetscScalar *u, *b;
+  PetscScalar       *r;
+  (void)snes;
+  PetscFunctionBegin;
+  PetscCall(VecGetArrayRead(U, &u));
+  PetscCall(VecGetArrayRead(ac->b, &b));
+  PetscCall(VecGetArray(rhs, &r));
+  PetscCall(cheb_err(ell_op_function_host(ac->op, ac->gamma, ac->exponent, u, b, r)));
+  PetscCall(VecRestoreArray(rhs, &r));
+  PetscCall(VecRestoreArrayRead(ac->b, &b));
+  PetscCall(VecRestoreArrayRead(U, &u));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode MatDestroy_Elliptic_hip(Mat A) {
+  ell_op *op;
+  PetscFunctionBegin;
+  PetscCall(MatShellGetContext(A, &op));
+  ell_op_destroy(op);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
