@@ -495,3 +495,245 @@ int orc_elliptic_exact(int d, const int *dims, int exact, double gamma, double e
   free(ixL);
   return 0;
 }
+
+/* ========================================================================= */
+/* Stokes restatement (stokes.C), -boundary 0.                                */
+/* ========================================================================= */
+static void stokes_counts(int d, const int *dims, long *N, long *I) {
+  *N = orc_local_size(d, dims); *I = orc_global_size(d, dims);
+}
+
+/* util.C:129-144 polyInterp, verbatim arithmetic (Neville table in w[i*4+..]). */
+static void poly_interp(int n, const double *x, double *w, double x0, double x1, double *f0, double *f1) {
+  int o = 0, e;
+  for (int di = 1; di < n; di++) {
+    o = di % 2; e = (o + 1) % 2;
+    for (int i = 0; i < n - di; i++) {
+      w[i * 4 + 2 * o]     = ((x0 - x[i + di]) * w[i * 4 + 2 * e]     + (x[i] - x0) * w[(i + 1) * 4 + 2 * e])     / (x[i] - x[i + di]);
+      w[i * 4 + 2 * o + 1] = ((x1 - x[i + di]) * w[i * 4 + 2 * e + 1] + (x[i] - x1) * w[(i + 1) * 4 + 2 * e + 1]) / (x[i] - x[i + di]);
+    }
+  }
+  *f0 = w[2 * o];
+  *f1 = w[2 * o + 1];
+}
+
+int orc_stokes_pressure_reduce(int d, const int *dims, double *pres) {
+  if (d < 2 || d > 3) return 6;                                   /* stokes.C:1036 */
+  const int m = dims[0], n = dims[1], p = (d == 2) ? 1 : dims[2];
+  int mnp = m > n ? m : n; if (p > mnp) mnp = p;
+  double *work = (double *)malloc(sizeof(double) * 4 * (size_t)mnp), *x = (double *)malloc(sizeof(double) * (size_t)mnp);
+  /* coordinates: x_i = cos(i pi/(dim-1)) (stokes.C:296) */
+#define CX(i) cos((i) * ORC_PI / (m - 1))
+#define CY(j) cos((j) * ORC_PI / (n - 1))
+#define CZ(k) cos((k) * ORC_PI / (p - 1))
+  for (int i = 1; i < m; i++) {                                   /* stokes.C:1042 */
+    if (p > 1) {
+      for (int j = 1; j < n; j++) {
+        const long iM = ((long)i * n + j) * p + 0, iP = ((long)i * n + j) * p + p - 1;
+        for (int k = 1; k < p - 1; k++) { x[k - 1] = CZ(k); work[(k - 1) * 4] = work[(k - 1) * 4 + 1] = pres[iM + k]; }
+        if (p - 2 >= 1) poly_interp(p - 2, x, work, CZ(0), CZ(p - 1), &pres[iM], &pres[iP]);
+      }
+    }
+    for (int k = 0; k < p; k++) {
+      const long iM = ((long)i * n + 0) * p + k, iP = ((long)i * n + n - 1) * p + k;
+      for (int j = 1; j < n - 1; j++) { x[j - 1] = CY(j); work[(j - 1) * 4] = work[(j - 1) * 4 + 1] = pres[iM + (long)j * p]; }
+      if (n - 2 >= 1) poly_interp(n - 2, x, work, CY(0), CY(n - 1), &pres[iM], &pres[iP]);
+    }
+  }
+  for (int j = 0; j < n; j++)
+    for (int k = 0; k < p; k++) {
+      const long iM = ((long)0 * n + j) * p + k, iP = ((long)(m - 1) * n + j) * p + k;
+      for (int i = 1; i < m - 1; i++) { x[i - 1] = CX(i); work[(i - 1) * 4] = work[(i - 1) * 4 + 1] = pres[iM + (long)i * n * p]; }
+      if (m - 2 >= 1) poly_interp(m - 2, x, work, CX(0), CX(m - 1), &pres[iM], &pres[iP]);
+    }
+#undef CX
+#undef CY
+#undef CZ
+  free(work); free(x);
+  return 0;
+}
+
+/* DV[i]: rank d+1, dims = {dim..., d}, tr = i (stokes.C:284-290); DP[i]: rank d scalar. */
+static int stokes_DV(int d, const int *dims, int i, const double *x, double *y, int mode, int nt) {
+  int cd[17];
+  for (int k = 0; k < d; k++) cd[k] = dims[k];
+  cd[d] = d;
+  return orc_cheb_mult(d + 1, i, cd, x, y, mode, nt);
+}
+
+/* velocity local <- global (scatterVL, zero elsewhere), optional dirichlet (scatterDL) */
+static void stokes_v_local(int d, long N, const int *ixL, const double *vG, const double *dirichlet, double *xL) {
+  long dd = 0;
+  for (long l = 0; l < N; l++)
+    for (int k = 0; k < d; k++) {
+      if (ixL[l] >= 0) xL[l * d + k] = vG[(long)ixL[l] * d + k];
+      else { xL[l * d + k] = dirichlet ? dirichlet[dd] : 0.0; dd++; }
+    }
+}
+
+int orc_stokes_mult_vv(int d, const int *dims, const double *eta, const double *deta, const double *Strain,
+                       const double *vG_in, double *vG_out, int mode, int nt) {
+  if (d < 1 || d > 3) return 6;
+  long N, I; stokes_counts(d, dims, &N, &I);
+  int *ixL = build_ixL(d, dims, N);
+  const long nd = N * d;
+  double *xL = (double *)malloc(sizeof(double) * (size_t)nd * (2 + 2 * d));
+  double *yL = xL + nd, *V = yL + nd, *W = V + (long)d * nd;
+  int err = 0;
+  stokes_v_local(d, N, ixL, vG_in, NULL, xL);                      /* stokes.C:634-637 */
+  for (int i = 0; i < d && !err; i++) err = stokes_DV(d, dims, i, xL, V + (long)i * nd, mode, nt);  /* :639 */
+  for (long i = 0; i < N; i++) {                                   /* :647-662 */
+    double strain[3][3], z = 0.0;
+    for (int j = 0; j < d; j++)
+      for (int k = 0; k < d; k++) {
+        strain[j][k] = 0.5 * (V[(long)j * nd + i * d + k] + V[(long)k * nd + i * d + j]);
+        z += strain[j][k] * Strain[(long)j * nd + i * d + k];
+      }
+    for (int j = 0; j < d; j++)
+      for (int k = 0; k < d; k++) {
+        const double s = eta[i] * strain[j][k];
+        V[(long)j * nd + i * d + k] = s + deta[i] * Strain[(long)j * nd + i * d + k] * z;
+      }
+  }
+  for (int i = 0; i < d && !err; i++) err = stokes_DV(d, dims, i, V + (long)i * nd, W + (long)i * nd, mode, nt);  /* :668 */
+  memset(yL, 0, sizeof(double) * (size_t)nd);
+  for (int i = 0; i < d; i++) for (long a = 0; a < nd; a++) yL[a] += -1.0 * W[(long)i * nd + a];    /* :670-671 */
+  for (long l = 0; l < N; l++) if (ixL[l] >= 0) for (int k = 0; k < d; k++) vG_out[(long)ixL[l] * d + k] = yL[l * d + k];
+  free(xL); free(ixL);
+  return err;
+}
+
+int orc_stokes_divergence(int d, const int *dims, const double *dirichlet, const double *vG, double *pG, int mode, int nt) {
+  if (d < 1 || d > 3) return 6;
+  long N, I; stokes_counts(d, dims, &N, &I);
+  int *ixL = build_ixL(d, dims, N);
+  double *xL = (double *)malloc(sizeof(double) * (size_t)N * (d + 3));
+  double *p0 = xL + N * d, *p1 = p0 + N, *p2 = p1 + N;
+  int err = 0;
+  stokes_v_local(d, N, ixL, vG, dirichlet, xL);                    /* stokes.C:575-582 */
+  memset(p2, 0, sizeof(double) * (size_t)N);
+  for (int i = 0; i < d && !err; i++) {                            /* :584-591 */
+    for (long l = 0; l < N; l++) p0[l] = xL[l * d + i];            /* VecStrideGather */
+    err = orc_cheb_mult(d, i, dims, p0, p1, mode, nt);
+    for (long l = 0; l < N; l++) p2[l] += 1.0 * p1[l];
+  }
+  for (long l = 0; l < N; l++) if (ixL[l] >= 0) pG[ixL[l]] = p2[l];
+  free(xL); free(ixL);
+  return err;
+}
+
+int orc_stokes_mult_vp(int d, const int *dims, const double *pG, double *vG, int mode, int nt) {
+  if (d < 2 || d > 3) return 6;
+  long N, I; stokes_counts(d, dims, &N, &I);
+  int *ixL = build_ixL(d, dims, N);
+  double *p0 = (double *)malloc(sizeof(double) * (size_t)N * (2 + d));
+  double *p1 = p0 + N, *vL = p1 + N;
+  for (long l = 0; l < N; l++) p0[l] = ixL[l] >= 0 ? pG[ixL[l]] : 0.0;          /* stokes.C:606-608 */
+  int err = orc_stokes_pressure_reduce(d, dims, p0);               /* :609 */
+  memset(vL, 0, sizeof(double) * (size_t)N * d);
+  for (int i = 0; i < d && !err; i++) {                            /* :611-614 */
+    err = orc_cheb_mult(d, i, dims, p0, p1, mode, nt);
+    for (long l = 0; l < N; l++) vL[l * d + i] = p1[l];            /* VecStrideScatter */
+  }
+  for (long l = 0; l < N; l++) if (ixL[l] >= 0) for (int k = 0; k < d; k++) vG[(long)ixL[l] * d + k] = vL[l * d + k];
+  free(p0); free(ixL);
+  return err;
+}
+
+int orc_stokes_mult(int d, const int *dims, const double *eta, const double *deta, const double *strain,
+                    const double *xG, double *yG, int mode, int nt) {
+  long N, I; stokes_counts(d, dims, &N, &I);
+  double *vG0 = (double *)malloc(sizeof(double) * (size_t)I * (3 * d + 2));
+  double *vG1 = vG0 + I * d, *vG2 = vG1 + I * d, *pG0 = vG2 + I * d, *pG1 = pG0 + I;
+  for (long n = 0; n < I; n++) { for (int k = 0; k < d; k++) vG0[n * d + k] = xG[n * (d + 1) + k]; pG0[n] = xG[n * (d + 1) + d]; }  /* scatterGV/GP */
+  int err = orc_stokes_mult_vv(d, dims, eta, deta, strain, vG0, vG1, mode, nt);                 /* stokes.C:508 */
+  if (!err) err = orc_stokes_divergence(d, dims, NULL, vG0, pG1, mode, nt);                      /* :509 */
+  if (!err) err = orc_stokes_mult_vp(d, dims, pG0, vG2, mode, nt);                               /* :512 */
+  for (long a = 0; a < I * d; a++) vG1[a] += 1.0 * vG2[a];                                       /* :513 */
+  for (long n = 0; n < I; n++) { for (int k = 0; k < d; k++) yG[n * (d + 1) + k] = vG1[n * d + k]; yG[n * (d + 1) + d] = pG1[n]; }
+  free(vG0);
+  return err;
+}
+
+static void rheology_eval(const orc_rheology *rh, double gamma, double *eta, double *deta) {
+  if (!rh || rh->kind == 0) { *eta = 1.0; *deta = 0.0; return; }   /* stokes.C:1924 */
+  const double n = rh->exponent, p = (1.0 - n) / (2.0 * n);          /* :1933-1934 */
+  *eta = rh->hardness * pow(rh->regularization + gamma / rh->gamma0, p);
+  if (fabs(n) > 1.0e-5) *deta = rh->hardness * p / rh->gamma0 * pow(rh->regularization + gamma / rh->gamma0, p - 1.0);
+  else *deta = 0.0;
+}
+
+int orc_stokes_function(int d, const int *dims, const orc_rheology *rh, const double *dirichlet,
+                        const double *force, const double *xG, double *yG,
+                        double *eta_o, double *deta_o, double *strain_o, int mode, int nt) {
+  if (d < 2 || d > 3) return 6;
+  long N, I; stokes_counts(d, dims, &N, &I);
+  int *ixL = build_ixL(d, dims, N);
+  const long nd = N * d;
+  double *buf = (double *)malloc(sizeof(double) * ((size_t)nd * (2 + 3 * d) + 2 * (size_t)N + (size_t)I * (3 * d + 2)));
+  double *xL = buf, *yL = xL + nd, *V = yL + nd, *W = V + (long)d * nd, *strain = W + (long)d * nd;
+  double *eta = strain + (long)d * nd, *deta = eta + N;
+  double *vG0 = deta + N, *vG1 = vG0 + I * d, *vG2 = vG1 + I * d, *pG0 = vG2 + I * d, *pG1 = pG0 + I;
+  int err = 0;
+  for (long n = 0; n < I; n++) { for (int k = 0; k < d; k++) vG0[n * d + k] = xG[n * (d + 1) + k]; pG0[n] = xG[n * (d + 1) + d]; }  /* stokes.C:691-694 */
+  stokes_v_local(d, N, ixL, vG0, dirichlet, xL);                   /* :695-699 */
+  for (int i = 0; i < d && !err; i++) err = stokes_DV(d, dims, i, xL, strain + (long)i * nd, mode, nt);  /* :701 */
+  for (long i = 0; i < N; i++) {                                   /* :710-725 */
+    double s[3][3], gamma = 0.0;
+    for (int j = 0; j < d; j++)
+      for (int k = 0; k < d; k++) {
+        s[j][k] = 0.5 * (strain[(long)j * nd + i * d + k] + strain[(long)k * nd + i * d + j]);
+        gamma += 0.5 * (s[j][k] * s[j][k]);
+      }
+    rheology_eval(rh, gamma, &eta[i], &deta[i]);
+    for (int j = 0; j < d; j++)
+      for (int k = 0; k < d; k++) { V[(long)j * nd + i * d + k] = eta[i] * s[j][k]; strain[(long)j * nd + i * d + k] = s[j][k]; }
+  }
+  for (int i = 0; i < d && !err; i++) err = stokes_DV(d, dims, i, V + (long)i * nd, W + (long)i * nd, mode, nt);  /* :737 */
+  memset(yL, 0, sizeof(double) * (size_t)nd);
+  for (int i = 0; i < d; i++) for (long a = 0; a < nd; a++) yL[a] += -1.0 * W[(long)i * nd + a];    /* :739-740 */
+  for (long l = 0; l < N; l++) if (ixL[l] >= 0) for (int k = 0; k < d; k++) vG1[(long)ixL[l] * d + k] = yL[l * d + k];  /* :743 */
+  if (!err) err = orc_stokes_divergence(d, dims, dirichlet, vG0, pG1, mode, nt);   /* :746, withDirichlet */
+  if (!err) err = orc_stokes_mult_vp(d, dims, pG0, vG2, mode, nt);                 /* :747 (overwrites vG0 in the reference) */
+  for (long a = 0; a < I * d; a++) vG1[a] += 1.0 * vG2[a];                         /* :750 */
+  for (long n = 0; n < I; n++) { for (int k = 0; k < d; k++) yG[n * (d + 1) + k] = vG1[n * d + k]; yG[n * (d + 1) + d] = pG1[n]; }
+  if (force) for (long a = 0; a < I * (d + 1); a++) yG[a] += -1.0 * force[a];      /* :756 */
+  if (eta_o) memcpy(eta_o, eta, sizeof(double) * (size_t)N);
+  if (deta_o) memcpy(deta_o, deta, sizeof(double) * (size_t)N);
+  if (strain_o) memcpy(strain_o, strain, sizeof(double) * (size_t)nd * d);
+  free(buf); free(ixL);
+  return err;
+}
+
+int orc_stokes_exact(int d, const int *dims, int exact, double *U, double *U2, double *dirichlet) {
+  if (d < 2 || d > 3) return 6;
+  long N, I; stokes_counts(d, dims, &N, &I);
+  int *ixL = build_ixL(d, dims, N);
+  int ind[4] = {0, 0, 0, 0};
+  long dd = 0;
+  for (long l = 0; l < N; l++) {
+    double c[3] = {0, 0, 0}, val[4] = {0, 0, 0, 0}, rhs[4] = {0, 0, 0, 0};
+    for (int j = 0; j < d; j++) c[j] = cos(ind[j] * ORC_PI / (dims[j] - 1));   /* stokes.C:296 */
+    const double eta = 1.0;
+    if (exact == 1 || exact == 2) {                                /* stokes.C:1963-2012 */
+      const double u = sin(0.5 * ORC_PI * c[0]) * cos(0.5 * ORC_PI * c[1]);
+      const double v = -cos(0.5 * ORC_PI * c[0]) * sin(0.5 * ORC_PI * c[1]);
+      /* Exact2 leaves the 3-D pressure slot unset in the reference (value[3] never written, :2000-2001);
+       * the restatement pins it to 0. */
+      const double p = (exact == 1) ? 0.25 * (cos(ORC_PI * c[0]) + cos(ORC_PI * c[1])) + 10 * (c[0] + c[1]) : 0.0;
+      val[0] = u; val[1] = v; if (d == 3) val[2] = 0.0; val[d] = p;
+      rhs[0] = (0.5 * ORC_PI) * (0.5 * ORC_PI) * eta * u; rhs[1] = (0.5 * ORC_PI) * (0.5 * ORC_PI) * eta * v;
+      if (exact == 1) { rhs[0] += -0.25 * ORC_PI * sin(ORC_PI * c[0]) + 10; rhs[1] += -0.25 * ORC_PI * sin(ORC_PI * c[1]) + 10; }
+      if (d == 3) rhs[2] = 0.0;
+      rhs[d] = 0.0;
+    } else if (exact != 0) { free(ixL); return 5; }
+    if (ixL[l] >= 0) {
+      for (int k = 0; k <= d; k++) { if (U) U[(long)ixL[l] * (d + 1) + k] = val[k]; if (U2) U2[(long)ixL[l] * (d + 1) + k] = rhs[k]; }
+    } else {
+      for (int k = 0; k < d; k++) { if (dirichlet) dirichlet[dd] = val[k]; dd++; }
+    }
+    for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
+  }
+  free(ixL);
+  return 0;
+}

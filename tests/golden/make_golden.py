@@ -111,6 +111,165 @@ def exp_field(dims):
     return sum(np.exp(g) for g in grids)
 
 
+# ---------------------------------------------------------------------------------------------
+# Stokes (stokes.C), -boundary 0 (all-Dirichlet velocity), numpy restatement
+# ---------------------------------------------------------------------------------------------
+def poly_interp(x, f, x0, x1):
+    """util.C:129-144 (Neville): value at x0 and x1 of the polynomial through (x, f)."""
+    n = len(x)
+    a = np.array(f, dtype=np.float64)
+    b = a.copy()
+    for di in range(1, n):
+        for i in range(n - di):
+            a[i] = ((x0 - x[i + di]) * a[i] + (x[i] - x0) * a[i + 1]) / (x[i] - x[i + di])
+            b[i] = ((x1 - x[i + di]) * b[i] + (x[i] - x1) * b[i + 1]) / (x[i] - x[i + di])
+    return a[0], b[0]
+
+
+def pressure_reduce(dims, pL):
+    """stokes.C:1029-1080, same sweep order (z inside the i-loop, then y, then x)."""
+    d = len(dims)
+    m, n = dims[0], dims[1]
+    p = 1 if d == 2 else dims[2]
+    P = pL.reshape(m, n, p).copy()
+    cx = np.cos(np.arange(m) * PI / (m - 1))
+    cy = np.cos(np.arange(n) * PI / (n - 1))
+    cz = np.cos(np.arange(p) * PI / (p - 1)) if p > 1 else np.zeros(1)
+    for i in range(1, m):
+        if p > 1:
+            for j in range(1, n):
+                P[i, j, 0], P[i, j, p - 1] = poly_interp(cz[1:p - 1], P[i, j, 1:p - 1], cz[0], cz[p - 1])
+        for k in range(p):
+            P[i, 0, k], P[i, n - 1, k] = poly_interp(cy[1:n - 1], P[i, 1:n - 1, k], cy[0], cy[n - 1])
+    for j in range(n):
+        for k in range(p):
+            P[0, j, k], P[m - 1, j, k] = poly_interp(cx[1:m - 1], P[1:m - 1, j, k], cx[0], cx[m - 1])
+    return P.reshape(pL.shape)
+
+
+def stokes_vv(dims, eta, deta, Strain, vG):
+    """stokes.C:623-676.  Local velocity arrays have shape dims + (d,)."""
+    d = len(dims)
+    mask = interior_mask(dims)
+    xL = np.zeros(dims + (d,))
+    xL[mask] = vG.reshape(-1, d)
+    V = [cheb_mult(xL, i) for i in range(d)]
+    strain = np.empty(dims + (d, d))
+    for j in range(d):
+        for k in range(d):
+            strain[..., j, k] = 0.5 * (V[j][..., k] + V[k][..., j])
+    z = np.zeros(dims)
+    for j in range(d):
+        for k in range(d):
+            z += strain[..., j, k] * Strain[j][..., k]
+    F = [np.empty(dims + (d,)) for _ in range(d)]
+    for j in range(d):
+        for k in range(d):
+            F[j][..., k] = eta * strain[..., j, k] + deta * Strain[j][..., k] * z
+    yL = np.zeros(dims + (d,))
+    for i in range(d):
+        yL += -1.0 * cheb_mult(F[i], i)
+    return yL[mask].reshape(-1)
+
+
+def stokes_div(dims, vG, dirichlet=None):
+    """stokes.C:570-595."""
+    d = len(dims)
+    mask = interior_mask(dims)
+    xL = np.zeros(dims + (d,))
+    xL[mask] = vG.reshape(-1, d)
+    if dirichlet is not None:
+        xL[~mask] = dirichlet.reshape(-1, d)
+    acc = np.zeros(dims)
+    for i in range(d):
+        acc += 1.0 * cheb_mult(np.ascontiguousarray(xL[..., i]), i)
+    return acc[mask].copy()
+
+
+def stokes_vp(dims, pG):
+    """stokes.C:599-619."""
+    d = len(dims)
+    mask = interior_mask(dims)
+    pL = np.zeros(dims)
+    pL[mask] = pG
+    pL = pressure_reduce(dims, pL)
+    vL = np.zeros(dims + (d,))
+    for i in range(d):
+        vL[..., i] = cheb_mult(pL, i)
+    return vL[mask].reshape(-1), pL
+
+
+def stokes_mult(dims, eta, deta, Strain, xG):
+    """stokes.C:499-519; full global vector = [v_0..v_{d-1}, p] per interior node."""
+    d = len(dims)
+    X = xG.reshape(-1, d + 1)
+    vG0, pG0 = np.ascontiguousarray(X[:, :d]).reshape(-1), np.ascontiguousarray(X[:, d])
+    vG1 = stokes_vv(dims, eta, deta, Strain, vG0)
+    pG1 = stokes_div(dims, vG0)
+    vG1 = vG1 + 1.0 * stokes_vp(dims, pG0)[0]
+    return np.concatenate([vG1.reshape(-1, d), pG1[:, None]], axis=1).reshape(-1)
+
+
+def rheology(kind, gamma, hardness=1.0, exponent=1.0, eps=1.0, gamma0=1.0):
+    """stokes.C:1920-1944."""
+    if kind == 0:
+        return np.ones_like(gamma), np.zeros_like(gamma)
+    n = exponent
+    p = (1.0 - n) / (2.0 * n)
+    eta = hardness * np.power(eps + gamma / gamma0, p)
+    deta = hardness * p / gamma0 * np.power(eps + gamma / gamma0, p - 1.0)
+    return eta, deta
+
+
+def stokes_function(dims, xG, dirichlet, force, rh):
+    """stokes.C:680-758."""
+    d = len(dims)
+    mask = interior_mask(dims)
+    X = xG.reshape(-1, d + 1)
+    vG0, pG0 = np.ascontiguousarray(X[:, :d]).reshape(-1), np.ascontiguousarray(X[:, d])
+    xL = np.zeros(dims + (d,))
+    xL[mask] = vG0.reshape(-1, d)
+    xL[~mask] = dirichlet.reshape(-1, d)
+    G = [cheb_mult(xL, i) for i in range(d)]
+    s = np.empty(dims + (d, d))
+    gamma = np.zeros(dims)
+    for j in range(d):
+        for k in range(d):
+            s[..., j, k] = 0.5 * (G[j][..., k] + G[k][..., j])
+            gamma += 0.5 * s[..., j, k] ** 2
+    eta, deta = rheology(*rh, gamma=gamma) if False else rheology(rh[0], gamma, *rh[1:])
+    yL = np.zeros(dims + (d,))
+    for i in range(d):
+        yL += -1.0 * cheb_mult(np.ascontiguousarray(eta[..., None] * s[..., i, :]), i)
+    vG1 = yL[mask].reshape(-1)
+    pG1 = stokes_div(dims, vG0, dirichlet)
+    vG1 = vG1 + 1.0 * stokes_vp(dims, pG0)[0]
+    y = np.concatenate([vG1.reshape(-1, d), pG1[:, None]], axis=1).reshape(-1)
+    y = y + -1.0 * force
+    strain = [np.ascontiguousarray(s[..., j, :]) for j in range(d)]
+    return y, eta, deta, strain
+
+
+def stokes_exact(dims, exact):
+    """stokes.C:1963-2012 via StokesCreateExactSolution (:942-1003); 3-D Exact2 pressure pinned to 0."""
+    d = len(dims)
+    grids = np.meshgrid(*[np.cos(np.arange(p) * PI / (p - 1)) for p in dims], indexing="ij")
+    x, y = grids[0], grids[1]
+    u = np.sin(0.5 * PI * x) * np.cos(0.5 * PI * y)
+    v = -np.cos(0.5 * PI * x) * np.sin(0.5 * PI * y)
+    p = 0.25 * (np.cos(PI * x) + np.cos(PI * y)) + 10 * (x + y) if exact == 1 else np.zeros(dims)
+    val = np.zeros(dims + (d + 1,))
+    rhs = np.zeros(dims + (d + 1,))
+    val[..., 0], val[..., 1], val[..., d] = u, v, p
+    rhs[..., 0] = (0.5 * PI) ** 2 * u
+    rhs[..., 1] = (0.5 * PI) ** 2 * v
+    if exact == 1:
+        rhs[..., 0] += -0.25 * PI * np.sin(PI * x) + 10
+        rhs[..., 1] += -0.25 * PI * np.sin(PI * y) + 10
+    mask = interior_mask(dims)
+    return val[mask].reshape(-1), rhs[mask].reshape(-1), val[~mask][:, :d].reshape(-1)
+
+
 def main():
     rng = np.random.default_rng(SEED)
     out = {}
@@ -154,6 +313,41 @@ def main():
         ell["ell_%s_fn_gradu" % tag] = np.stack([g.ravel() for g in gradu])
         ell["ell_%s_mult_nl" % tag] = elliptic_mult(dims, U, eta, deta, gradu)
     np.savez_compressed(os.path.join(HERE, "elliptic_golden.npz"), **ell)
+    st = {}
+    for dims in [(8, 7), (7, 6, 5)]:
+        tag = "x".join(str(v) for v in dims)
+        d = len(dims)
+        mask = interior_mask(dims)
+        I = int(mask.sum())
+        xG = rng.standard_normal(I * (d + 1))
+        ones, zeros = np.ones(dims), np.zeros(dims)
+        zS = [np.zeros(dims + (d,)) for _ in range(d)]
+        st["st_%s_x" % tag] = xG
+        st["st_%s_mult_lin" % tag] = stokes_mult(dims, ones, zeros, zS, xG)
+        X = xG.reshape(-1, d + 1)
+        vG, pG = np.ascontiguousarray(X[:, :d]).reshape(-1), np.ascontiguousarray(X[:, d])
+        st["st_%s_vv_lin" % tag] = stokes_vv(dims, ones, zeros, zS, vG)
+        st["st_%s_pv" % tag] = stokes_div(dims, vG)
+        vp, pL = stokes_vp(dims, pG)
+        st["st_%s_vp" % tag] = vp
+        st["st_%s_preduce" % tag] = pL.ravel()
+        # power-law state (README:52: -exponent 3 -eps 1e-4) from the Exact1 field plus noise
+        U, U2, dv = stokes_exact(dims, 1)
+        Un = U + 0.05 * rng.standard_normal(U.shape)
+        rh = (1, 1.0, 3.0, 1e-4, 1.0)
+        y, eta, deta, strain = stokes_function(dims, Un, dv, U2, rh)
+        st["st_%s_fn_x" % tag] = Un
+        st["st_%s_fn_force" % tag] = U2
+        st["st_%s_fn_dirichlet" % tag] = dv
+        st["st_%s_fn_y" % tag] = y
+        st["st_%s_fn_eta" % tag] = eta.ravel()
+        st["st_%s_fn_deta" % tag] = deta.ravel()
+        st["st_%s_fn_strain" % tag] = np.stack([a.ravel() for a in strain])
+        st["st_%s_mult_nl" % tag] = stokes_mult(dims, eta, deta, strain, xG)
+        ylin, *_ = stokes_function(dims, U, dv, U2, (0,))
+        st["st_%s_exact1_U" % tag] = U
+        st["st_%s_exact1_residual" % tag] = ylin
+    np.savez_compressed(os.path.join(HERE, "stokes_golden.npz"), **st)
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

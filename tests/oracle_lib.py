@@ -141,3 +141,119 @@ def elliptic_exact(dims, exact, gamma=0.0, exponent=2.0, cos_scale=1.0):
     if err:
         raise ValueError("orc_elliptic_exact error %d" % err)
     return u, u2, dv
+
+
+# ---------------------------------------------------------------------------------------------
+# Stokes (stokes.C), -boundary 0
+# ---------------------------------------------------------------------------------------------
+class Rheology(C.Structure):
+    _fields_ = [("kind", C.c_int), ("hardness", C.c_double), ("exponent", C.c_double),
+                ("regularization", C.c_double), ("gamma0", C.c_double)]
+
+
+def _bind_stokes():
+    L = lib()
+    if getattr(L, "_stokes_bound", False):
+        return L
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.orc_stokes_pressure_reduce.argtypes = [C.c_int, ip, dp]
+    L.orc_stokes_mult_vv.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp, C.c_int, C.c_int]
+    L.orc_stokes_divergence.argtypes = [C.c_int, ip, dp, dp, dp, C.c_int, C.c_int]
+    L.orc_stokes_mult_vp.argtypes = [C.c_int, ip, dp, dp, C.c_int, C.c_int]
+    L.orc_stokes_mult.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp, C.c_int, C.c_int]
+    L.orc_stokes_function.argtypes = [C.c_int, ip, C.POINTER(Rheology), dp, dp, dp, dp, dp, dp, dp, C.c_int, C.c_int]
+    L.orc_stokes_exact.argtypes = [C.c_int, ip, C.c_int, dp, dp, dp]
+    L._stokes_bound = True
+    return L
+
+
+def stokes_sizes(dims):
+    """(N local nodes, I interior nodes, gv, gp, g, dv)."""
+    d = len(dims)
+    N, I, D = sizes(dims)
+    return N, I, d * I, I, (d + 1) * I, d * D
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _state(dims, eta, deta, strain):
+    d = len(dims)
+    N = sizes(dims)[0]
+    eta = np.ones(N) if eta is None else _c(eta).ravel()
+    deta = np.zeros(N) if deta is None else _c(deta).ravel()
+    strain = np.zeros(d * N * d) if strain is None else _c(strain).ravel()
+    assert eta.size == N and deta.size == N and strain.size == d * N * d
+    return eta, deta, strain
+
+
+def stokes_pressure_reduce(dims, pL):
+    pL = _c(pL).copy().ravel()
+    err = _bind_stokes().orc_stokes_pressure_reduce(len(dims), _ip(dims), _dp(pL))
+    if err:
+        raise ValueError("orc_stokes_pressure_reduce error %d" % err)
+    return pL
+
+
+def stokes_mult_vv(dims, vG, eta=None, deta=None, strain=None, mode=FAST, nthreads=1):
+    eta, deta, strain = _state(dims, eta, deta, strain)
+    vG = _c(vG)
+    out = np.empty_like(vG)
+    err = _bind_stokes().orc_stokes_mult_vv(len(dims), _ip(dims), _dp(eta), _dp(deta), _dp(strain), _dp(vG), _dp(out), mode, nthreads)
+    if err:
+        raise ValueError("orc_stokes_mult_vv error %d" % err)
+    return out
+
+
+def stokes_divergence(dims, vG, dirichlet=None, mode=FAST, nthreads=1):
+    vG = _c(vG)
+    out = np.empty(stokes_sizes(dims)[3])
+    err = _bind_stokes().orc_stokes_divergence(len(dims), _ip(dims), _dp(_c(dirichlet)), _dp(vG), _dp(out), mode, nthreads)
+    if err:
+        raise ValueError("orc_stokes_divergence error %d" % err)
+    return out
+
+
+def stokes_mult_vp(dims, pG, mode=FAST, nthreads=1):
+    pG = _c(pG)
+    out = np.empty(stokes_sizes(dims)[2])
+    err = _bind_stokes().orc_stokes_mult_vp(len(dims), _ip(dims), _dp(pG), _dp(out), mode, nthreads)
+    if err:
+        raise ValueError("orc_stokes_mult_vp error %d" % err)
+    return out
+
+
+def stokes_mult(dims, xG, eta=None, deta=None, strain=None, mode=FAST, nthreads=1):
+    eta, deta, strain = _state(dims, eta, deta, strain)
+    xG = _c(xG)
+    out = np.empty_like(xG)
+    err = _bind_stokes().orc_stokes_mult(len(dims), _ip(dims), _dp(eta), _dp(deta), _dp(strain), _dp(xG), _dp(out), mode, nthreads)
+    if err:
+        raise ValueError("orc_stokes_mult error %d" % err)
+    return out
+
+
+def stokes_function(dims, xG, dirichlet, force, rheology=(0, 1.0, 1.0, 1.0, 1.0), mode=FAST, nthreads=1):
+    """StokesFunction (stokes.C:680-758); returns y, eta, deta, strain[d][N*d]."""
+    d = len(dims)
+    N = sizes(dims)[0]
+    xG = _c(xG)
+    y = np.empty_like(xG)
+    eta, deta, strain = np.empty(N), np.empty(N), np.empty(d * N * d)
+    rh = Rheology(*rheology)
+    err = _bind_stokes().orc_stokes_function(d, _ip(dims), C.byref(rh), _dp(_c(dirichlet)), _dp(_c(force)), _dp(xG), _dp(y),
+                                             _dp(eta), _dp(deta), _dp(strain), mode, nthreads)
+    if err:
+        raise ValueError("orc_stokes_function error %d" % err)
+    return y, eta, deta, strain.reshape(d, N * d)
+
+
+def stokes_exact(dims, exact):
+    d = len(dims)
+    _, _, _, _, g, dv = stokes_sizes(dims)
+    U, U2, dvals = np.empty(g), np.empty(g), np.empty(dv)
+    err = _bind_stokes().orc_stokes_exact(d, _ip(dims), exact, _dp(U), _dp(U2), _dp(dvals))
+    if err:
+        raise ValueError("orc_stokes_exact error %d" % err)
+    return U, U2, dvals
