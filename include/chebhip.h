@@ -117,6 +117,45 @@ int ell_op_get_state(ell_op *op, int which, double *dst_host);
 int ell_op_set_state(ell_op *op, int which, const double *src_host);
 
 /* ------------------------------------------------------------------------- */
+/* Operator level: the Stokes MatShells (StokesCtx stokes.C:40-65,             */
+/* StokesCreate :257-344) with -boundary 0: every boundary node is a velocity  */
+/* Dirichlet node, numMixed == 0 (the StokesMixed* hooks are no-ops).          */
+/* Vector layouts (StokesSetupDomain, stokes.C:773-938), I = interior nodes:   */
+/*   full global  g  = (d+1)*I : [v_0 .. v_{d-1}, p] per interior node         */
+/*   velocity     gv = d*I     : node-major        pressure gp = I             */
+/*   dirichlet    dv = d*(N-I) : boundary nodes in BlockIt order, node-major   */
+/* d = 2 or 3 (StokesPressureReduceOrder, stokes.C:1036).                      */
+/* ------------------------------------------------------------------------- */
+typedef struct stokes_op stokes_op;
+
+int stokes_op_create(int d, const int *dims, stokes_op **out);      /* StokesCreate, stokes.C:257-344 */
+int stokes_op_destroy(stokes_op *op);                               /* StokesDestroy, stokes.C:348-388 */
+/* which: 0 local nodes N, 1 interior nodes I, 2 gv, 3 gp, 4 g, 5 dv */
+long stokes_op_size(const stokes_op *op, int which);
+
+/* options->rheology (stokes.C:1920-1944): kind 0 = StokesRheologyLinear, 1 = StokesRheologyPower
+ * with -hardness, -exponent, -eps, -gamma0 (stokes.C:412-415). */
+int stokes_op_set_rheology(stokes_op *op, int kind, double hardness, double exponent,
+                           double regularization, double gamma0);
+int stokes_op_set_dirichlet(stokes_op *op, const double *values_host);   /* c->dirichlet, dv doubles */
+int stokes_op_set_force(stokes_op *op, const double *force_host);        /* c->force, g doubles     */
+
+/* StokesMatMult (stokes.C:499-519) on full global vectors. */
+int stokes_op_mult(stokes_op *op, const double *xG_dev, double *yG_dev, void *stream);
+/* StokesMatMultVV (:623-676), StokesMatMultPV (:557-566), StokesMatMultVP (:599-619): the inner
+ * MatShells MatVV / MatPV / MatVP that the Schur complement (:523-535) and the block
+ * preconditioners (:1714-1817) call.  StokesMatMultSchur itself is VP -> KSPSolve -> PV -> scale(-1)
+ * and stays on the PETSc side. */
+int stokes_op_mult_vv(stokes_op *op, const double *vG_dev, double *vG_out_dev, void *stream);
+int stokes_op_mult_pv(stokes_op *op, const double *vG_dev, double *pG_out_dev, void *stream);
+int stokes_op_mult_vp(stokes_op *op, const double *pG_dev, double *vG_out_dev, void *stream);
+/* StokesFunction (:680-758): yG = F(xG) - force; refreshes eta, deta, strain. */
+int stokes_op_function(stokes_op *op, const double *xG_dev, double *yG_dev, void *stream);
+/* Operator state to/from the host: which = 0 eta (N), 1 deta (N), 2+j strain[j] (N*d). */
+int stokes_op_get_state(stokes_op *op, int which, double *dst_host);
+int stokes_op_set_state(stokes_op *op, int which, const double *src_host);
+
+/* ------------------------------------------------------------------------- */
 /* Instrumentation (the reference has none: SURVEY 5.1).                      */
 /* ------------------------------------------------------------------------- */
 /* Number of sweep-kernel launches issued by this process so far. */

@@ -33,6 +33,10 @@ ABI_SYMBOLS = [
     "ell_op_create", "ell_op_destroy", "ell_op_local_size", "ell_op_global_size",
     "ell_op_dirichlet_size", "ell_op_mult", "ell_op_mult_host", "ell_op_function",
     "ell_op_function_host", "ell_op_set_dirichlet", "ell_op_get_state", "ell_op_set_state",
+    "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
+    "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
+    "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
+    "stokes_op_set_state",
 ]
 
 
@@ -85,6 +89,17 @@ def lib():
         L.ell_op_set_dirichlet.argtypes = [vp, dp]
         L.ell_op_get_state.argtypes = [vp, C.c_int, dp]
         L.ell_op_set_state.argtypes = [vp, C.c_int, dp]
+        L.stokes_op_create.argtypes = [C.c_int, ip, C.POINTER(vp)]
+        L.stokes_op_destroy.argtypes = [vp]
+        L.stokes_op_size.argtypes = [vp, C.c_int]
+        L.stokes_op_size.restype = C.c_long
+        L.stokes_op_set_rheology.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.stokes_op_set_dirichlet.argtypes = [vp, dp]
+        L.stokes_op_set_force.argtypes = [vp, dp]
+        for f in (L.stokes_op_mult, L.stokes_op_mult_vv, L.stokes_op_mult_pv, L.stokes_op_mult_vp, L.stokes_op_function):
+            f.argtypes = [vp, vp, vp, vp]
+        L.stokes_op_get_state.argtypes = [vp, C.c_int, dp]
+        L.stokes_op_set_state.argtypes = [vp, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -245,6 +260,81 @@ class EllipticOp:
     def destroy(self):
         if self._h:
             lib().ell_op_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class StokesOp:
+    """The Stokes MatShells (StokesCreate, stokes.C:257-344) with -boundary 0.
+
+    mult <-> StokesMatMult (stokes.C:499-519); mult_vv / mult_pv / mult_vp <-> MatVV / MatPV / MatVP
+    (:623-676, :557-566, :599-619); function <-> StokesFunction (:680-758)."""
+
+    def __init__(self, dims):
+        self.dims = tuple(int(d) for d in dims)
+        self.d = len(self.dims)
+        h = C.c_void_p()
+        _chk(lib().stokes_op_create(self.d, _ints(self.dims), C.byref(h)))
+        self._h = h
+        sz = [lib().stokes_op_size(h, w) for w in range(6)]
+        self.local_nodes, self.interior_nodes, self.velocity_size, self.pressure_size, self.global_size, self.dirichlet_size = sz
+
+    def set_rheology(self, kind, hardness=1.0, exponent=1.0, regularization=1.0, gamma0=1.0):
+        _chk(lib().stokes_op_set_rheology(self._h, kind, hardness, exponent, regularization, gamma0))
+
+    def set_dirichlet(self, values):
+        import numpy as np
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        assert values.size == self.dirichlet_size
+        _chk(lib().stokes_op_set_dirichlet(self._h, _np_dp(values)))
+
+    def set_force(self, force):
+        import numpy as np
+        force = np.ascontiguousarray(force, dtype=np.float64)
+        assert force.size == self.global_size
+        _chk(lib().stokes_op_set_force(self._h, _np_dp(force)))
+
+    def _call(self, fn, x, nx, y, ny):
+        _chk(fn(self._h, _dev_ptr(x, nx), _dev_ptr(y, ny), _stream()))
+        return y
+
+    def mult(self, x, y):
+        return self._call(lib().stokes_op_mult, x, self.global_size, y, self.global_size)
+
+    def mult_vv(self, v, out):
+        return self._call(lib().stokes_op_mult_vv, v, self.velocity_size, out, self.velocity_size)
+
+    def mult_pv(self, v, pout):
+        return self._call(lib().stokes_op_mult_pv, v, self.velocity_size, pout, self.pressure_size)
+
+    def mult_vp(self, p, vout):
+        return self._call(lib().stokes_op_mult_vp, p, self.pressure_size, vout, self.velocity_size)
+
+    def function(self, x, y):
+        return self._call(lib().stokes_op_function, x, self.global_size, y, self.global_size)
+
+    def get_state(self, which):
+        import numpy as np
+        n = self.local_nodes if which < 2 else self.local_nodes * self.d
+        out = np.empty(n)
+        _chk(lib().stokes_op_get_state(self._h, which, _np_dp(out)))
+        return out
+
+    def set_state(self, which, values):
+        import numpy as np
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        n = self.local_nodes if which < 2 else self.local_nodes * self.d
+        assert values.size == n
+        _chk(lib().stokes_op_set_state(self._h, which, _np_dp(values)))
+
+    def destroy(self):
+        if self._h:
+            lib().stokes_op_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -24,6 +24,13 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
+// shared with stokes.hip
+int chebhip_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
 #define HIPCHK(expr)                                                                         \
   do {                                                                                       \
     hipError_t e_ = (expr);                                                                  \

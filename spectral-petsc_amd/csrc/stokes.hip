@@ -1,0 +1,448 @@
+// stokes.hip -- the Stokes operator callbacks (stokes.C:499-758) over the sweep kernel:
+// StokesMatMult / VV / PV / VP and StokesFunction with the linear and power-law rheologies,
+// -boundary 0 (all-Dirichlet velocity).  Every ChebMult of the reference is one
+// cheb_sweep_kernel launch (DV[i]: rank d+1 tensor with the d components innermost,
+// stokes.C:284-290; DP[i]: scalar rank d); the vector passes between them are the small
+// node-local kernels below.
+#include "../../include/chebhip.h"
+#include "sweep.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace chebhip;
+
+int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+#define SHIPCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline unsigned sgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+#define GS_LOOP(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// xL <- velocity part of a global vector (node stride `gs`: d for vG, d+1 for the full vector), zero or
+// Dirichlet values on the boundary: VecZeroEntries + scatterVL (+ scatterDL), stokes.C:575-582,634-637,695-699.
+__global__ void k_st_vlocal(long N, int d, int gs, const int *__restrict__ ixL, const double *__restrict__ src,
+                            const double *__restrict__ dirloc, double *__restrict__ xL) {
+  GS_LOOP(a, N * d) {
+    const long l = a / d; const int k = (int)(a - l * d);
+    const int n = ixL[l];
+    xL[a] = n >= 0 ? src[(long)n * gs + k] : (dirloc ? dirloc[a] : 0.0);
+  }
+}
+
+// pL <- pressure part of a global vector (stride gs, offset go), zero on the boundary: stokes.C:605-608.
+__global__ void k_st_plocal(long N, int gs, int go, const int *__restrict__ ixL, const double *__restrict__ src,
+                            double *__restrict__ pL) {
+  GS_LOOP(l, N) { const int n = ixL[l]; pL[l] = n >= 0 ? src[(long)n * gs + go] : 0.0; }
+}
+
+// VecStrideGather(workV[0], i, workP[0]) stokes.C:585
+__global__ void k_st_comp(long N, int d, int i, const double *__restrict__ xL, double *__restrict__ p0) {
+  GS_LOOP(l, N) p0[l] = xL[l * d + i];
+}
+
+// Boundary pressure of one family of grid lines (StokesPressureReduceOrder, stokes.C:1029-1080): the two
+// end values of a line become the degree-(len-3) polynomial through its interior values evaluated at the
+// ends.  The reference builds a Neville table per line (util.C:129-144, O(len^2)); the same linear
+// functional is applied here as two dot products with precomputed Lagrange weights.
+__global__ void k_st_preduce(double *__restrict__ pres, long na, long a0, long sa, long nb, long b0, long sb,
+                             long se, int len, const double *__restrict__ w0, const double *__restrict__ w1) {
+  GS_LOOP(t, na * nb) {
+    const long a = t / nb, b = t - a * nb;
+    double *line = pres + (a + a0) * sa + (b + b0) * sb;
+    double f0 = 0.0, f1 = 0.0;
+    for (int j = 1; j < len - 1; j++) { const double v = line[(long)j * se]; f0 += w0[j - 1] * v; f1 += w1[j - 1] * v; }
+    line[0] = f0; line[(long)(len - 1) * se] = f1;
+  }
+}
+
+// Node loop of StokesMatMultVV, stokes.C:647-662.  V[j], S[j]: N*d arrays (component k of direction j).
+template <int D>
+__global__ void k_st_node_vv(long N, double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
+                             const double *__restrict__ S0, const double *__restrict__ S1, const double *__restrict__ S2,
+                             const double *__restrict__ eta, const double *__restrict__ deta) {
+  double *V[3] = {V0, V1, V2};
+  const double *S[3] = {S0, S1, S2};
+  GS_LOOP(i, N) {
+    double g[D][D], strain[D][D], S0v[D][D], z = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = 0; k < D; k++) { g[j][k] = V[j][i * D + k]; S0v[j][k] = S[j][i * D + k]; }
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = 0; k < D; k++) { strain[j][k] = 0.5 * (g[j][k] + g[k][j]); z += strain[j][k] * S0v[j][k]; }
+    const double e = eta[i], de = deta[i];
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = 0; k < D; k++) V[j][i * D + k] = e * strain[j][k] + de * S0v[j][k] * z;
+  }
+}
+
+// Node loop of StokesFunction, stokes.C:710-725, with the rheology inlined (stokes.C:1920-1944).
+template <int D>
+__global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict__ S1, double *__restrict__ S2,
+                             double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
+                             double *__restrict__ eta, double *__restrict__ deta,
+                             int kind, double hardness, double expo, double eps, double gamma0) {
+  double *V[3] = {V0, V1, V2};
+  double *S[3] = {S0, S1, S2};
+  GS_LOOP(i, N) {
+    double g[D][D], s[D][D], gamma = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = 0; k < D; k++) g[j][k] = S[j][i * D + k];
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = 0; k < D; k++) { s[j][k] = 0.5 * (g[j][k] + g[k][j]); gamma += 0.5 * (s[j][k] * s[j][k]); }
+    double e = 1.0, de = 0.0;
+    if (kind == 1) {
+      const double p = (1.0 - expo) / (2.0 * expo);
+      e = hardness * pow(eps + gamma / gamma0, p);
+      de = (fabs(expo) > 1.0e-5) ? hardness * p / gamma0 * pow(eps + gamma / gamma0, p - 1.0) : 0.0;
+    }
+    eta[i] = e; deta[i] = de;
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = 0; k < D; k++) { V[j][i * D + k] = e * s[j][k]; S[j][i * D + k] = s[j][k]; }
+  }
+}
+
+// Final scatter: velocity rows = yL (+ grad p), pressure rows = div v, minus force
+// (scatterLV/VG, VecAXPY stokes.C:513-517,750-756).  Any of yL / gp0 / p2 may be null.
+__global__ void k_st_out(long N, int d, int gs, const int *__restrict__ ixL, const double *__restrict__ yL,
+                         const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
+                         const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out) {
+  const double *gp[3] = {gp0, gp1, gp2};
+  GS_LOOP(l, N) {
+    const int n = ixL[l];
+    if (n < 0) continue;
+    const long o = (long)n * gs;
+    if (yL || gp0)
+      for (int k = 0; k < d; k++) {
+        double v = yL ? yL[l * d + k] : 0.0;
+        if (gp0) v = yL ? v + 1.0 * gp[k][l] : gp[k][l];
+        if (force) v += -1.0 * force[o + k];
+        out[o + k] = v;
+      }
+    if (p2) { double v = p2[l]; if (force) v += -1.0 * force[o + po]; out[o + po] = v; }
+  }
+}
+
+__global__ void k_st_fill(long n, double v, double *__restrict__ a) { GS_LOOP(i, n) a[i] = v; }
+
+// ---------------------------------------------------------------------------------------------
+struct stokes_op {
+  int d = 0;
+  std::vector<int> dims;
+  long N = 0, I = 0;
+  std::map<int, DiffMat> mats;
+  std::vector<unsigned> innerP, ncolsP, innerV, ncolsV;      // DP[i] / DV[i] geometry
+  int *ixL = nullptr;
+  double *xL = nullptr, *yL = nullptr;                       // workV[0], workV[1]
+  double *V[3] = {nullptr, nullptr, nullptr};                // workV[2..]
+  double *strain[3] = {nullptr, nullptr, nullptr};           // c->strain[]
+  double *eta = nullptr, *deta = nullptr;
+  double *pL = nullptr, *p0 = nullptr, *p2 = nullptr, *gp[3] = {nullptr, nullptr, nullptr};   // workP[]
+  double *dirloc = nullptr, *force = nullptr;
+  std::vector<double *> w0, w1;                              // pressure extrapolation weights per dim
+  int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
+};
+
+static int st_alloc(double **p, size_t n) { SHIPCHK(hipMalloc((void **)p, n * sizeof(double))); SHIPCHK(hipMemset(*p, 0, n * sizeof(double))); return 0; }
+
+extern "C" int stokes_op_destroy(stokes_op *op) {
+  if (!op) return 0;
+  for (auto &kv : op->mats) diffmat_destroy(&kv.second);
+  double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
+                   op->pL, op->p0, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force};
+  for (double *p : all) if (p) (void)hipFree(p);
+  for (double *p : op->w0) if (p) (void)hipFree(p);
+  for (double *p : op->w1) if (p) (void)hipFree(p);
+  if (op->ixL) (void)hipFree(op->ixL);
+  delete op;
+  return 0;
+}
+
+extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!dims || d < 2 || d > 3) return chebhip_fail(CHEBHIP_ERR_DIMS, "d = %d: Stokes needs d = 2 or 3 (stokes.C:1036)", d);
+  long N = 1, I = 1;
+  for (int k = 0; k < d; k++) {
+    if (dims[k] < 3) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d but must be >= 3", k, dims[k]);
+    if (dims[k] > 256) return chebhip_fail(CHEBHIP_ERR_ARG, "dims[%d] = %d: at most 256 points per line in this build", k, dims[k]);
+    N *= dims[k]; I *= dims[k] - 2;
+    if (N * d > 0x7fffffffL) return chebhip_fail(CHEBHIP_ERR_DIMS, "tensor of more than 2^31-1 values");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return chebhip_fail(CHEBHIP_ERR_DEVICE, "no usable HIP device; libchebhip has no CPU fallback");
+  stokes_op *op = new (std::nothrow) stokes_op;
+  if (!op) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  op->d = d; op->dims.assign(dims, dims + d); op->N = N; op->I = I;
+#define OPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { stokes_op_destroy(op); \
+    return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+#define OPRC(expr) do { int rc_ = (expr); if (rc_) { stokes_op_destroy(op); return rc_; } } while (0)
+  for (int k = 0; k < d; k++)
+    if (!op->mats.count(dims[k])) { DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m; }
+  {  // ixLP of StokesSetupDomain (stokes.C:791-879): interior index or -1, BlockIt order
+    std::vector<int> ixL((size_t)N), ind(d, 0);
+    long g = 0;
+    for (long l = 0; l < N; l++) {
+      bool bdy = false;
+      for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == dims[j] - 1) bdy = true;
+      ixL[l] = bdy ? -1 : (int)g++;
+      for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
+    }
+    OPCHK(hipMalloc((void **)&op->ixL, (size_t)N * sizeof(int)));
+    OPCHK(hipMemcpy(op->ixL, ixL.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
+  }
+  op->innerP.resize(d); op->ncolsP.resize(d); op->innerV.resize(d); op->ncolsV.resize(d);
+  for (int k = 0; k < d; k++) {
+    unsigned in = 1; for (int r = k + 1; r < d; r++) in *= dims[r];
+    op->innerP[k] = in; op->ncolsP[k] = (unsigned)(N / dims[k]);
+    op->innerV[k] = in * d; op->ncolsV[k] = (unsigned)(N * d / dims[k]);      // cheb_dim = {dim..., d}, stokes.C:284-290
+  }
+  const size_t nd = (size_t)N * d;
+  OPRC(st_alloc(&op->xL, nd)); OPRC(st_alloc(&op->yL, nd));
+  for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
+  OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
+  OPRC(st_alloc(&op->pL, (size_t)N)); OPRC(st_alloc(&op->p0, (size_t)N)); OPRC(st_alloc(&op->p2, (size_t)N));
+  hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
+  // Lagrange weights of the interior nodes x_1..x_{P-2} at x_0 and x_{P-1} (the polyInterp functional)
+  op->w0.assign(d, nullptr); op->w1.assign(d, nullptr);
+  for (int k = 0; k < d; k++) {
+    const int P = dims[k], m = P - 2;
+    std::vector<long double> x(P);
+    for (int i = 0; i < P; i++) x[i] = cosl(3.14159265358979323846264338327950288L * i / (P - 1));
+    std::vector<double> a(m), b(m);
+    for (int j = 1; j <= m; j++) {
+      long double l0 = 1.0L, l1 = 1.0L;
+      for (int q = 1; q <= m; q++) if (q != j) { l0 *= (x[0] - x[q]) / (x[j] - x[q]); l1 *= (x[P - 1] - x[q]) / (x[j] - x[q]); }
+      a[j - 1] = (double)l0; b[j - 1] = (double)l1;
+    }
+    OPCHK(hipMalloc((void **)&op->w0[k], (size_t)m * sizeof(double)));
+    OPCHK(hipMalloc((void **)&op->w1[k], (size_t)m * sizeof(double)));
+    OPCHK(hipMemcpy(op->w0[k], a.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+    OPCHK(hipMemcpy(op->w1[k], b.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+  }
+  OPCHK(hipDeviceSynchronize());
+#undef OPCHK
+#undef OPRC
+  *out = op;
+  return 0;
+}
+
+extern "C" long stokes_op_size(const stokes_op *op, int which) {
+  if (!op) return -1;
+  switch (which) {
+    case 0: return op->N;
+    case 1: return op->I;
+    case 2: return op->I * op->d;
+    case 3: return op->I;
+    case 4: return op->I * (op->d + 1);
+    case 5: return (op->N - op->I) * op->d;
+    default: return -1;
+  }
+}
+
+extern "C" int stokes_op_set_rheology(stokes_op *op, int kind, double hardness, double exponent, double eps, double gamma0) {
+  if (!op) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  if (kind != 0 && kind != 1) return chebhip_fail(CHEBHIP_ERR_ARG, "rheology %d not implemented (stokes.C:470-480)", kind);
+  op->rh_kind = kind; op->rh_hard = hardness; op->rh_expo = exponent; op->rh_eps = eps; op->rh_g0 = gamma0;
+  return 0;
+}
+
+extern "C" int stokes_op_set_dirichlet(stokes_op *op, const double *values) {
+  if (!op || !values) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  const int d = op->d;
+  std::vector<double> loc((size_t)op->N * d, 0.0);
+  std::vector<int> ind(d, 0);
+  long dd = 0;
+  for (long l = 0; l < op->N; l++) {                      // ixDL order: boundary nodes in BlockIt order, d values each
+    bool bdy = false;
+    for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) bdy = true;
+    if (bdy) for (int k = 0; k < d; k++) loc[l * d + k] = values[dd++];
+    for (int j = d - 1; j >= 0; j--) { if (++ind[j] < op->dims[j]) break; ind[j] = 0; }
+  }
+  if (!op->dirloc) SHIPCHK(hipMalloc((void **)&op->dirloc, loc.size() * sizeof(double)));
+  SHIPCHK(hipMemcpy(op->dirloc, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int stokes_op_set_force(stokes_op *op, const double *force) {
+  if (!op || !force) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  const size_t g = (size_t)op->I * (op->d + 1);
+  if (!op->force) SHIPCHK(hipMalloc((void **)&op->force, (g ? g : 1) * sizeof(double)));
+  SHIPCHK(hipMemcpy(op->force, force, g * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ---- building blocks ------------------------------------------------------------------------
+static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *y, int out_mode, const double *acc,
+                       double alpha, hipStream_t st) {
+  SweepParams sp = {};
+  sp.ncols = vec ? op->ncolsV[k] : op->ncolsP[k];
+  sp.inner = vec ? op->innerV[k] : op->innerP[k];
+  sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.out_mode = out_mode; sp.acc = acc; sp.alpha = alpha;
+  SHIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  return 0;
+}
+
+// yL = -sum_j DV[j] V[j]   (stokes.C:668-671, 737-740)
+static int st_div_stress(stokes_op *op, hipStream_t st) {
+  for (int j = 0; j < op->d; j++) {
+    int rc = sweep_plain(op, true, j, op->V[j], op->yL, j == 0 ? OUT_STORE : OUT_ACC, op->yL, -1.0, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]
+static int st_viscous_jacobian(stokes_op *op, hipStream_t st) {
+  const int d = op->d;
+  for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->V[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :639
+  if (d == 2) hipLaunchKernelGGL((k_st_node_vv<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2],
+                                 (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta);
+  else hipLaunchKernelGGL((k_st_node_vv<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2],
+                          (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta);
+  return st_div_stress(op, st);
+}
+
+// p2 = sum_i DP[i] (component i of xL)   (StokesDivergence, stokes.C:583-591)
+static int st_divergence(stokes_op *op, hipStream_t st) {
+  for (int i = 0; i < op->d; i++) {
+    hipLaunchKernelGGL(k_st_comp, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->d, i, (const double *)op->xL, op->p0);
+    int rc = sweep_plain(op, false, i, op->p0, op->p2, i == 0 ? OUT_STORE : OUT_ACC, op->p2, 1.0, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// pL (interior filled, boundary zero) -> boundary extrapolation -> gp[i] = DP[i] pL   (stokes.C:609-614)
+static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
+  const int d = op->d;
+  const long m = op->dims[0], n = op->dims[1], p = (d == 2) ? 1 : op->dims[2];
+  if (p > 1)    // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052)
+    hipLaunchKernelGGL(k_st_preduce, dim3(sgrid((m - 1) * (n - 1))), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, n - 1, 1L, p, 1L,
+                       (int)p, (const double *)op->w0[2], (const double *)op->w1[2]);
+  // y lines of planes i = 1..m-1, every k (stokes.C:1054-1062)
+  hipLaunchKernelGGL(k_st_preduce, dim3(sgrid((m - 1) * p)), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, p, 0L, 1L, p,
+                     (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
+  // x lines, every (j, k) (stokes.C:1064-1074)
+  hipLaunchKernelGGL(k_st_preduce, dim3(sgrid(n * p)), dim3(256), 0, st, op->pL, n, 0L, p, p, 0L, 1L, n * p,
+                     (int)m, (const double *)op->w0[0], (const double *)op->w1[0]);
+  for (int i = 0; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
+  return 0;
+}
+
+#define ARGCHK(c) do { if (!(c)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument"); } while (0)
+
+extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
+  ARGCHK(op && vG && out);
+  hipStream_t st = (hipStream_t)stream;
+  const int d = op->d;
+  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, vG, (const double *)nullptr, op->xL);
+  int rc = st_viscous_jacobian(op, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, (const double *)op->yL,
+                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0, (const double *)nullptr, out);
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, void *stream) {
+  ARGCHK(op && vG && pout);
+  hipStream_t st = (hipStream_t)stream;
+  const int d = op->d;
+  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, vG, (const double *)nullptr, op->xL);
+  int rc = st_divergence(op, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, 1, (const int *)op->ixL, (const double *)nullptr,
+                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)op->p2, 0, (const double *)nullptr, pout);
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, void *stream) {
+  ARGCHK(op && pG && vout);
+  hipStream_t st = (hipStream_t)stream;
+  const int d = op->d;
+  hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 1, 0, (const int *)op->ixL, pG, op->pL);
+  int rc = st_pressure_gradient(op, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, (const double *)nullptr,
+                     (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)nullptr, 0, (const double *)nullptr, vout);
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void *stream) {
+  ARGCHK(op && xG && yG);
+  hipStream_t st = (hipStream_t)stream;
+  const int d = op->d;
+  // scatterGV + scatterVL, zero boundary: the same xL serves MatVV (:508) and MatPV (:509)
+  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, xG, (const double *)nullptr, op->xL);
+  int rc = st_viscous_jacobian(op, st); if (rc) return rc;
+  if ((rc = st_divergence(op, st))) return rc;
+  hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d + 1, d, (const int *)op->ixL, xG, op->pL);   // scatterGP (:510)
+  if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // MatVP (:512)
+  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, (const double *)op->yL,
+                     (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, (const double *)nullptr, yG);
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, void *stream) {
+  ARGCHK(op && xG && yG);
+  hipStream_t st = (hipStream_t)stream;
+  const int d = op->d;
+  // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
+  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, xG, (const double *)op->dirloc, op->xL);
+  for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->strain[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :701
+  if (d == 2) hipLaunchKernelGGL((k_st_node_fn<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
+                                 op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  else hipLaunchKernelGGL((k_st_node_fn<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
+                          op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
+  if ((rc = st_divergence(op, st))) return rc;                                                                                   // :746
+  hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d + 1, d, (const int *)op->ixL, xG, op->pL);
+  if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // :747
+  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, (const double *)op->yL,
+                     (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, (const double *)op->force, yG);   // :750-756
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int st_state_ptr(stokes_op *op, int which, double **p, size_t *n) {
+  if (which == 0) { *p = op->eta; *n = (size_t)op->N; }
+  else if (which == 1) { *p = op->deta; *n = (size_t)op->N; }
+  else if (which >= 2 && which < 2 + op->d) { *p = op->strain[which - 2]; *n = (size_t)op->N * op->d; }
+  else return chebhip_fail(CHEBHIP_ERR_ARG, "which = %d out of range", which);
+  return 0;
+}
+
+extern "C" int stokes_op_get_state(stokes_op *op, int which, double *dst) {
+  ARGCHK(op && dst);
+  double *p; size_t n; int rc = st_state_ptr(op, which, &p, &n); if (rc) return rc;
+  SHIPCHK(hipDeviceSynchronize());
+  SHIPCHK(hipMemcpy(dst, p, n * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int stokes_op_set_state(stokes_op *op, int which, const double *src) {
+  ARGCHK(op && src);
+  double *p; size_t n; int rc = st_state_ptr(op, which, &p, &n); if (rc) return rc;
+  SHIPCHK(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}

@@ -1,0 +1,143 @@
+"""GPU parity tests of the Stokes callbacks (stokes.C:499-758) through the C ABI, against the golden
+vectors and the CPU oracle.  Tolerance: 1e-10 normwise on N(0,1) inputs (float64); the pressure
+gradient goes through the boundary extrapolation (a dot product here, a Neville table in the
+reference: equal to rounding, amplified by the extrapolation weights) and gets 1e-9."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+import oracle_lib as orc
+from conftest import relerr, HERE
+
+pytestmark = pytest.mark.gpu
+sp = ge.load()
+SEED = 20240229
+POWER = (1, 1.0, 3.0, 1e-4, 1.0)   # README:52
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def run(fn, x, nout):
+    y = torch.full((nout,), float("nan"), dtype=torch.float64, device="cuda")
+    fn(dev(x), y)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def g():
+    return dict(np.load(os.path.join(HERE, "golden", "stokes_golden.npz")))
+
+
+@pytest.mark.parametrize("dims", [(8, 7), (7, 6, 5)])
+def test_stokes_golden(g, dims):
+    tag = "x".join(str(v) for v in dims)
+    d = len(dims)
+    op = sp.StokesOp(dims)
+    x = g["st_%s_x" % tag]
+    X = x.reshape(-1, d + 1)
+    vG, pG = np.ascontiguousarray(X[:, :d]).ravel(), np.ascontiguousarray(X[:, d])
+    assert relerr(run(op.mult_vv, vG, op.velocity_size), g["st_%s_vv_lin" % tag]) < 1e-10
+    assert relerr(run(op.mult_pv, vG, op.pressure_size), g["st_%s_pv" % tag]) < 1e-10
+    assert relerr(run(op.mult_vp, pG, op.velocity_size), g["st_%s_vp" % tag]) < 1e-9
+    assert relerr(run(op.mult, x, op.global_size), g["st_%s_mult_lin" % tag]) < 1e-9
+    # StokesFunction with the power-law rheology, then the Jacobian apply with the state it leaves
+    op.set_rheology(*POWER)
+    op.set_dirichlet(g["st_%s_fn_dirichlet" % tag])
+    op.set_force(g["st_%s_fn_force" % tag])
+    y = run(op.function, g["st_%s_fn_x" % tag], op.global_size)
+    assert relerr(op.get_state(0), g["st_%s_fn_eta" % tag]) < 1e-10
+    assert relerr(op.get_state(1), g["st_%s_fn_deta" % tag]) < 1e-10
+    for j in range(d):
+        assert relerr(op.get_state(2 + j), g["st_%s_fn_strain" % tag][j]) < 1e-10
+    assert relerr(y, g["st_%s_fn_y" % tag]) < 1e-9
+    assert relerr(run(op.mult, x, op.global_size), g["st_%s_mult_nl" % tag]) < 1e-9
+    op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(20, 17), (33, 18), (12, 11, 10), (24, 20, 18), (64, 64, 64)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_stokes_mult_vs_oracle(dims):
+    """StokesMatMult and its three blocks, linear state (BASELINE config 4 is -dim 64,64,64)."""
+    d = len(dims)
+    op = sp.StokesOp(dims)
+    rng = np.random.default_rng(SEED)
+    x = rng.standard_normal(op.global_size)
+    X = x.reshape(-1, d + 1)
+    vG, pG = np.ascontiguousarray(X[:, :d]).ravel(), np.ascontiguousarray(X[:, d])
+    nt = 16
+    assert relerr(run(op.mult_vv, vG, op.velocity_size), orc.stokes_mult_vv(dims, vG, nthreads=nt)) < 1e-10
+    assert relerr(run(op.mult_pv, vG, op.pressure_size), orc.stokes_divergence(dims, vG, nthreads=nt)) < 1e-10
+    assert relerr(run(op.mult_vp, pG, op.velocity_size), orc.stokes_mult_vp(dims, pG, nthreads=nt)) < 1e-9
+    assert relerr(run(op.mult, x, op.global_size), orc.stokes_mult(dims, x, nthreads=nt)) < 1e-9
+    op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(18, 16), (14, 12, 10), (32, 32, 32)], ids=lambda s: "x".join(map(str, s)))
+def test_stokes_function_power_law_vs_oracle(dims):
+    """StokesFunction with -rheology 1 -exponent 3 -eps 1e-4 (config 5 parameters) and the Newton-linearised
+    StokesMatMult that follows it."""
+    d = len(dims)
+    op = sp.StokesOp(dims)
+    U, U2, dv = orc.stokes_exact(dims, 1)
+    rng = np.random.default_rng(SEED)
+    xs = U + 0.05 * rng.standard_normal(U.shape)
+    op.set_rheology(*POWER)
+    op.set_dirichlet(dv)
+    op.set_force(U2)
+    y = run(op.function, xs, op.global_size)
+    yo, eta, deta, strain = orc.stokes_function(dims, xs, dv, U2, POWER, nthreads=16)
+    assert relerr(op.get_state(0), eta) < 1e-10
+    assert relerr(op.get_state(1), deta) < 1e-10
+    assert relerr(y, yo) < 1e-9
+    x = rng.standard_normal(op.global_size)
+    assert relerr(run(op.mult, x, op.global_size), orc.stokes_mult(dims, x, eta, deta, strain, nthreads=16)) < 1e-9
+    op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(16, 14), (12, 10, 9)])
+def test_constant_pressure_null_space(dims):
+    """stokes.C:190-212 MatNullSpaceTest on the GPU path: A [0; const] = 0."""
+    d = len(dims)
+    op = sp.StokesOp(dims)
+    x = np.zeros((op.interior_nodes, d + 1))
+    x[:, d] = 1.0
+    y = run(op.mult, x.ravel(), op.global_size)
+    assert np.abs(y).max() < 1e-9
+    op.destroy()
+
+
+def test_exact2_residual():
+    """stokes.C:190-212 with Exact2 (README:43): residual of the exact solution at 20^2 is ~1e-10."""
+    dims = (20, 20)
+    op = sp.StokesOp(dims)
+    U, U2, dv = orc.stokes_exact(dims, 2)
+    op.set_dirichlet(dv)
+    op.set_force(U2)
+    r = run(op.function, U, op.global_size)
+    ro, *_ = orc.stokes_function(dims, U, dv, U2, nthreads=4)
+    assert np.abs(r - ro).max() < 1e-9
+    assert np.abs(r).max() < 1e-6
+    op.destroy()
+
+
+def test_stokes_linearity_config5_size():
+    """Size-independent property at BASELINE config 5 size (128^3): StokesMatMult is linear."""
+    dims = (128, 128, 128)
+    op = sp.StokesOp(dims)
+    torch.manual_seed(SEED)
+    x = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+    z = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+    y1, y2, y3 = (torch.empty_like(x) for _ in range(3))
+    op.mult(x, y1)
+    op.mult(z, y2)
+    op.mult(1.5 * x - 0.5 * z, y3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y3).all()
+    assert (torch.linalg.norm(1.5 * y1 - 0.5 * y2 - y3) / torch.linalg.norm(y3)).item() < 1e-11
+    op.destroy()
