@@ -44,6 +44,8 @@ extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 // Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
 extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
 
+static bool use_two_stage();
+
 static int require_device() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -62,6 +64,7 @@ struct cheb_plan {
   long N = 0;
   unsigned inner = 1, ncols = 0;
   DiffMat mat;
+  DiffMat lap;                          // trimmed plans: interior D D
   bool trimmed = false;                 // created by cheb_plan_create_trimmed
   double *hx = nullptr, *hy = nullptr;  // staging for the host-pointer path
 };
@@ -122,7 +125,8 @@ extern "C" int cheb_plan_create_trimmed(int rank, int tr, const int *dims, cheb_
   p->rank = rank; p->tr = tr; p->dims.assign(dims, dims + rank); p->trimmed = true;
   p->N = N / full[tr] * dims[tr]; p->inner = inner; p->ncols = (unsigned)(N / full[tr]);
   hipError_t e = diffmat_create(full[tr], &p->mat);
-  if (e != hipSuccess) { delete p; return fail(CHEBHIP_ERR_DEVICE, "diffmat_create: %s", hipGetErrorString(e)); }
+  if (e == hipSuccess) e = diffmat_create_lap(full[tr], &p->lap);
+  if (e != hipSuccess) { diffmat_destroy(&p->mat); delete p; return fail(CHEBHIP_ERR_DEVICE, "diffmat_create: %s", hipGetErrorString(e)); }
   *out = p;
   return 0;
 }
@@ -137,10 +141,11 @@ extern "C" int cheb_apply_lap1d(cheb_plan *p, const double *x, const double *acc
   if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct");
   SweepParams sp = {};
   sp.ncols = p->ncols; sp.inner = p->inner;
-  sp.in0 = x; sp.in_mode = IN_PLAIN; sp.trim = 1; sp.coef_mode = COEF_UNIT;
+  sp.in0 = x; sp.in_mode = IN_PLAIN;
   sp.alpha = alpha; sp.out = y;
   if (acc) { sp.out_mode = OUT_ACC; sp.acc = acc; } else sp.out_mode = OUT_STORE;
-  HIPCHK(fused_launch(p->mat, sp, (hipStream_t)stream));
+  if (use_two_stage()) { sp.trim = 1; sp.coef_mode = COEF_UNIT; HIPCHK(fused_launch(p->mat, sp, (hipStream_t)stream)); }
+  else HIPCHK(sweep_launch(p->lap, sp, (hipStream_t)stream));
   return 0;
 }
 
@@ -170,6 +175,7 @@ extern "C" int cheb_apply_host(cheb_plan *p, const double *x, double *y) {
 extern "C" int cheb_plan_destroy(cheb_plan *p) {
   if (!p) return 0;
   diffmat_destroy(&p->mat);
+  diffmat_destroy(&p->lap);
   if (p->hx) (void)hipFree(p->hx);
   if (p->hy) (void)hipFree(p->hy);
   delete p;
@@ -219,6 +225,7 @@ struct ell_op {
   std::vector<int> dims;
   long N = 0, G = 0;
   std::map<int, DiffMat> mats;          // one matrix per distinct extent
+  std::map<int, DiffMat> laps;          // interior (D D) per distinct extent: the constant-coefficient path
   std::vector<unsigned> inner, ncols;   // per direction
   std::vector<unsigned> inner_g, ncols_g; // per direction, in the interior (global-vector) layout
   std::vector<int *> gcol;              // per direction: device [ncols_k]
@@ -272,7 +279,10 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
 #define OPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ell_op_destroy(op); \
     return fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
   for (int k = 0; k < d; k++)
-    if (!op->mats.count(dims[k])) { DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m; }
+    if (!op->mats.count(dims[k])) {
+      DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m;
+      if (dims[k] > 2) { DiffMat l; OPCHK(diffmat_create_lap(dims[k], &l)); op->laps[dims[k]] = l; }
+    }
   // SetupBC (elliptic.C:372-434): ixL in BlockIt order; interior strides of the global vector
   std::vector<long> gs(d, 1);
   for (int k = d - 2; k >= 0; k--) gs[k] = gs[k + 1] * (dims[k + 1] - 2);
@@ -325,6 +335,7 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
 extern "C" int ell_op_destroy(ell_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
+  for (auto &kv : op->laps) diffmat_destroy(&kv.second);
   for (auto p : op->gcol) if (p) (void)hipFree(p);
   for (auto p : op->g) if (p) (void)hipFree(p);
   for (auto p : op->gradu) if (p) (void)hipFree(p);
@@ -361,6 +372,14 @@ static int ell_divergence(ell_op *op, int in_mode, double *const *src, double *o
   }
   return 0;
 }
+
+static int g_two_stage = -1;
+static bool use_two_stage() {
+  if (g_two_stage < 0) { const char *e = getenv("CHEBHIP_TWO_STAGE"); g_two_stage = (e && e[0] == '1') ? 1 : 0; }
+  return g_two_stage == 1;
+}
+// Undocumented profiling hook (not in chebhip.h): select the two-stage kernel for the linear state.
+extern "C" void chebhip_debug_two_stage(int on) { g_two_stage = on ? 1 : 0; }
 
 static bool use_unfused() {
   static int v = -1;
@@ -410,17 +429,22 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
     // Linear state (eta == 1, deta == 0; homogeneous Dirichlet rows, elliptic.C:305-308): every
     // array of the apply lives in the interior layout of the global vectors, so there is no
     // gather/scatter at all -- lines through boundary nodes carry zeros in and are not read out.
-    // V = -sum_k D_k D_k w0 restricted to the interior, one fused launch per direction.
+    // V = -sum_k D_k D_k w0 restricted to the interior, one launch per direction.
+    //  default : the two sweeps of a direction collapse into one product with the interior block
+    //            of D D (constant coefficient), cheb_sweep_kernel, half the MFMA work;
+    //  two-stage (CHEBHIP_TWO_STAGE=1 / chebhip_debug_two_stage): the same fused gradient ->
+    //            flux -> divergence kernel the variable-coefficient path uses.
     for (int k = 0; k < op->d; k++) {
       SweepParams sp = {};
       sp.ncols = op->ncols_g[k]; sp.inner = op->inner_g[k];
-      sp.in0 = U; sp.in_mode = IN_PLAIN; sp.trim = 1; sp.coef_mode = COEF_UNIT;
+      sp.in0 = U; sp.in_mode = IN_PLAIN;
       sp.alpha = -1.0;                                             // VecAXPY(w0,-1,.) elliptic.C:333
       if (k == 0 && op->d > 1) { sp.out_mode = OUT_STORE; sp.out = op->W; }
       else if (k == 0) { sp.out_mode = OUT_STORE; sp.out = V; }
       else if (k == op->d - 1) { sp.out_mode = OUT_ACC; sp.out = V; sp.acc = op->W; }
       else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
-      HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st));
+      if (use_two_stage()) { sp.trim = 1; sp.coef_mode = COEF_UNIT; HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st)); }
+      else HIPCHK(sweep_launch(op->laps[op->dims[k]], sp, st));
     }
     return 0;
   }

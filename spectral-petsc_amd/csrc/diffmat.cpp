@@ -84,6 +84,58 @@ hipError_t diffmat_create(int P, DiffMat *out) {
   return hipSuccess;
 }
 
+// Second-derivative operator of a zero-Dirichlet line, restricted to its interior:
+//   L = (D D)[1..n-1, 1..n-1],  M = P-2 points.
+// For constant coefficients the two sweeps of a direction, D_k (1 * D_k w0) with w0 = 0 at both ends
+// (elliptic.C:305-334 with eta = 1, deta = 0), collapse into y = L x on the interior values.  L is
+// centro-SYMMETRIC (L[m-i][m-j] = L[i][j], m = M-1), so with e, o as above
+//     y_i = (ME e)_i + (MO o)_i,   y_{m-i} = (ME e)_i - (MO o)_i      (note the sign vs. D).
+// The product is formed in long double and rounded once.
+hipError_t diffmat_create_lap(int P, DiffMat *out) {
+  const int n = P - 1, M = P - 2, m = M - 1;
+  const int H = (M + 1) / 2;
+  int KS = 4;
+  while (4 * KS < H) KS *= 2;
+  const int MTP = KS / 4;
+  std::vector<long double> D((size_t)P * P), L((size_t)M * M);
+  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) D[(size_t)i * P + j] = dentry(i, j, n);
+  for (int i = 0; i < M; i++)
+    for (int j = 0; j < M; j++) {
+      long double s = 0.0L;
+      for (int q = 0; q < P; q++) s += D[(size_t)(i + 1) * P + q] * D[(size_t)q * P + (j + 1)];
+      L[(size_t)i * M + j] = s;
+    }
+  const size_t cnt = (size_t)MTP * KS * 64;
+  std::vector<double> fe(cnt, 0.0), fo(cnt, 0.0);
+  for (int mt = 0; mt < MTP; mt++)
+    for (int s = 0; s < KS; s++)
+      for (int l = 0; l < 64; l++) {
+        const int i = mt * 16 + (l & 15), j = 4 * s + (l >> 4);
+        if (i >= H || j >= H) continue;
+        long double me, mo;
+        if (2 * j == m) { me = L[(size_t)i * M + j]; mo = 0.0L; }
+        else {
+          const long double a = L[(size_t)i * M + j], b = L[(size_t)i * M + (m - j)];
+          me = 0.5L * (a + b); mo = 0.5L * (a - b);
+        }
+        fe[((size_t)mt * KS + s) * 64 + l] = (double)me;
+        fo[((size_t)mt * KS + s) * 64 + l] = (double)mo;
+      }
+  DiffMat r;
+  r.P = M; r.H = H; r.KS = KS; r.MTP = MTP; r.sym = 1;
+  hipError_t e = hipMalloc((void **)&r.fragE, (cnt + 8) * sizeof(double));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void **)&r.fragO, cnt * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(r.fragE); return e; }
+  r.zero = r.fragE + cnt;
+  e = hipMemset(r.zero, 0, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(r.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(r.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(r.fragE); (void)hipFree(r.fragO); return e; }
+  *out = r;
+  return hipSuccess;
+}
+
 void diffmat_destroy(DiffMat *m) {
   if (m->fragE) (void)hipFree(m->fragE);
   if (m->fragO) (void)hipFree(m->fragO);

@@ -41,6 +41,7 @@ struct SweepParams {
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
   const double *zero;           // a few zero doubles in HBM: the source of every masked-off load
   unsigned ntiles;
+  int sym;            // mirror rows are a - b (centro-symmetric matrix) instead of b - a
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
   int coef_mode;      // fused launches only: CoefMode; eta = in1, deta = in2, du0 = in4 (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
@@ -55,10 +56,14 @@ struct DiffMat {
   int MTP = 0;         // padded m-tiles of 16 rows = KS/4
   double *fragE = nullptr, *fragO = nullptr;  // device, [MTP][KS][64]
   double *zero = nullptr;                     // device, 8 zero doubles (tail of the fragE allocation)
+  int sym = 0;                                // 0: centro-antisymmetric (D), 1: centro-symmetric (interior D D)
 };
 
 // Builds (in long double) and uploads the fragment-ordered matrices.  Returns hipSuccess or error.
 hipError_t diffmat_create(int P, DiffMat *out);
+// Interior second-derivative operator (D D)[1..n-1,1..n-1] of a zero-Dirichlet line of P points; the
+// returned DiffMat describes lines of P-2 stored points.
+hipError_t diffmat_create_lap(int P, DiffMat *out);
 void diffmat_destroy(DiffMat *m);
 // Host-side dense differentiation matrix (row-major P x P), for tests and the adapter.
 void diffmat_dense_host(int P, double *D);

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
         else { double t = 0; for (int s = 0; s < CH; s++) t += rj[s] + rm[s]; if (t == 12345.678) park_chunk(cur ^ 1, sub); }
       }
       // ---- stores: accumulator element r of a lane is row 4r + (lane >> 4), col lane & 15 ----
+      if (p.sym) { const v4d t = ce; ce = co; co = t; }   // centro-symmetric matrix: y_{n-i} = a - b, i.e. the roles of a and b swap in (b - a)
       if (!(ablate & 2) || ce[0] == 12345.678) {
         const double alpha = p.alpha;
         if (p.out_mode == OUT_STORE) {
@@ -332,7 +333,7 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.ablate = g_ablate;
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sym = m.sym; p.ablate = g_ablate;
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);

@@ -13,6 +13,7 @@ U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
 V = torch.empty_like(U)
 L = sp.lib()
 for ab in abl:
+    L.chebhip_debug_two_stage(1 if os.environ.get('TWO_STAGE') == '1' else 0)
     L.chebhip_debug_ablate(ab)
     for _ in range(300):
         op.mult(U, V)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Time the Stokes callbacks at the BASELINE configs 4 and 5 (sustained loop, HIP events)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+sp = ge.load()
+
+def timeit(fn, reps=50):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+for P, power in ((64, False), (128, True)):
+    dims = (P, P, P)
+    op = sp.StokesOp(dims)
+    if power:
+        op.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
+    x = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    v = torch.randn(op.velocity_size, dtype=torch.float64, device="cuda"); vo = torch.empty_like(v)
+    p = torch.randn(op.pressure_size, dtype=torch.float64, device="cuda"); po = torch.empty_like(p)
+    import numpy as np
+    op.set_dirichlet(np.zeros(op.dirichlet_size)); op.set_force(np.zeros(op.global_size))
+    t_fn = timeit(lambda: op.function(x, y))
+    t_mm = timeit(lambda: op.mult(x, y))
+    t_vv = timeit(lambda: op.mult_vv(v, vo))
+    t_pv = timeit(lambda: op.mult_pv(v, po))
+    t_vp = timeit(lambda: op.mult_vp(p, vo))
+    n = float(P) ** 3
+    bm, bf = (680.0 if power else 600.0), 712.0
+    print("stokes %d^3 %s: MatMult %.1f us (%.2f TB/s alg @%g B/node)  Function %.1f us (%.2f TB/s alg)  VV %.1f  PV %.1f  VP %.1f us" % (
+        P, "power-law" if power else "linear", t_mm, bm * n / t_mm / 1e6, bm, t_fn, bf * n / t_fn / 1e6, t_vv, t_pv, t_vp))
+    op.destroy()
