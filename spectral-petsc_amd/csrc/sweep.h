@@ -77,6 +77,10 @@ hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 int sweep_get_ablate();
 void sweep_note_launch();
 
+// 16-byte-access specialisation (sweep_vec.hip); used by sweep_launch when eligible
+bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);
+hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+
 long sweep_launch_count();
 void sweep_set_ablate(int bits);
 

@@ -25,6 +25,7 @@
 #include "sweep.h"
 #include <atomic>
 #include <type_traits>
+#include <cstdlib>
 
 namespace chebhip {
 
@@ -334,6 +335,11 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sym = m.sym; p.ablate = g_ablate;
+  {
+    static int novec = -1;
+    if (novec < 0) { const char *e = getenv("CHEBHIP_NOVEC"); novec = (e && e[0] == '1') ? 1 : 0; }
+    if (!novec && sweep_vec_eligible(m, p)) return sweep_vec_launch(m, p, stream);
+  }
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);

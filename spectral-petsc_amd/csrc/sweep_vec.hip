@@ -1,0 +1,304 @@
+// sweep_vec.hip -- cheb_sweep_kernel specialised for 16-byte global accesses.
+//
+// Same algorithm, tiling and LDS images as sweep.hip (matrix halves in registers, double-buffered
+// parity-split tile, v_mfma_f64_16x16x4_f64 chains), restricted to what the hot launches need --
+// plain input, STORE or ACC output -- and with every HBM access widened from 8 to 16 bytes per lane:
+//   * a CU's load/store path moves 8-B accesses at ~0.6x the rate of 16-B ones, and at P = 256 the
+//     launch is as much per-CU-bandwidth-bound as MFMA-bound;
+//   * half as many memory instructions and address computations per point.
+// Loads: COLFAST lanes take two neighbouring lines of one row, JFAST lanes two neighbouring points
+// (and the mirrored pair) of one line; both go to LDS with one ds_write_b128 per image.
+// Stores: the accumulator layout gives a lane ONE column (COLFAST) / ONE point (JFAST) of four rows;
+// neighbouring lanes swap half of their values (DPP quad_perm) so that each ends up with TWO adjacent
+// columns/points of two rows and stores them as one 16-B piece.
+// Preconditions (checked on the host, otherwise sweep.hip runs): COLFAST: even line stride;
+// JFAST: stride 1 and even line length; all arrays 16-B aligned.
+#include "sweep.h"
+
+namespace chebhip {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32;
+
+__device__ __forceinline__ void lds_barrier_v() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// exchange with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double swap1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int KS, bool JFAST>
+__global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p) {
+  constexpr int MTP = KS / 4;
+  constexpr int NG = 8 / MTP;
+  constexpr int HP = 4 * KS;
+  constexpr int NSUB = (KS >= 16) ? 2 : 1;
+  constexpr int NT = 16 * NG * NSUB;
+  constexpr int LDJ = HP + 2;
+  constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
+  constexpr int ITEMS = HP * NT / 2 / 512;            // 16-B slots per thread per tile
+  constexpr int CH = ITEMS / NSUB;
+  constexpr int QSTEP = JFAST ? 512 / (HP / 2) : 512 / (NT / 2);   // line step (JFAST) / j-pair step (COLFAST)
+  constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
+  constexpr int KSTR = JFAST ? 4 : 4 * NT;
+  static_assert(CH >= 1 && (QSTEP % 2 == 0 || JFAST), "tile geometry");
+  __shared__ double smem[4 * LDS_ELEMS];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mt = w % MTP, ng = w / MTP;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int odd = l16 & 1, l16e = l16 & ~1;
+  const int nn = p.P - 1, H = p.H;
+  const u32 inner = p.inner, ncols = p.ncols;
+  const u32 lineLen = (u32)p.P * inner;
+
+  double ae[KS], ao[KS];
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
+    ao[s] = p.fragO[((long)(mt * KS + s)) * 64 + lane];
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see sweep.hip
+
+  const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
+  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
+  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
+  const u32 t_step = gridDim.x / nxcd;
+
+  // loader slots: COLFAST (line pair 2*ld_a, j-pair ld_b + s*QSTEP); JFAST (points 2*ld_a, 2*ld_a+1 of line ld_b + s*QSTEP)
+  const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
+  const int ld_b = JFAST ? tid / (HP / 2) : tid / (NT / 2);
+  const int ld_lds0 = JFAST ? ld_b * LDJ + 2 * ld_a : ld_b * NT + ((2 * ld_a) ^ ((ld_b & 1) << 4));
+
+  // Two chunks of prefetched lines are in flight at a time (A, B): each rides under TWO MFMA chains
+  // before it is parity-split into LDS -- one chain (~3.5 us) is not enough to cover an HBM round trip
+  // when the whole chip streams.
+  d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
+  const d2 *zero2 = (const d2 *)p.zero;
+
+  const int ablate = p.ablate;   // profiling only (sweep.h)
+  auto issue_loads = [&](u32 tile, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
+    if (ablate & 1) {
+#pragma unroll
+      for (int s = 0; s < CH; s++) { rj[s] = d2{1.0 + s, 2.0}; rm[s] = d2{0.5, 0.25}; }
+      return;
+    }
+    if (!JFAST) {
+      const u32 o = tile / tpo, q0 = (tile - o * tpo) * NT;
+      const u32 q = q0 + 2 * ld_a;
+      const bool cv = q < inner;                            // inner is even: the pair is in or out together
+      const u32 base = o * lineLen + q;
+      int jp = ld_b + chunk * CH * QSTEP;
+      u32 rel = (u32)jp * inner;
+      const u32 top = base + (u32)nn * inner;
+      asm volatile("" : "+v"(rel), "+v"(jp));
+#pragma unroll
+      for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * inner) {
+        const bool ok = cv && jp < H;
+        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
+        rm[s] = *((ok && nn - jp != jp) ? (const d2 *)(p.in0 + (top - rel)) : zero2);
+      }
+    } else {
+      const int j = 2 * ld_a;                               // points j, j+1 and their mirrors n-j-1, n-j
+#pragma unroll
+      for (int s = 0; s < CH; s++) {
+        const u32 c = tile * NT + ld_b + (chunk * CH + s) * QSTEP;
+        const bool ok = c < ncols && j < H;
+        const u32 base = (ok ? c : 0u) * lineLen;
+        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
+        rm[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
+      }
+    }
+  };
+
+  auto park_chunk = [&](int buf, int chunk, const d2 (&rj)[CH], const d2 (&rm)[CH]) {
+    double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
+#pragma unroll
+    for (int s = 0; s < CH; s++) {
+      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
+      d2 e, o;
+      if (!JFAST) {
+        const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn;   // rm was left 0 there
+        e = rj[s] + rm[s];
+        o = rj[s] - rm[s];
+        if (mid) o = d2{0.0, 0.0};
+      } else {
+        // rj = (x_j, x_{j+1}), rm = (x_{n-j-1}, x_{n-j}); point j+1 may be past the half (H odd) -> 0
+        const bool v1 = 2 * ld_a + 1 < H;
+        e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
+        o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
+      }
+      *(d2 *)(dE + idx) = e;
+      *(d2 *)(dO + idx) = o;
+    }
+  };
+
+  const int i0 = mt * 16 + (JFAST ? l16 : kq);
+  const bool acc_on = (p.out_mode == OUT_ACC);
+  const double alpha = p.alpha;
+
+  u32 tile = t_lo + blockIdx.x / nxcd;
+  if (tile < t_hi) {
+#pragma unroll 1
+    for (int ch = 0; ch < NSUB; ch++) { issue_loads(tile, ch, rjA, rmA); park_chunk(0, ch, rjA, rmA); }
+    if (NSUB == 2 && tile + t_step < t_hi) issue_loads(tile + t_step, 0, rjA, rmA);   // rides under the first chain
+  }
+  lds_barrier_v();
+  int cur = 0;
+  for (; tile < t_hi; tile += t_step) {
+    const u32 nxt = tile + t_step;
+    const bool has_next = nxt < t_hi;
+    const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
+    const u32 t_o = tile / tpo, t_q0 = (tile - t_o * tpo) * NT;
+    auto do_sub = [&](int sub, auto &&issue_fn, auto &&park_fn) {
+      issue_fn();
+      const int nb = (ng * NSUB + sub) * 16;
+
+      // After the lane exchange this lane owns, for rp = 0,1: accumulator row r = 2*rp + odd, and of it
+      // the two adjacent columns (COLFAST) / points (JFAST) starting at the even lane of its pair.
+      u32 a_hi[2], a_lo[2];      // element offsets of the two 16-B pieces (row i / mirror row n-i)
+      bool ok_hi[2], ok_lo[2], fold[2];
+      d2 acc_hi[2], acc_lo[2];
+#pragma unroll
+      for (int rp = 0; rp < 2; rp++) {
+        const int r = 2 * rp + odd;
+        if (!JFAST) {
+          const u32 q = t_q0 + nb + l16e;
+          const int i = i0 + 4 * r;
+          const u32 b = t_o * lineLen + q;
+          ok_hi[rp] = q < inner && i < H;
+          ok_lo[rp] = ok_hi[rp] && (nn - i != i);
+          fold[rp] = false;
+          a_hi[rp] = b + (u32)i * inner;
+          a_lo[rp] = b + (u32)(nn - i) * inner;
+        } else {
+          const u32 c = tile * NT + nb + 4 * r + kq;
+          const int ie = mt * 16 + l16e;                   // points ie, ie+1 of line c; mirrors n-ie-1, n-ie
+          const u32 b = (c < ncols ? c : 0u) * lineLen;
+          ok_hi[rp] = c < ncols && ie < H;
+          fold[rp] = ok_hi[rp] && (ie + 1 >= H);            // H odd: point ie+1 IS the mirror of ie
+          ok_lo[rp] = ok_hi[rp] && !fold[rp];
+          a_hi[rp] = b + (u32)ie;
+          a_lo[rp] = b + (u32)(nn - ie - 1);
+        }
+        acc_hi[rp] = d2{0.0, 0.0}; acc_lo[rp] = d2{0.0, 0.0};
+        if (acc_on && !(ablate & 1)) {
+          acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
+          acc_lo[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
+        }
+      }
+
+      v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
+      if (ablate & 4) { ce[0] = sE[l16]; co[0] = sO[l16]; }
+      else {
+        const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
+        const double *fE = sE + frag, *fO = sO + frag;
+        double fb[2][4];
+        fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
+#pragma unroll
+        for (int g = 0; g < KS / 2; g++) {
+          const int cb = g & 1, nbuf = cb ^ 1;
+          if (g + 1 < KS / 2) {
+            fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
+            fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
+          }
+          if (!JFAST) {
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g], fb[cb][2], co, 0, 0, 0);
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g + 1], fb[cb][3], co, 0, 0, 0);
+          } else {
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], ao[2 * g], co, 0, 0, 0);
+            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], ao[2 * g + 1], co, 0, 0, 0);
+          }
+        }
+      }
+      park_fn();                                            // before the stores: the wait covers loads only
+
+      // hi = value of row i, lo = value of the mirror row n-i  (D: b - a;  D D: a - b)
+      double hi[4], lo[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
+#pragma unroll
+      for (int rp = 0; rp < 2; rp++) {
+        // even lane keeps row 2rp and gets the neighbour's row 2rp; odd lane keeps row 2rp+1
+        const double own_hi = odd ? hi[2 * rp + 1] : hi[2 * rp], snd_hi = odd ? hi[2 * rp] : hi[2 * rp + 1];
+        const double own_lo = odd ? lo[2 * rp + 1] : lo[2 * rp], snd_lo = odd ? lo[2 * rp] : lo[2 * rp + 1];
+        const double rcv_hi = swap1(snd_hi), rcv_lo = swap1(snd_lo);
+        d2 vh = odd ? d2{rcv_hi, own_hi} : d2{own_hi, rcv_hi};   // ascending columns / points
+        d2 vl;
+        if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
+        else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};  // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
+        if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};   // (y_ie, y_{n-ie}) : adjacent when H is odd
+        vh = acc_hi[rp] + alpha * vh;
+        vl = acc_lo[rp] + alpha * vl;
+        if ((ablate & 2) && vh.x != 12345.678) continue;
+        if (ok_hi[rp]) *(d2 *)(p.out + a_hi[rp]) = vh;
+        if (ok_lo[rp]) *(d2 *)(p.out + a_lo[rp]) = vl;
+      }
+    };
+    if (NSUB == 2) {
+      const u32 nxt2 = nxt + t_step;
+      do_sub(0, [&] { if (has_next) issue_loads(nxt, 1, rjB, rmB); },
+                [&] { if (has_next) park_chunk(cur ^ 1, 0, rjA, rmA); });
+      do_sub(1, [&] { if (nxt2 < t_hi) issue_loads(nxt2, 0, rjA, rmA); },
+                [&] { if (has_next) park_chunk(cur ^ 1, 1, rjB, rmB); });
+    } else {
+      do_sub(0, [&] { if (has_next) issue_loads(nxt, 0, rjA, rmA); },
+                [&] { if (has_next) park_chunk(cur ^ 1, 0, rjA, rmA); });
+    }
+    lds_barrier_v();
+    cur ^= 1;
+  }
+}
+
+template <int KS, bool JFAST>
+static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
+  constexpr int MTP = KS / 4, NG = 8 / MTP, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB;
+  SweepParams p = p0;
+  if (JFAST) p.ntiles = (p.ncols + NT - 1) / NT;
+  else p.ntiles = (p.ncols / p.inner) * ((p.inner + NT - 1) / NT);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+    e = hipGetDeviceProperties(&prop, dev); if (e != hipSuccess) return e;
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
+  sweep_note_launch();
+  return hipGetLastError();
+}
+
+bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p) {
+  if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
+  const bool jfast = p.inner < 16;
+  if (jfast && (p.inner != 1 || (m.P & 1))) return false;
+  if (!jfast && (p.inner & 1)) return false;
+  auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
+  if (!al(p.in0) || !al(p.out) || (p.out_mode == OUT_ACC && !al(p.acc))) return false;
+  return m.KS == 4 || m.KS == 8 || m.KS == 16 || m.KS == 32;
+}
+
+hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
+  const bool jfast = p.inner < 16;
+  switch (m.KS) {
+    case 4: return jfast ? launch_v<4, true>(p, stream) : launch_v<4, false>(p, stream);
+    case 8: return jfast ? launch_v<8, true>(p, stream) : launch_v<8, false>(p, stream);
+    case 16: return jfast ? launch_v<16, true>(p, stream) : launch_v<16, false>(p, stream);
+    case 32: return jfast ? launch_v<32, true>(p, stream) : launch_v<32, false>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace chebhip
