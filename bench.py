@@ -127,20 +127,23 @@ def main():
         ms_per_step = wall * 1e3 / args.steps
         value = args.steps / wall
         npts = float(P) ** 3
-        # dominant kernel: cheb_fused_kernel, 3 launches per matvec (each = 2 of the reference's 6
-        # ChebMult + its share of the vector passes) on torch's current stream, timed with HIP events
+        # dominant kernel: 3 launches per matvec, one per direction (each replaces 2 of the reference's
+        # 6 ChebMult + its share of the vector passes) on torch's current stream, timed with HIP events
         # around the K steps; algorithmic bytes per launch = 112*P^3/3
         launch_s = (dev_ms * 1e-3) / (args.steps * launches_per_step)
         alg_bytes_launch = BYTES_PER_POINT * npts / launches_per_step / world
         achieved = alg_bytes_launch / launch_s
+        two_stage = os.environ.get("CHEBHIP_TWO_STAGE") == "1"
         traffic = None      # HBM bytes per launch from the committed PMC profile of this kernel/config, if any
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step:
+            if tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step and not two_stage:
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        flops_launch = 6.0 * float(P) * npts / launches_per_step / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
+        # FP64 MFMA work actually issued: constant-coefficient path = one (P-2)-point even/odd product per
+        # direction ((P-2) flop/point); two-stage path = two P-point products per direction (2P flop/point)
+        flops_launch = ((2.0 * P) if two_stage else float(P - 2)) * (float(P - 2) ** 3) / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
         out = {
             "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
             "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,7 +153,7 @@ def main():
                        "P": P, "parallelism": parallelism, "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "cheb_fused_kernel", "avg_launch_us": launch_s * 1e6,
+                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec_kernel", "avg_launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "mfma_f64_tflops": flops_launch / launch_s / 1e12,
                          "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},
