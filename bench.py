@@ -71,9 +71,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1
+    # path on a single-GPU box (the exchange is then staged through the host: not a measurement)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     P = args.size
     dims = (P, P, P)
@@ -95,6 +102,7 @@ def main():
         parallelism = "slab%d+all2all" % world
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -117,7 +125,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = t.item()

@@ -103,6 +103,11 @@ class DistPoissonOp:
     def _a2a(self, out, inp, out_split, in_split):
         if self.G == 1:
             out.copy_(inp)
+        elif inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU, BENCH_DIST_BACKEND=gloo): stage through the host
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(ho, inp.cpu(), out_split, in_split, group=self.group)
+            out.copy_(ho)
         else:
             dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
 
