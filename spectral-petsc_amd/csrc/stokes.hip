@@ -24,6 +24,7 @@ int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
   } while (0)
 
 static inline unsigned sgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+static inline unsigned pgrid(long nlines) { long g = (nlines + 31) / 32; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 #define GS_LOOP(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // xL <- velocity part of a global vector (node stride `gs`: d for vG, d+1 for the full vector), zero or
@@ -52,14 +53,35 @@ __global__ void k_st_comp(long N, int d, int i, const double *__restrict__ xL, d
 // end values of a line become the degree-(len-3) polynomial through its interior values evaluated at the
 // ends.  The reference builds a Neville table per line (util.C:129-144, O(len^2)); the same linear
 // functional is applied here as two dot products with precomputed Lagrange weights.
-__global__ void k_st_preduce(double *__restrict__ pres, long na, long a0, long sa, long nb, long b0, long sb,
-                             long se, int len, const double *__restrict__ w0, const double *__restrict__ w1) {
-  GS_LOOP(t, na * nb) {
-    const long a = t / nb, b = t - a * nb;
-    double *line = pres + (a + a0) * sa + (b + b0) * sb;
+// 256 threads = 8 parts x 32 lines: neighbouring threads take neighbouring lines (coalesced for the y and x
+// families, whose lines are strided), each part sums a fixed slice of the line and the 8 partial sums are
+// added in a fixed order through LDS -- deterministic, and 8x the parallelism of one thread per line.
+__global__ __launch_bounds__(256) void k_st_preduce(double *__restrict__ pres, long na, long a0, long sa, long nb, long b0,
+                                                    long sb, long se, int len, const double *__restrict__ w0,
+                                                    const double *__restrict__ w1) {
+  __shared__ double s0[8][32], s1[8][32];
+  const int tb = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const long nlines = na * nb;
+  const int m = len - 2, chunk = (m + 7) / 8;
+  for (long g = blockIdx.x; g * 32 < nlines; g += gridDim.x) {
+    const long t = g * 32 + tb;
     double f0 = 0.0, f1 = 0.0;
-    for (int j = 1; j < len - 1; j++) { const double v = line[(long)j * se]; f0 += w0[j - 1] * v; f1 += w1[j - 1] * v; }
-    line[0] = f0; line[(long)(len - 1) * se] = f1;
+    double *line = nullptr;
+    if (t < nlines) {
+      const long a = t / nb, b = t - a * nb;
+      line = pres + (a + a0) * sa + (b + b0) * sb;
+      const int j0 = part * chunk, j1 = (j0 + chunk < m) ? j0 + chunk : m;
+      for (int j = j0; j < j1; j++) { const double v = line[(long)(j + 1) * se]; f0 += w0[j] * v; f1 += w1[j] * v; }
+    }
+    s0[part][tb] = f0; s1[part][tb] = f1;
+    __syncthreads();
+    if (part == 0 && t < nlines) {
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { r0 += s0[q][tb]; r1 += s1[q][tb]; }
+      line[0] = r0; line[(long)(len - 1) * se] = r1;
+    }
+    __syncthreads();
   }
 }
 
@@ -122,22 +144,27 @@ __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict
 
 // Final scatter: velocity rows = yL (+ grad p), pressure rows = div v, minus force
 // (scatterLV/VG, VecAXPY stokes.C:513-517,750-756).  Any of yL / gp0 / p2 may be null.
-__global__ void k_st_out(long N, int d, int gs, const int *__restrict__ ixL, const double *__restrict__ yL,
+template <int D>
+__global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const double *__restrict__ yL,
                          const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
                          const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out) {
-  const double *gp[3] = {gp0, gp1, gp2};
   GS_LOOP(l, N) {
     const int n = ixL[l];
     if (n < 0) continue;
     const long o = (long)n * gs;
-    if (yL || gp0)
-      for (int k = 0; k < d; k++) {
-        double v = yL ? yL[l * d + k] : 0.0;
-        if (gp0) v = yL ? v + 1.0 * gp[k][l] : gp[k][l];
-        if (force) v += -1.0 * force[o + k];
-        out[o + k] = v;
+    if (yL || gp0) {
+      double v[D];
+#pragma unroll
+      for (int k = 0; k < D; k++) v[k] = yL ? yL[l * D + k] : 0.0;
+      if (gp0) {
+        const double g0 = gp0[l], g1 = gp1[l], g2 = (D == 3) ? gp2[l] : 0.0;
+        if (yL) { v[0] += 1.0 * g0; v[1] += 1.0 * g1; if (D == 3) v[D - 1] += 1.0 * g2; }
+        else { v[0] = g0; v[1] = g1; if (D == 3) v[D - 1] = g2; }
       }
-    if (p2) { double v = p2[l]; if (force) v += -1.0 * force[o + po]; out[o + po] = v; }
+#pragma unroll
+      for (int k = 0; k < D; k++) { if (force) v[k] += -1.0 * force[o + k]; out[o + k] = v[k]; }
+    }
+    if (p2) { double w = p2[l]; if (force) w += -1.0 * force[o + po]; out[o + po] = w; }
   }
 }
 
@@ -337,18 +364,21 @@ static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   const int d = op->d;
   const long m = op->dims[0], n = op->dims[1], p = (d == 2) ? 1 : op->dims[2];
   if (p > 1)    // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052)
-    hipLaunchKernelGGL(k_st_preduce, dim3(sgrid((m - 1) * (n - 1))), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, n - 1, 1L, p, 1L,
+    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid((m - 1) * (n - 1))), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, n - 1, 1L, p, 1L,
                        (int)p, (const double *)op->w0[2], (const double *)op->w1[2]);
   // y lines of planes i = 1..m-1, every k (stokes.C:1054-1062)
-  hipLaunchKernelGGL(k_st_preduce, dim3(sgrid((m - 1) * p)), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, p, 0L, 1L, p,
+  hipLaunchKernelGGL(k_st_preduce, dim3(pgrid((m - 1) * p)), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, p, 0L, 1L, p,
                      (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
   // x lines, every (j, k) (stokes.C:1064-1074)
-  hipLaunchKernelGGL(k_st_preduce, dim3(sgrid(n * p)), dim3(256), 0, st, op->pL, n, 0L, p, p, 0L, 1L, n * p,
+  hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(n * p)), dim3(256), 0, st, op->pL, n, 0L, p, p, 0L, 1L, n * p,
                      (int)m, (const double *)op->w0[0], (const double *)op->w1[0]);
   for (int i = 0; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
   return 0;
 }
 
+// k_st_out<d> with the common launch geometry
+#define ST_OUT(...) do { if (d == 2) hipLaunchKernelGGL((k_st_out<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); \
+                         else hipLaunchKernelGGL((k_st_out<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); } while (0)
 #define ARGCHK(c) do { if (!(c)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument"); } while (0)
 
 extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
@@ -357,7 +387,7 @@ extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, v
   const int d = op->d;
   hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, vG, (const double *)nullptr, op->xL);
   int rc = st_viscous_jacobian(op, st); if (rc) return rc;
-  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, (const double *)op->yL,
+  ST_OUT(d, (const int *)op->ixL, (const double *)op->yL,
                      (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0, (const double *)nullptr, out);
   SHIPCHK(hipGetLastError());
   return 0;
@@ -369,7 +399,7 @@ extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, 
   const int d = op->d;
   hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, vG, (const double *)nullptr, op->xL);
   int rc = st_divergence(op, st); if (rc) return rc;
-  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, 1, (const int *)op->ixL, (const double *)nullptr,
+  ST_OUT(1, (const int *)op->ixL, (const double *)nullptr,
                      (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)op->p2, 0, (const double *)nullptr, pout);
   SHIPCHK(hipGetLastError());
   return 0;
@@ -381,7 +411,7 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
   const int d = op->d;
   hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 1, 0, (const int *)op->ixL, pG, op->pL);
   int rc = st_pressure_gradient(op, st); if (rc) return rc;
-  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, (const double *)nullptr,
+  ST_OUT(d, (const int *)op->ixL, (const double *)nullptr,
                      (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)nullptr, 0, (const double *)nullptr, vout);
   SHIPCHK(hipGetLastError());
   return 0;
@@ -397,7 +427,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   if ((rc = st_divergence(op, st))) return rc;
   hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d + 1, d, (const int *)op->ixL, xG, op->pL);   // scatterGP (:510)
   if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // MatVP (:512)
-  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, (const double *)op->yL,
+  ST_OUT(d + 1, (const int *)op->ixL, (const double *)op->yL,
                      (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, (const double *)nullptr, yG);
   SHIPCHK(hipGetLastError());
   return 0;
@@ -418,7 +448,7 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   if ((rc = st_divergence(op, st))) return rc;                                                                                   // :746
   hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d + 1, d, (const int *)op->ixL, xG, op->pL);
   if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // :747
-  hipLaunchKernelGGL(k_st_out, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, (const double *)op->yL,
+  ST_OUT(d + 1, (const int *)op->ixL, (const double *)op->yL,
                      (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, (const double *)op->force, yG);   // :750-756
   SHIPCHK(hipGetLastError());
   return 0;
