@@ -139,6 +139,8 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
     }
   };
 
+  constexpr bool STAG = (KS >= 16);   // staggered in-chain placement needs a chain long enough to hide it
+  const bool grpB = w >= 4;             // second wave of each SIMD
   const int i0 = mt * 16 + (JFAST ? l16 : kq);
   const bool acc_on = (p.out_mode == OUT_ACC);
   const double alpha = p.alpha;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
     const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
     const u32 t_o = tile / tpo, t_q0 = (tile - t_o * tpo) * NT;
     auto do_sub = [&](int sub, auto &&issue_fn, auto &&park_fn) {
-      issue_fn();
+      if (!STAG) issue_fn();
       const int nb = (ng * NSUB + sub) * 16;
 
       // After the lane exchange this lane owns, for rp = 0,1: accumulator row r = 2*rp + odd, and of it
@@ -188,11 +190,18 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
           a_lo[rp] = b + (u32)(nn - ie - 1);
         }
         acc_hi[rp] = d2{0.0, 0.0}; acc_lo[rp] = d2{0.0, 0.0};
-        if (acc_on && !(ablate & 1)) {
-          acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
-          acc_lo[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
-        }
       }
+      // the VecAXPY operand of this sub-tile: fetched early in the chain (staggered like the loads)
+      auto acc_fn = [&] {
+        if (acc_on && !(ablate & 1)) {
+#pragma unroll
+          for (int rp = 0; rp < 2; rp++) {
+            acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
+            acc_lo[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
+          }
+        }
+      };
+      if (!STAG) acc_fn();
 
       v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
       if (ablate & 4) { ce[0] = sE[l16]; co[0] = sO[l16]; }
@@ -208,6 +217,13 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
             fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
             fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
           }
+          if (STAG) {
+            // The loads of the chunk after next and the parity split of the chunk that has arrived sit
+            // INSIDE the chain, at different places for the two waves of a SIMD (waves 0-3 / 4-7): while
+            // one wave issues its memory and LDS-write instructions the other keeps the MFMA pipe busy.
+            if (g == (grpB ? 0 : KS / 8)) { acc_fn(); issue_fn(); }
+            if (g == (grpB ? KS / 4 : 3 * KS / 8)) park_fn();
+          }
           if (!JFAST) {
             ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
             co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g], fb[cb][2], co, 0, 0, 0);
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
           }
         }
       }
-      park_fn();                                            // before the stores: the wait covers loads only
+      if (!STAG) park_fn();                                 // before the stores: the wait covers loads only
 
       // hi = value of row i, lo = value of the mirror row n-i  (D: b - a;  D D: a - b)
       double hi[4], lo[4];
