@@ -168,7 +168,10 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(P, args.cpu_threads)          # the faithful one: the reference is serial
+            ncpu = min(os.cpu_count() or 1, 16)
+            if ncpu > args.cpu_threads:                                       # the generous one: OpenMP over lines
+                out["cpu_baseline_all_cores"] = cpu_baseline(P, ncpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -58,6 +58,35 @@ static int require_device() {
 // ---------------------------------------------------------------------------------------------
 // kernel-level plan (MatCreateCheb / ChebMult / ChebDestroy, chebyshev.c:89-235)
 // ---------------------------------------------------------------------------------------------
+// Lines longer than 256 points do not fit the register-resident MFMA kernels.  cheb_apply still serves
+// them (the reference accepts any extent) with a plain dense product on the FP64 VALU: 4 lines per
+// workgroup staged in LDS, D^T streamed from L2 (coalesced over the output index).  Correctness path,
+// not a tuned one.
+__global__ __launch_bounds__(256) void k_dense_long(int P, unsigned ncols, unsigned inner, const double *__restrict__ DT,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double xs[];                 // [4][P]
+  for (unsigned c0 = blockIdx.x * 4; c0 < ncols; c0 += gridDim.x * 4) {
+    for (int t = threadIdx.x; t < 4 * P; t += 256) {
+      const unsigned c = c0 + t / P; const int j = t % P;
+      xs[t] = c < ncols ? x[(long)(c / inner) * P * inner + (c % inner) + (long)j * inner] : 0.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += 256) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int j = 0; j < P; j++) {
+        const double d = DT[(long)j * P + i];
+        a0 += d * xs[j]; a1 += d * xs[P + j]; a2 += d * xs[2 * P + j]; a3 += d * xs[3 * P + j];
+      }
+      const double a[4] = {a0, a1, a2, a3};
+      for (int l = 0; l < 4; l++) {
+        const unsigned c = c0 + l;
+        if (c < ncols) y[(long)(c / inner) * P * inner + (c % inner) + (long)i * inner] = a[l];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 struct cheb_plan {
   int rank = 0, tr = 0;
   std::vector<int> dims;
@@ -65,11 +94,12 @@ struct cheb_plan {
   unsigned inner = 1, ncols = 0;
   DiffMat mat;
   DiffMat lap;                          // trimmed plans: interior D D
+  double *longDT = nullptr;             // lines > 256 points: dense D^T (row-major, [j][i]) for k_dense_long
   bool trimmed = false;                 // created by cheb_plan_create_trimmed
   double *hx = nullptr, *hy = nullptr;  // staging for the host-pointer path
 };
 
-static int check_geom(int rank, int tr, const int *dims, long *N, unsigned *inner) {
+static int check_geom(int rank, int tr, const int *dims, long *N, unsigned *inner, bool allow_long = false) {
   if (!dims || rank < 1 || rank > 16) return fail(CHEBHIP_ERR_DIMS, "rank = %d must be in 1..16", rank);
   if (!(0 <= tr && tr < rank)) return fail(CHEBHIP_ERR_TDIM, "tdim out of range");              // chebyshev.c:106
   long n = 1, in = 1;
@@ -80,8 +110,9 @@ static int check_geom(int rank, int tr, const int *dims, long *N, unsigned *inne
     if (n > 0x7fffffffL) return fail(CHEBHIP_ERR_DIMS, "tensor of more than 2^31-1 points");
   }
   if (n < 2 || dims[tr] < 2) return fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 2", n);       // chebyshev.c:18,98
-  if (dims[tr] > 256)
+  if (dims[tr] > 256 && !allow_long)
     return fail(CHEBHIP_ERR_ARG, "dims[tr] = %d: this build keeps the differentiation matrix in registers and supports <= 256 points per line", dims[tr]);
+  if (dims[tr] > 4096) return fail(CHEBHIP_ERR_ARG, "dims[tr] = %d: at most 4096 points per line", dims[tr]);
   *N = n; *inner = (unsigned)in;
   return 0;
 }
@@ -90,15 +121,24 @@ extern "C" int cheb_plan_create(int rank, int tr, const int *dims, cheb_plan **o
   if (!out) return fail(CHEBHIP_ERR_ARG, "out is NULL");
   *out = nullptr;
   long N; unsigned inner;
-  int rc = check_geom(rank, tr, dims, &N, &inner);
+  int rc = check_geom(rank, tr, dims, &N, &inner, true);
   if (rc) return rc;
   if ((rc = require_device())) return rc;
   cheb_plan *p = new (std::nothrow) cheb_plan;
   if (!p) return fail(CHEBHIP_ERR_MEMORY, "out of host memory");
   p->rank = rank; p->tr = tr; p->dims.assign(dims, dims + rank);
   p->N = N; p->inner = inner; p->ncols = (unsigned)(N / dims[tr]);
-  hipError_t e = diffmat_create(dims[tr], &p->mat);
-  if (e != hipSuccess) { delete p; return fail(CHEBHIP_ERR_DEVICE, "diffmat_create: %s", hipGetErrorString(e)); }
+  hipError_t e = hipSuccess;
+  if (dims[tr] <= 256) e = diffmat_create(dims[tr], &p->mat);
+  else {
+    const int P = dims[tr];
+    std::vector<double> D((size_t)P * P), DT((size_t)P * P);
+    diffmat_dense_host(P, D.data());
+    for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) DT[(size_t)j * P + i] = D[(size_t)i * P + j];
+    e = hipMalloc((void **)&p->longDT, DT.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(p->longDT, DT.data(), DT.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) { if (p->longDT) (void)hipFree(p->longDT); delete p; return fail(CHEBHIP_ERR_DEVICE, "plan matrices: %s", hipGetErrorString(e)); }
   *out = p;
   return 0;
 }
@@ -153,6 +193,14 @@ extern "C" int cheb_apply(cheb_plan *p, const double *x, double *y, void *stream
   if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct (as every ChebMult call site)");
   if (p->trimmed) return fail(CHEBHIP_ERR_ARG, "plan is trimmed: use cheb_apply_lap1d");
+  if (p->longDT) {
+    const int P = p->dims[p->tr];
+    unsigned grid = (p->ncols + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_dense_long, dim3(grid), dim3(256), (size_t)4 * P * sizeof(double), (hipStream_t)stream, P, p->ncols, p->inner,
+                       (const double *)p->longDT, x, y);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   SweepParams sp = {};
   sp.ncols = p->ncols; sp.inner = p->inner;
   sp.in0 = x; sp.out = y; sp.alpha = 1.0;
@@ -176,6 +224,7 @@ extern "C" int cheb_plan_destroy(cheb_plan *p) {
   if (!p) return 0;
   diffmat_destroy(&p->mat);
   diffmat_destroy(&p->lap);
+  if (p->longDT) (void)hipFree(p->longDT);
   if (p->hx) (void)hipFree(p->hx);
   if (p->hy) (void)hipFree(p->hy);
   delete p;

@@ -101,6 +101,16 @@ def test_cheb_large_vs_oracle(shape, tr):
     assert relerr(y, ref) < TOL
 
 
+@pytest.mark.parametrize("shape,tr", [((300, 40), 0), ((12, 513), 1), ((6, 400, 5), 1)])
+def test_cheb_long_lines(shape, tr):
+    """Lines longer than 256 points take the dense VALU path of cheb_apply (no register-resident matrix)."""
+    rng = np.random.default_rng(SEED)
+    x = rng.standard_normal(shape)
+    y = gpu_cheb(x, tr)
+    ref = orc.cheb_mult(x, tr, orc.FAST, nthreads=8)
+    assert relerr(y, ref) < TOL
+
+
 @pytest.mark.parametrize("dims", [(33, 32, 31), (64, 64, 64)])
 def test_cheb_exp_known_answer(dims):
     """cheb.c:73-112 on the GPU: d/dx_d (e^x+e^y+e^z) = e^{x_d}; HIP error <= 4x oracle error + eps."""
