@@ -217,6 +217,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
             fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
             fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
           }
+          // fence: keep the fragment reads of group g+1 ABOVE the MFMAs of group g (hipcc otherwise sinks
+          // them to just before their use and every group starts with an exposed LDS round trip)
+          __builtin_amdgcn_sched_barrier(0);
           if (STAG) {
             // The loads of the chunk after next and the parity split of the chunk that has arrived sit
             // INSIDE the chain, at different places for the two waves of a SIMD (waves 0-3 / 4-7): while
