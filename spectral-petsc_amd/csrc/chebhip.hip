@@ -43,6 +43,10 @@ extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 // Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
 extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
+// Diagnostic builds (-DCHEB_STAMPS) only: device buffer of 256*8*4 uint64 receiving per-wave phase cycle sums.
+static const double *g_stamp_buf = nullptr;
+extern "C" void chebhip_debug_stamp_buffer(const void *dev) { g_stamp_buf = (const double *)dev; }
+const double *chebhip_stamp_buf() { return g_stamp_buf; }
 
 static bool use_two_stage();
 

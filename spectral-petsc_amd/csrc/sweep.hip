@@ -333,12 +333,16 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
   return hipGetLastError();
 }
 
+}  // namespace chebhip
+const double *chebhip_stamp_buf();
+namespace chebhip {
+
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sym = m.sym; p.ablate = g_ablate;
   {
     static int novec = -1;
     if (novec < 0) { const char *e = getenv("CHEBHIP_NOVEC"); novec = (e && e[0] == '1') ? 1 : 0; }
-    if (!novec && sweep_vec_eligible(m, p)) return sweep_vec_launch(m, p, stream);
+    if (!novec && sweep_vec_eligible(m, p)) { if (chebhip_stamp_buf()) p.in4 = chebhip_stamp_buf(); return sweep_vec_launch(m, p, stream); }
   }
   const bool jfast = p.inner < 16;
   switch (m.KS) {

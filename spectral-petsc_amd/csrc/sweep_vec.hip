@@ -145,6 +145,15 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
   const bool acc_on = (p.out_mode == OUT_ACC);
   const double alpha = p.alpha;
 
+#ifdef CHEB_STAMPS
+  unsigned long long st_pre = 0, st_chain = 0, st_post = 0, st_bar = 0, st_t0, st_t1, st_begin, st_loop, st_end;
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(v) do { } while (0)
+#endif
+#ifdef CHEB_STAMPS
+  STAMP(st_begin);
+#endif
   u32 tile = t_lo + blockIdx.x / nxcd;
   if (tile < t_hi) {
 #pragma unroll 1
@@ -152,6 +161,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
     if (NSUB == 2 && tile + t_step < t_hi) issue_loads(tile + t_step, 0, rjA, rmA);   // rides under the first chain
   }
   lds_barrier_v();
+#ifdef CHEB_STAMPS
+  STAMP(st_loop);
+#endif
   int cur = 0;
   for (; tile < t_hi; tile += t_step) {
     const u32 nxt = tile + t_step;
@@ -159,6 +171,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
     const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
     const u32 t_o = tile / tpo, t_q0 = (tile - t_o * tpo) * NT;
     auto do_sub = [&](int sub, auto &&issue_fn, auto &&park_fn) {
+#ifdef CHEB_STAMPS
+      STAMP(st_t0);
+#endif
       if (!STAG) issue_fn();
       const int nb = (ng * NSUB + sub) * 16;
 
@@ -203,6 +218,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
       };
       if (!STAG) acc_fn();
 
+#ifdef CHEB_STAMPS
+      STAMP(st_t1); st_pre += st_t1 - st_t0;
+#endif
       v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
       if (ablate & 4) { ce[0] = sE[l16]; co[0] = sO[l16]; }
       else {
@@ -240,6 +258,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
           }
         }
       }
+#ifdef CHEB_STAMPS
+      STAMP(st_t0); st_chain += st_t0 - st_t1;
+#endif
       if (!STAG) park_fn();                                 // before the stores: the wait covers loads only
 
       // hi = value of row i, lo = value of the mirror row n-i  (D: b - a;  D D: a - b)
@@ -263,6 +284,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
         if (ok_hi[rp]) *(d2 *)(p.out + a_hi[rp]) = vh;
         if (ok_lo[rp]) *(d2 *)(p.out + a_lo[rp]) = vl;
       }
+#ifdef CHEB_STAMPS
+      STAMP(st_t1); st_post += st_t1 - st_t0;
+#endif
     };
     if (NSUB == 2) {
       const u32 nxt2 = nxt + t_step;
@@ -274,9 +298,23 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
       do_sub(0, [&] { if (has_next) issue_loads(nxt, 0, rjA, rmA); },
                 [&] { if (has_next) park_chunk(cur ^ 1, 0, rjA, rmA); });
     }
+#ifdef CHEB_STAMPS
+    STAMP(st_t0);
+#endif
     lds_barrier_v();
+#ifdef CHEB_STAMPS
+    STAMP(st_t1); st_bar += st_t1 - st_t0;
+#endif
     cur ^= 1;
   }
+#ifdef CHEB_STAMPS
+  STAMP(st_end);
+  if (lane == 0 && p.in4) {
+    unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)blockIdx.x * 8 + w) * 8;
+    dbg[0] = st_pre; dbg[1] = st_chain; dbg[2] = st_post; dbg[3] = st_bar;
+    dbg[4] = st_loop - st_begin; dbg[5] = st_end - st_loop; dbg[6] = st_begin; dbg[7] = st_end;
+  }
+#endif
 }
 
 template <int KS, bool JFAST>
