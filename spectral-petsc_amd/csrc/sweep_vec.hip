@@ -46,7 +46,11 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
   constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
   constexpr int KSTR = JFAST ? 4 : 4 * NT;
   static_assert(CH >= 1 && (QSTEP % 2 == 0 || JFAST), "tile geometry");
-  __shared__ double smem[4 * LDS_ELEMS];
+  // At P = 256 the matrix halves need 128 VGPRs per wave.  The last NFL odd-half fragments live in the LDS
+  // left over by the tile images instead (32 KiB), which frees 2*NFL VGPRs for a deeper operand prefetch.
+  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
+  constexpr int KR = KS - NFL;                       // odd-half fragments kept in registers
+  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mt = w % MTP, ng = w / MTP;
@@ -56,11 +60,13 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
   const u32 inner = p.inner, ncols = p.ncols;
   const u32 lineLen = (u32)p.P * inner;
 
-  double ae[KS], ao[KS];
+  double ae[KS], ao[KR > 0 ? KR : 1];
+  double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;   // this wave's LDS-resident fragments
 #pragma unroll
   for (int s = 0; s < KS; s++) {
     ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
-    ao[s] = p.fragO[((long)(mt * KS + s)) * 64 + lane];
+    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
+    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see sweep.hip
 
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 
   constexpr bool STAG = (KS >= 16);   // staggered in-chain placement needs a chain long enough to hide it
   const bool grpB = w >= 4;             // second wave of each SIMD
+#define AO(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
   const int i0 = mt * 16 + (JFAST ? l16 : kq);
   const bool acc_on = (p.out_mode == OUT_ACC);
   const double alpha = p.alpha;
@@ -247,14 +254,14 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
           }
           if (!JFAST) {
             ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g], fb[cb][2], co, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g), fb[cb][2], co, 0, 0, 0);
             ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g + 1], fb[cb][3], co, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g + 1), fb[cb][3], co, 0, 0, 0);
           } else {
             ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], ao[2 * g], co, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], AO(2 * g), co, 0, 0, 0);
             ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], ao[2 * g + 1], co, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], AO(2 * g + 1), co, 0, 0, 0);
           }
         }
       }
