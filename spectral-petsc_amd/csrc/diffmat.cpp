@@ -71,11 +71,12 @@ hipError_t diffmat_create(int P, DiffMat *out) {
       }
   DiffMat m;
   m.P = P; m.H = H; m.KS = KS; m.MTP = MTP;
-  hipError_t e = hipMalloc((void **)&m.fragE, (cnt + 8) * sizeof(double));
+  hipError_t e = hipMalloc((void **)&m.fragE, (cnt + 8 + 1024) * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMalloc((void **)&m.fragO, cnt * sizeof(double));
   if (e != hipSuccess) { (void)hipFree(m.fragE); return e; }
   m.zero = m.fragE + cnt;
+  m.sink = m.zero + 8;
   e = hipMemset(m.zero, 0, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
@@ -123,11 +124,12 @@ hipError_t diffmat_create_lap(int P, DiffMat *out) {
       }
   DiffMat r;
   r.P = M; r.H = H; r.KS = KS; r.MTP = MTP; r.sym = 1;
-  hipError_t e = hipMalloc((void **)&r.fragE, (cnt + 8) * sizeof(double));
+  hipError_t e = hipMalloc((void **)&r.fragE, (cnt + 8 + 1024) * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMalloc((void **)&r.fragO, cnt * sizeof(double));
   if (e != hipSuccess) { (void)hipFree(r.fragE); return e; }
   r.zero = r.fragE + cnt;
+  r.sink = r.zero + 8;
   e = hipMemset(r.zero, 0, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(r.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(r.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);

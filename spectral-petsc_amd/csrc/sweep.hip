@@ -338,7 +338,7 @@ const double *chebhip_stamp_buf();
 namespace chebhip {
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sym = m.sym; p.ablate = g_ablate;
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate;
   {
     static int novec = -1;
     if (novec < 0) { const char *e = getenv("CHEBHIP_NOVEC"); novec = (e && e[0] == '1') ? 1 : 0; }
