@@ -161,7 +161,7 @@ def main():
                        "P": P, "parallelism": parallelism, "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec_kernel", "avg_launch_us": launch_s * 1e6,
+                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec2_kernel", "avg_launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "mfma_f64_tflops": flops_launch / launch_s / 1e12,
                          "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},
