@@ -27,26 +27,27 @@ static inline unsigned sgrid(long n) { long g = (n + 255) / 256; return (unsigne
 static inline unsigned pgrid(long nlines) { long g = (nlines + 31) / 32; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 #define GS_LOOP(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
-// xL <- velocity part of a global vector (node stride `gs`: d for vG, d+1 for the full vector), zero or
-// Dirichlet values on the boundary: VecZeroEntries + scatterVL (+ scatterDL), stokes.C:575-582,634-637,695-699.
-__global__ void k_st_vlocal(long N, int d, int gs, const int *__restrict__ ixL, const double *__restrict__ src,
-                            const double *__restrict__ dirloc, double *__restrict__ xL) {
-  GS_LOOP(a, N * d) {
-    const long l = a / d; const int k = (int)(a - l * d);
+// Work-vector layout.  The reference keeps the d components of a node interleaved (rank d+1 plans with the
+// components innermost, stokes.C:284-290); the global vectors at the ABI keep that layout.  Inside the
+// operator the component index is OUTERMOST (field k occupies [k*N, (k+1)*N)): DV[i] is then DP[i] over d
+// stacked scalar fields -- contiguous lines for the last grid dimension, 16-byte accesses everywhere -- and a
+// component is a contiguous scalar field (no VecStrideGather/Scatter copies, stokes.C:585,613).
+//
+// xL <- velocity part, pL <- pressure part of a global vector (node stride gs, pressure offset go); zero or
+// Dirichlet values on the boundary: VecZeroEntries + scatterGV/VL (+ scatterDL) + scatterGP,
+// stokes.C:505-510,575-582,605-608,634-637,695-699.  xL or pL may be null.
+template <int D>
+__global__ void k_st_local(long N, int gs, int go, const int *__restrict__ ixL, const double *__restrict__ src,
+                           const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL) {
+  GS_LOOP(l, N) {
     const int n = ixL[l];
-    xL[a] = n >= 0 ? src[(long)n * gs + k] : (dirloc ? dirloc[a] : 0.0);
+    const double *s = src + (long)(n >= 0 ? n : 0) * gs;
+    if (xL) {
+#pragma unroll
+      for (int k = 0; k < D; k++) xL[k * N + l] = n >= 0 ? s[k] : (dirloc ? dirloc[k * N + l] : 0.0);
+    }
+    if (pL) pL[l] = n >= 0 ? s[go] : 0.0;
   }
-}
-
-// pL <- pressure part of a global vector (stride gs, offset go), zero on the boundary: stokes.C:605-608.
-__global__ void k_st_plocal(long N, int gs, int go, const int *__restrict__ ixL, const double *__restrict__ src,
-                            double *__restrict__ pL) {
-  GS_LOOP(l, N) { const int n = ixL[l]; pL[l] = n >= 0 ? src[(long)n * gs + go] : 0.0; }
-}
-
-// VecStrideGather(workV[0], i, workP[0]) stokes.C:585
-__global__ void k_st_comp(long N, int d, int i, const double *__restrict__ xL, double *__restrict__ p0) {
-  GS_LOOP(l, N) p0[l] = xL[l * d + i];
 }
 
 // Boundary pressure of one family of grid lines (StokesPressureReduceOrder, stokes.C:1029-1080): the two
@@ -85,11 +86,15 @@ __global__ __launch_bounds__(256) void k_st_preduce(double *__restrict__ pres, l
   }
 }
 
-// Node loop of StokesMatMultVV, stokes.C:647-662.  V[j], S[j]: N*d arrays (component k of direction j).
-template <int D>
+// Node loop of StokesMatMultVV, stokes.C:647-662.  V[j], S[j]: d stacked fields (component k of direction j).
+// DETA = false when deta is identically zero (linear rheology): the deta * S0 * z term vanishes and S0 is not
+// read.  The trace of the velocity gradient is the divergence StokesMatMult needs for the pressure rows
+// (DV[i] restricted to component i IS DP[i] on that component, stokes.C:583-591), so it is written here
+// (div may be null) instead of being recomputed by d more sweeps.
+template <int D, bool DETA>
 __global__ void k_st_node_vv(long N, double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
                              const double *__restrict__ S0, const double *__restrict__ S1, const double *__restrict__ S2,
-                             const double *__restrict__ eta, const double *__restrict__ deta) {
+                             const double *__restrict__ eta, const double *__restrict__ deta, double *__restrict__ div) {
   double *V[3] = {V0, V1, V2};
   const double *S[3] = {S0, S1, S2};
   GS_LOOP(i, N) {
@@ -97,16 +102,17 @@ __global__ void k_st_node_vv(long N, double *__restrict__ V0, double *__restrict
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
-      for (int k = 0; k < D; k++) { g[j][k] = V[j][i * D + k]; S0v[j][k] = S[j][i * D + k]; }
+      for (int k = 0; k < D; k++) { g[j][k] = V[j][k * N + i]; S0v[j][k] = DETA ? S[j][k * N + i] : 0.0; }
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
       for (int k = 0; k < D; k++) { strain[j][k] = 0.5 * (g[j][k] + g[k][j]); z += strain[j][k] * S0v[j][k]; }
-    const double e = eta[i], de = deta[i];
+    const double e = eta[i], de = DETA ? deta[i] : 0.0;
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
-      for (int k = 0; k < D; k++) V[j][i * D + k] = e * strain[j][k] + de * S0v[j][k] * z;
+      for (int k = 0; k < D; k++) V[j][k * N + i] = DETA ? e * strain[j][k] + de * S0v[j][k] * z : e * strain[j][k];
+    if (div) { double t = g[0][0] + g[1][1]; if (D == 3) t += g[D - 1][D - 1]; div[i] = t; }
   }
 }
 
@@ -114,7 +120,7 @@ __global__ void k_st_node_vv(long N, double *__restrict__ V0, double *__restrict
 template <int D>
 __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict__ S1, double *__restrict__ S2,
                              double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
-                             double *__restrict__ eta, double *__restrict__ deta,
+                             double *__restrict__ eta, double *__restrict__ deta, double *__restrict__ div,
                              int kind, double hardness, double expo, double eps, double gamma0) {
   double *V[3] = {V0, V1, V2};
   double *S[3] = {S0, S1, S2};
@@ -123,7 +129,7 @@ __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
-      for (int k = 0; k < D; k++) g[j][k] = S[j][i * D + k];
+      for (int k = 0; k < D; k++) g[j][k] = S[j][k * N + i];
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
@@ -138,7 +144,8 @@ __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
-      for (int k = 0; k < D; k++) { V[j][i * D + k] = e * s[j][k]; S[j][i * D + k] = s[j][k]; }
+      for (int k = 0; k < D; k++) { V[j][k * N + i] = e * s[j][k]; S[j][k * N + i] = s[j][k]; }
+    if (div) { double t = g[0][0] + g[1][1]; if (D == 3) t += g[D - 1][D - 1]; div[i] = t; }    // stokes.C:746
   }
 }
 
@@ -155,7 +162,7 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
     if (yL || gp0) {
       double v[D];
 #pragma unroll
-      for (int k = 0; k < D; k++) v[k] = yL ? yL[l * D + k] : 0.0;
+      for (int k = 0; k < D; k++) v[k] = yL ? yL[k * N + l] : 0.0;
       if (gp0) {
         const double g0 = gp0[l], g1 = gp1[l], g2 = (D == 3) ? gp2[l] : 0.0;
         if (yL) { v[0] += 1.0 * g0; v[1] += 1.0 * g1; if (D == 3) v[D - 1] += 1.0 * g2; }
@@ -182,9 +189,10 @@ struct stokes_op {
   double *V[3] = {nullptr, nullptr, nullptr};                // workV[2..]
   double *strain[3] = {nullptr, nullptr, nullptr};           // c->strain[]
   double *eta = nullptr, *deta = nullptr;
-  double *pL = nullptr, *p0 = nullptr, *p2 = nullptr, *gp[3] = {nullptr, nullptr, nullptr};   // workP[]
+  double *pL = nullptr, *p2 = nullptr, *gp[3] = {nullptr, nullptr, nullptr};   // workP[]
   double *dirloc = nullptr, *force = nullptr;
   std::vector<double *> w0, w1;                              // pressure extrapolation weights per dim
+  bool deta_nonzero = false;                                 // deta == 0 everywhere: the node loop skips S0
   int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
 };
 
@@ -194,7 +202,7 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
-                   op->pL, op->p0, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force};
+                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force};
   for (double *p : all) if (p) (void)hipFree(p);
   for (double *p : op->w0) if (p) (void)hipFree(p);
   for (double *p : op->w1) if (p) (void)hipFree(p);
@@ -241,13 +249,13 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
   for (int k = 0; k < d; k++) {
     unsigned in = 1; for (int r = k + 1; r < d; r++) in *= dims[r];
     op->innerP[k] = in; op->ncolsP[k] = (unsigned)(N / dims[k]);
-    op->innerV[k] = in * d; op->ncolsV[k] = (unsigned)(N * d / dims[k]);      // cheb_dim = {dim..., d}, stokes.C:284-290
+    op->innerV[k] = in; op->ncolsV[k] = (unsigned)(N / dims[k]) * d;          // DV[k]: the same lines for d stacked fields
   }
   const size_t nd = (size_t)N * d;
   OPRC(st_alloc(&op->xL, nd)); OPRC(st_alloc(&op->yL, nd));
   for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
   OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
-  OPRC(st_alloc(&op->pL, (size_t)N)); OPRC(st_alloc(&op->p0, (size_t)N)); OPRC(st_alloc(&op->p2, (size_t)N));
+  OPRC(st_alloc(&op->pL, (size_t)N)); OPRC(st_alloc(&op->p2, (size_t)N));
   hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
   // Lagrange weights of the interior nodes x_1..x_{P-2} at x_0 and x_{P-1} (the polyInterp functional)
   op->w0.assign(d, nullptr); op->w1.assign(d, nullptr);
@@ -302,7 +310,7 @@ extern "C" int stokes_op_set_dirichlet(stokes_op *op, const double *values) {
   for (long l = 0; l < op->N; l++) {                      // ixDL order: boundary nodes in BlockIt order, d values each
     bool bdy = false;
     for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) bdy = true;
-    if (bdy) for (int k = 0; k < d; k++) loc[l * d + k] = values[dd++];
+    if (bdy) for (int k = 0; k < d; k++) loc[(size_t)k * op->N + l] = values[dd++];
     for (int j = d - 1; j >= 0; j--) { if (++ind[j] < op->dims[j]) break; ind[j] = 0; }
   }
   if (!op->dirloc) SHIPCHK(hipMalloc((void **)&op->dirloc, loc.size() * sizeof(double)));
@@ -319,14 +327,24 @@ extern "C" int stokes_op_set_force(stokes_op *op, const double *force) {
 }
 
 // ---- building blocks ------------------------------------------------------------------------
+// DP[k] (scalar field) or DV[k] (d stacked fields: same lines, d times as many)
 static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *y, int out_mode, const double *acc,
                        double alpha, hipStream_t st) {
   SweepParams sp = {};
   sp.ncols = vec ? op->ncolsV[k] : op->ncolsP[k];
-  sp.inner = vec ? op->innerV[k] : op->innerP[k];
+  sp.inner = op->innerP[k];
   sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.out_mode = out_mode; sp.acc = acc; sp.alpha = alpha;
   SHIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
   return 0;
+}
+
+#define ST_D(KERNEL, ...) do { if (d == 2) hipLaunchKernelGGL((KERNEL<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); \
+                               else hipLaunchKernelGGL((KERNEL<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); } while (0)
+
+// xL / pL <- global vector (either may be null)
+static void st_local(stokes_op *op, int gs, int go, const double *src, const double *dirloc, double *xL, double *pL, hipStream_t st) {
+  const int d = op->d;
+  ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL);
 }
 
 // yL = -sum_j DV[j] V[j]   (stokes.C:668-671, 737-740)
@@ -338,22 +356,23 @@ static int st_div_stress(stokes_op *op, hipStream_t st) {
   return 0;
 }
 
-// viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]
-static int st_viscous_jacobian(stokes_op *op, hipStream_t st) {
+// viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]; div (may be null)
+// receives the trace of the gradient = StokesDivergence of the same xL
+static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st) {
   const int d = op->d;
   for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->V[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :639
-  if (d == 2) hipLaunchKernelGGL((k_st_node_vv<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2],
-                                 (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta);
-  else hipLaunchKernelGGL((k_st_node_vv<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2],
-                          (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta);
+#define NODE_VV(D_, DETA_) hipLaunchKernelGGL((k_st_node_vv<D_, DETA_>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
+    (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
+  if (d == 2) { if (op->deta_nonzero) NODE_VV(2, true); else NODE_VV(2, false); }
+  else        { if (op->deta_nonzero) NODE_VV(3, true); else NODE_VV(3, false); }
+#undef NODE_VV
   return st_div_stress(op, st);
 }
 
-// p2 = sum_i DP[i] (component i of xL)   (StokesDivergence, stokes.C:583-591)
+// p2 = sum_i DP[i] (component i of xL)   (StokesDivergence, stokes.C:583-591); a component is a contiguous field
 static int st_divergence(stokes_op *op, hipStream_t st) {
   for (int i = 0; i < op->d; i++) {
-    hipLaunchKernelGGL(k_st_comp, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->d, i, (const double *)op->xL, op->p0);
-    int rc = sweep_plain(op, false, i, op->p0, op->p2, i == 0 ? OUT_STORE : OUT_ACC, op->p2, 1.0, st);
+    int rc = sweep_plain(op, false, i, op->xL + (size_t)i * op->N, op->p2, i == 0 ? OUT_STORE : OUT_ACC, op->p2, 1.0, st);
     if (rc) return rc;
   }
   return 0;
@@ -376,19 +395,17 @@ static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   return 0;
 }
 
-// k_st_out<d> with the common launch geometry
-#define ST_OUT(...) do { if (d == 2) hipLaunchKernelGGL((k_st_out<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); \
-                         else hipLaunchKernelGGL((k_st_out<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); } while (0)
+#define ST_OUT(...) ST_D(k_st_out, __VA_ARGS__)
 #define ARGCHK(c) do { if (!(c)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument"); } while (0)
+#define CDP(x) ((const double *)(x))
 
 extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
   ARGCHK(op && vG && out);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
-  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, vG, (const double *)nullptr, op->xL);
-  int rc = st_viscous_jacobian(op, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, (const double *)op->yL,
-                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0, (const double *)nullptr, out);
+  st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
+  int rc = st_viscous_jacobian(op, nullptr, st); if (rc) return rc;
+  ST_OUT(d, (const int *)op->ixL, CDP(op->yL), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -397,10 +414,9 @@ extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, 
   ARGCHK(op && vG && pout);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
-  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d, (const int *)op->ixL, vG, (const double *)nullptr, op->xL);
+  st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
   int rc = st_divergence(op, st); if (rc) return rc;
-  ST_OUT(1, (const int *)op->ixL, (const double *)nullptr,
-                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)op->p2, 0, (const double *)nullptr, pout);
+  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -409,10 +425,9 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
   ARGCHK(op && pG && vout);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
-  hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 1, 0, (const int *)op->ixL, pG, op->pL);
+  st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
   int rc = st_pressure_gradient(op, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, (const double *)nullptr,
-                     (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)nullptr, 0, (const double *)nullptr, vout);
+  ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -421,14 +436,12 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   ARGCHK(op && xG && yG);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
-  // scatterGV + scatterVL, zero boundary: the same xL serves MatVV (:508) and MatPV (:509)
-  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, xG, (const double *)nullptr, op->xL);
-  int rc = st_viscous_jacobian(op, st); if (rc) return rc;
-  if ((rc = st_divergence(op, st))) return rc;
-  hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d + 1, d, (const int *)op->ixL, xG, op->pL);   // scatterGP (:510)
+  // scatterGV + scatterVL (zero boundary) and scatterGP (:505-510) in one pass over xG; the same xL serves
+  // MatVV (:508) and MatPV (:509), whose result is the trace written by the node loop
+  st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
+  int rc = st_viscous_jacobian(op, op->p2, st); if (rc) return rc;
   if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // MatVP (:512)
-  ST_OUT(d + 1, (const int *)op->ixL, (const double *)op->yL,
-                     (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, (const double *)nullptr, yG);
+  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(nullptr), yG);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -438,41 +451,52 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
-  hipLaunchKernelGGL(k_st_vlocal, dim3(sgrid(op->N * d)), dim3(256), 0, st, op->N, d, d + 1, (const int *)op->ixL, xG, (const double *)op->dirloc, op->xL);
+  st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
   for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->strain[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :701
-  if (d == 2) hipLaunchKernelGGL((k_st_node_fn<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
-                                 op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
-  else hipLaunchKernelGGL((k_st_node_fn<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
-                          op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
+       op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  op->deta_nonzero = (op->rh_kind == 1);
   int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
-  if ((rc = st_divergence(op, st))) return rc;                                                                                   // :746
-  hipLaunchKernelGGL(k_st_plocal, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, d + 1, d, (const int *)op->ixL, xG, op->pL);
   if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // :747
-  ST_OUT(d + 1, (const int *)op->ixL, (const double *)op->yL,
-                     (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, (const double *)op->force, yG);   // :750-756
+  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(op->force), yG);   // :750-756
   SHIPCHK(hipGetLastError());
   return 0;
 }
 
-static int st_state_ptr(stokes_op *op, int which, double **p, size_t *n) {
+// State at the ABI is in the reference's layout (strain[j]: N nodes x d components, component fastest)
+static int st_state_ptr(stokes_op *op, int which, double **p, size_t *n, bool *soa) {
+  *soa = false;
   if (which == 0) { *p = op->eta; *n = (size_t)op->N; }
   else if (which == 1) { *p = op->deta; *n = (size_t)op->N; }
-  else if (which >= 2 && which < 2 + op->d) { *p = op->strain[which - 2]; *n = (size_t)op->N * op->d; }
+  else if (which >= 2 && which < 2 + op->d) { *p = op->strain[which - 2]; *n = (size_t)op->N * op->d; *soa = true; }
   else return chebhip_fail(CHEBHIP_ERR_ARG, "which = %d out of range", which);
   return 0;
 }
 
 extern "C" int stokes_op_get_state(stokes_op *op, int which, double *dst) {
   ARGCHK(op && dst);
-  double *p; size_t n; int rc = st_state_ptr(op, which, &p, &n); if (rc) return rc;
+  double *p; size_t n; bool soa; int rc = st_state_ptr(op, which, &p, &n, &soa); if (rc) return rc;
   SHIPCHK(hipDeviceSynchronize());
-  SHIPCHK(hipMemcpy(dst, p, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (!soa) { SHIPCHK(hipMemcpy(dst, p, n * sizeof(double), hipMemcpyDeviceToHost)); return 0; }
+  std::vector<double> tmp(n);
+  SHIPCHK(hipMemcpy(tmp.data(), p, n * sizeof(double), hipMemcpyDeviceToHost));
+  const size_t N = (size_t)op->N; const int d = op->d;
+  for (size_t l = 0; l < N; l++) for (int k = 0; k < d; k++) dst[l * d + k] = tmp[k * N + l];
   return 0;
 }
 
 extern "C" int stokes_op_set_state(stokes_op *op, int which, const double *src) {
   ARGCHK(op && src);
-  double *p; size_t n; int rc = st_state_ptr(op, which, &p, &n); if (rc) return rc;
-  SHIPCHK(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
+  double *p; size_t n; bool soa; int rc = st_state_ptr(op, which, &p, &n, &soa); if (rc) return rc;
+  SHIPCHK(hipDeviceSynchronize());
+  if (!soa) {
+    SHIPCHK(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
+    if (which == 1) { bool nz = false; for (size_t i = 0; i < n && !nz; i++) nz = (src[i] != 0.0); op->deta_nonzero = nz; }
+    return 0;
+  }
+  std::vector<double> tmp(n);
+  const size_t N = (size_t)op->N; const int d = op->d;
+  for (size_t l = 0; l < N; l++) for (int k = 0; k < d; k++) tmp[k * N + l] = src[l * d + k];
+  SHIPCHK(hipMemcpy(p, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
