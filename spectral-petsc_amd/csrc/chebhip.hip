@@ -247,14 +247,31 @@ __global__ void k_gather_bc(long N, const int *__restrict__ ixL, const double *_
   }
 }
 
-// eta = 1 + gamma u^e, deta = e gamma u^(e-1): elliptic.C:508-509.
-__global__ void k_coeff(long N, double gamma, double expo, const double *__restrict__ u,
-                        double *__restrict__ eta, double *__restrict__ deta) {
+// w0 as above and eta = 1 + gamma u^e, deta = e gamma u^(e-1) (elliptic.C:508-509) in one pass over the local
+// vector (FormFunction, elliptic.C:486-509).  For a small integer
+// exponent (the reference's default is 2, elliptic.C:141) u^(e-1) is a product and u^e = u^(e-1) * u: no pow().
+__global__ void k_gather_coeff(long N, const int *__restrict__ ixL, const double *__restrict__ U,
+                               const double *__restrict__ dirloc, double gamma, double expo, int iexp,
+                               double *__restrict__ w0, double *__restrict__ eta, double *__restrict__ deta) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-    const double v = u[i];
-    eta[i] = 1.0 + gamma * pow(v, expo);
-    deta[i] = expo * gamma * pow(v, expo - 1.0);
+    const int g = ixL[i];
+    const double v = g >= 0 ? U[g] : (dirloc ? dirloc[i] : 0.0);
+    w0[i] = v;
+    if (iexp > 0) {
+      double pw = 1.0;
+      for (int q = 1; q < iexp; q++) pw *= v;
+      eta[i] = 1.0 + gamma * (pw * v);
+      deta[i] = expo * gamma * pw;
+    } else {
+      eta[i] = 1.0 + gamma * pow(v, expo);
+      deta[i] = expo * gamma * pow(v, expo - 1.0);
+    }
   }
+}
+
+// c_k = deta * du0_k: the coefficient of u in the linearised flux (elliptic.C:321), formed once per state
+__global__ void k_cprod(long N, const double *__restrict__ deta, const double *__restrict__ du, double *__restrict__ c) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) c[i] = deta[i] * du[i];
 }
 
 __global__ void k_fill(long N, double v, double *__restrict__ a) {
@@ -288,6 +305,8 @@ struct ell_op {
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
+  std::vector<double *> cprod;          // deta * gradu[k]: what the Jacobian apply reads (refreshed when the state changes)
+  bool cdirty = true;
   double *eta = nullptr, *deta = nullptr, *dirloc = nullptr;
   CoeffMode mode = COEFF_UNIT;
   double *hU = nullptr, *hV = nullptr, *hB = nullptr;  // staging for host-pointer calls
@@ -303,11 +322,13 @@ static int ell_alloc_state(ell_op *op) {
     HIPCHK(hipMemset(op->deta, 0, bytes));                                                           // VecSet(deta,0) :266
   }
   if (op->gradu.empty()) {
-    op->gradu.assign(op->d, nullptr);
+    op->gradu.assign(op->d, nullptr); op->cprod.assign(op->d, nullptr);
     for (int k = 0; k < op->d; k++) {
       HIPCHK(hipMalloc((void **)&op->gradu[k], bytes));
       HIPCHK(hipMemset(op->gradu[k], 0, bytes));
+      HIPCHK(hipMalloc((void **)&op->cprod[k], bytes));
     }
+    op->cdirty = true;
   }
   return 0;
 }
@@ -392,6 +413,7 @@ extern "C" int ell_op_destroy(ell_op *op) {
   for (auto p : op->gcol) if (p) (void)hipFree(p);
   for (auto p : op->g) if (p) (void)hipFree(p);
   for (auto p : op->gradu) if (p) (void)hipFree(p);
+  for (auto p : op->cprod) if (p) (void)hipFree(p);
   double *singles[] = {op->W, op->w0, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
   for (double *p : singles) if (p) (void)hipFree(p);
   if (op->ixL) (void)hipFree(op->ixL);
@@ -504,11 +526,16 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   // General coefficients: w0 = gather(U) on the fly (VecScatter GL + dirichlet0, elliptic.C:305-308),
   // V = scatter( -sum_k D_k( eta D_k w0 + deta w0 du0_k ) ); the gradient and the flux
   // (elliptic.C:309-323) never leave the chip.
+  if (op->cdirty) {
+    for (int k = 0; k < op->d; k++)
+      hipLaunchKernelGGL(k_cprod, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->deta, (const double *)op->gradu[k], op->cprod[k]);
+    op->cdirty = false;
+  }
   for (int k = 0; k < op->d; k++) {
     SweepParams sp = {};
     sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
     sp.in0 = U; sp.in_mode = IN_GATHER;
-    sp.coef_mode = COEF_FULL; sp.in1 = op->eta; sp.in2 = op->deta; sp.in4 = op->gradu[k];
+    sp.coef_mode = COEF_FULL; sp.in1 = op->eta; sp.in2 = op->cprod[k];
     ell_out_chain(op, k, V, &sp);
     HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st));
   }
@@ -522,10 +549,10 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
   int rc = ell_alloc_state(op);
   if (rc) return rc;
   const int d = op->d;
-  hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U,
-                     (const double *)op->dirloc, op->w0);                        // elliptic.C:486-493
-  hipLaunchKernelGGL(k_coeff, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, gamma, exponent,
-                     (const double *)op->w0, op->eta, op->deta);                 // :508-509
+  const int iexp = (exponent == std::floor(exponent) && exponent >= 1.0 && exponent <= 8.0) ? (int)exponent : 0;
+  hipLaunchKernelGGL(k_gather_coeff, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const int *)op->ixL, U,
+                     (const double *)op->dirloc, gamma, exponent, iexp, op->w0, op->eta, op->deta);   // elliptic.C:486-493, 508-509
+  op->cdirty = true;
   // eta stays exactly 1 and deta exactly 0 only when gamma == 0 and no pow() can produce inf/nan
   const bool unit = (gamma == 0.0) && (exponent == std::floor(exponent)) && exponent >= 1.0;
   op->mode = unit ? COEFF_UNIT : COEFF_FULL;
@@ -625,6 +652,6 @@ extern "C" int ell_op_set_state(ell_op *op, int which, const double *src) {
   if (!op || !src) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
   HIPCHK(hipMemcpy(p, src, (size_t)op->N * sizeof(double), hipMemcpyHostToDevice));
-  op->mode = COEFF_FULL;
+  op->mode = COEFF_FULL; op->cdirty = true;
   return 0;
 }

@@ -5,7 +5,8 @@
 // full set of lines can do all three without the gradient ever leaving the chip:
 //
 //   stage 1:  g = D u        MFMA chains over the (e,o)-split input tile in LDS region IN
-//             f = coef(g)    in the accumulator registers (eta, deta, du0 fetched per output)
+//             f = coef(g)    in the accumulator registers (eta and c = deta du0 fetched per output before
+//                            the chain, u read back from the LDS tile)
 //             parity-split f straight from the accumulators into LDS region F
 //   stage 2:  t = D f        MFMA chains over F;  out = acc + alpha*t  from the accumulators
 //
@@ -225,14 +226,21 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
       const int nb = (ng * NSUB + sub) * 16;
       u32 ob[4]; bool ov[4]; int og[4];
       out_geom(tile, nb, ob, ov, og);
-      double cv[8];                                     // eta at (line, i) and (line, n-i)
+      // eta (and c = deta * du0) at (line, i) and (line, n-i): requested BEFORE the chain, so that the
+      // round trip to HBM is covered by it
+      double cv[8], cc[(COEF == COEF_FULL) ? 8 : 1];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         cv[2 * r] = 1.0; cv[2 * r + 1] = 1.0;
+        if (COEF == COEF_FULL) { cc[2 * r] = 0.0; cc[2 * r + 1] = 0.0; }
         if (COEF != COEF_UNIT && ov[r]) {
           const int i = i0 + (JFAST ? 0 : 4 * r);
           cv[2 * r] = p.in1[ob[r] + (u32)i * inner];
           cv[2 * r + 1] = p.in1[ob[r] + (u32)(nn - i) * inner];
+          if (COEF == COEF_FULL) {
+            cc[2 * r] = p.in2[ob[r] + (u32)i * inner];
+            cc[2 * r + 1] = p.in2[ob[r] + (u32)(nn - i) * inner];
+          }
         }
       }
       v4d ce, co;
@@ -247,11 +255,12 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
           if (p.gout) { p.gout[ai] = gi; if (im != i) p.gout[am] = gm; }     // c->gradu[k], elliptic.C:498
           double fi = cv[2 * r] * gi, fm = cv[2 * r + 1] * gm;               // eta * g
           if (COEF == COEF_FULL) {                                     // + deta * u * du0 (elliptic.C:321)
-            double ui, um;
-            if (p.in_mode == IN_GATHER) { ui = fetch_u<IN_GATHER>(p, ai, i, og[r], true); um = fetch_u<IN_GATHER>(p, am, im, og[r], true); }
-            else { ui = p.in0[ai]; um = p.in0[am]; }
-            fi = fi + p.in2[ai] * ui * p.in4[ai];
-            fm = fm + p.in2[am] * um * p.in4[am];
+            // u is on chip: the parity-split tile holds e = u_i + u_{n-i} and o = u_i - u_{n-i}
+            const int uidx = JFAST ? (nb + 4 * r + kq) * LDJ + i : i * NT + ((nb + l16) ^ ((i & 1) << 4));
+            const double ue = inE[uidx], uo = inO[uidx];
+            const double ui = (im != i) ? 0.5 * (ue + uo) : ue, um = 0.5 * (ue - uo);
+            fi = fi + cc[2 * r] * ui;
+            fm = fm + cc[2 * r + 1] * um;
           }
           if (im != i) { e2 = fi + fm; o2 = fi - fm; } else { e2 = fi; o2 = 0.0; }
         }

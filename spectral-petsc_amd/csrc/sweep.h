@@ -23,7 +23,7 @@ enum OutMode : int {
 enum CoefMode : int {
   COEF_UNIT = 0,   // f = g                                   (eta == 1, deta == 0)
   COEF_ETA = 1,    // f = eta * g                             (elliptic.C:511)
-  COEF_FULL = 2    // f = eta * g + deta * u * du0            (elliptic.C:321)
+  COEF_FULL = 2    // f = eta * g + c * u,  c = deta * du0    (elliptic.C:321; c is formed once per linearisation)
 };
 
 struct SweepParams {
@@ -44,7 +44,7 @@ struct SweepParams {
   unsigned ntiles;
   int sym;            // mirror rows are a - b (centro-symmetric matrix) instead of b - a
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
-  int coef_mode;      // fused launches only: CoefMode; eta = in1, deta = in2, du0 = in4 (local layout)
+  int coef_mode;      // fused launches only: CoefMode; eta = in1, c = deta * du0 = in2 (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
   int variant;        // profiling only: experimental schedule switches (CHEBHIP_VARIANT)
   int ablate;         // profiling only (see sweep_set_ablate); 0 in production
