@@ -45,6 +45,10 @@ const char *chebhip_last_error(void);
 int chebhip_version(void);
 const char *chebhip_arch(void);
 
+/* A linear map on device vectors: y = A x.  ell_op_mult, stokes_op_mult and stokes_op_mult_vv have
+ * exactly this shape (ctx = the operator handle) and can be passed as is. */
+typedef int (*chebhip_apply_fn)(void *ctx, const double *x_dev, double *y_dev, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Kernel level: the N-D Chebyshev derivative (chebyshev.h:18-24,31-34).      */
 /* ------------------------------------------------------------------------- */
@@ -144,16 +148,45 @@ int stokes_op_set_force(stokes_op *op, const double *force_host);        /* c->f
 int stokes_op_mult(stokes_op *op, const double *xG_dev, double *yG_dev, void *stream);
 /* StokesMatMultVV (:623-676), StokesMatMultPV (:557-566), StokesMatMultVP (:599-619): the inner
  * MatShells MatVV / MatPV / MatVP that the Schur complement (:523-535) and the block
- * preconditioners (:1714-1817) call.  StokesMatMultSchur itself is VP -> KSPSolve -> PV -> scale(-1)
- * and stays on the PETSc side. */
+ * preconditioners (:1714-1817) call. */
 int stokes_op_mult_vv(stokes_op *op, const double *vG_dev, double *vG_out_dev, void *stream);
 int stokes_op_mult_pv(stokes_op *op, const double *vG_dev, double *pG_out_dev, void *stream);
 int stokes_op_mult_vp(stokes_op *op, const double *pG_dev, double *vG_out_dev, void *stream);
+/* StokesMatMultSchur (:523-535): out = -PV * solve(VV, VP * pG), all on device vectors.
+ * `inner_solve(ctx, rhs_dev, sol_dev, stream)` stands for KSPSolve(KSPSchurVelocity) (:531; operators
+ * MatVV / MatVVPC, options prefix svel_, :338-341): the PETSc adapter passes a wrapper around that KSP.
+ * NULL selects the built-in solver: unpreconditioned restarted GMRES on MatVV with KSP's defaults
+ * (restart 30, rtol 1e-5, atol 1e-50, max_it 10000, zero initial guess), see chebhip_fgmres_* below. */
+int stokes_op_mult_schur(stokes_op *op, const double *pG_dev, double *pG_out_dev,
+                         chebhip_apply_fn inner_solve, void *inner_ctx, void *stream);
+int stokes_op_set_inner_solver(stokes_op *op, int restart, double rtol, double atol, int max_it);
+int stokes_op_inner_iterations(const stokes_op *op);   /* MatVV applies of the last built-in inner solve */
 /* StokesFunction (:680-758): yG = F(xG) - force; refreshes eta, deta, strain. */
 int stokes_op_function(stokes_op *op, const double *xG_dev, double *yG_dev, void *stream);
 /* Operator state to/from the host: which = 0 eta (N), 1 deta (N), 2+j strain[j] (N*d). */
 int stokes_op_get_state(stokes_op *op, int which, double *dst_host);
 int stokes_op_set_state(stokes_op *op, int which, const double *src_host);
+
+/* ------------------------------------------------------------------------- */
+/* Krylov driver on device vectors: the caller of the path.     */
+/* KSPSolve with KSPFGMRES around MatMult_Elliptic (elliptic.C:181-185) and    */
+/* KSPSchurVelocity inside StokesMatMultSchur (stokes.C:531).  Restarted       */
+/* flexible GMRES, right preconditioner M (NULL = none; may change between     */
+/* applications), classical Gram-Schmidt, convergence on                       */
+/* |r| <= max(rtol |b|, atol) as KSPDefaultConverged.  All vectors stay in     */
+/* HBM; the host sees one Hessenberg column per iteration.                     */
+/* ------------------------------------------------------------------------- */
+typedef struct chebhip_fgmres chebhip_fgmres;
+int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out);
+int chebhip_fgmres_destroy(chebhip_fgmres *k);
+int chebhip_fgmres_set_tolerances(chebhip_fgmres *k, double rtol, double atol, int max_it);
+/* x_nonzero = 0: zero initial guess (x is overwritten); 1: x_dev holds the initial guess. */
+int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void *actx, chebhip_apply_fn M, void *mctx,
+                         const double *b_dev, double *x_dev, int x_nonzero, void *stream);
+int chebhip_fgmres_iterations(const chebhip_fgmres *k);   /* operator applies of the last solve */
+double chebhip_fgmres_residual(const chebhip_fgmres *k);  /* last (recurrence) residual norm */
+/* KSPConvergedReason of the last solve: 2 rtol, 3 atol, -3 max_it, -9 NaN/breakdown */
+int chebhip_fgmres_reason(const chebhip_fgmres *k);
 
 /* ------------------------------------------------------------------------- */
 /* Instrumentation (the reference has none: SURVEY 5.1).                      */

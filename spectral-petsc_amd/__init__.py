@@ -36,7 +36,9 @@ ABI_SYMBOLS = [
     "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
     "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
     "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
-    "stokes_op_set_state",
+    "stokes_op_set_state", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations",
+    "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
+    "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason",
 ]
 
 
@@ -100,6 +102,17 @@ def lib():
             f.argtypes = [vp, vp, vp, vp]
         L.stokes_op_get_state.argtypes = [vp, C.c_int, dp]
         L.stokes_op_set_state.argtypes = [vp, C.c_int, dp]
+        L.stokes_op_mult_schur.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.stokes_op_set_inner_solver.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.stokes_op_inner_iterations.argtypes = [vp]
+        L.chebhip_fgmres_create.argtypes = [C.c_long, C.c_int, C.POINTER(vp)]
+        L.chebhip_fgmres_destroy.argtypes = [vp]
+        L.chebhip_fgmres_set_tolerances.argtypes = [vp, C.c_double, C.c_double, C.c_int]
+        L.chebhip_fgmres_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+        L.chebhip_fgmres_iterations.argtypes = [vp]
+        L.chebhip_fgmres_residual.argtypes = [vp]
+        L.chebhip_fgmres_residual.restype = C.c_double
+        L.chebhip_fgmres_reason.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -315,6 +328,17 @@ class StokesOp:
     def mult_vp(self, p, vout):
         return self._call(lib().stokes_op_mult_vp, p, self.pressure_size, vout, self.velocity_size)
 
+    def mult_schur(self, p, pout, restart=None, rtol=None, atol=1e-50, max_it=10000):
+        """StokesMatMultSchur (stokes.C:523-535) with the built-in inner GMRES on MatVV (KSP defaults unless given)."""
+        if restart is not None or rtol is not None:
+            _chk(lib().stokes_op_set_inner_solver(self._h, 30 if restart is None else restart, 1e-5 if rtol is None else rtol, atol, max_it))
+        _chk(lib().stokes_op_mult_schur(self._h, _dev_ptr(p, self.pressure_size), _dev_ptr(pout, self.pressure_size), None, None, _stream()))
+        return pout
+
+    @property
+    def inner_iterations(self):
+        return lib().stokes_op_inner_iterations(self._h)
+
     def function(self, x, y):
         return self._call(lib().stokes_op_function, x, self.global_size, y, self.global_size)
 
@@ -335,6 +359,50 @@ class StokesOp:
     def destroy(self):
         if self._h:
             lib().stokes_op_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Fgmres:
+    """Restarted flexible GMRES on device vectors (KSPFGMRES's role, elliptic.C:181-185).
+
+    `A` and the optional right preconditioner `M` are operator objects of this module (EllipticOp,
+    StokesOp): their C entry points are handed to the solver directly, no Python in the loop.
+    """
+
+    def __init__(self, n, restart=30, rtol=1e-5, atol=1e-50, max_it=10000):
+        self.n = int(n)
+        h = C.c_void_p()
+        _chk(lib().chebhip_fgmres_create(self.n, restart, C.byref(h)))
+        self._h = h
+        _chk(lib().chebhip_fgmres_set_tolerances(h, rtol, atol, max_it))
+
+    @staticmethod
+    def _fn(op, entry):
+        if op is None:
+            return None, None
+        name = {"EllipticOp": "ell_op_", "StokesOp": "stokes_op_"}[type(op).__name__] + entry
+        return C.cast(getattr(lib(), name), C.c_void_p), op._h
+
+    def solve(self, A, b, x, M=None, x_nonzero=False, a_entry="mult", m_entry="mult"):
+        fa, ca = self._fn(A, a_entry)
+        fm, cm = self._fn(M, m_entry)
+        _chk(lib().chebhip_fgmres_solve(self._h, fa, ca, fm, cm, _dev_ptr(b, self.n), _dev_ptr(x, self.n),
+                                        1 if x_nonzero else 0, _stream()))
+        return x
+
+    iterations = property(lambda self: lib().chebhip_fgmres_iterations(self._h))
+    residual = property(lambda self: lib().chebhip_fgmres_residual(self._h))
+    reason = property(lambda self: lib().chebhip_fgmres_reason(self._h))
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            lib().chebhip_fgmres_destroy(self._h)
             self._h = None
 
     def __del__(self):

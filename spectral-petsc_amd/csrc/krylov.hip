@@ -1,0 +1,240 @@
+// krylov.hip -- restarted flexible GMRES on device vectors: the role KSPSolve plays around the operator
+// callbacks (KSPFGMRES, elliptic.C:181-185; KSPSchurVelocity inside StokesMatMultSchur, stokes.C:531).
+//
+// The operator and the (right, possibly varying) preconditioner are callbacks on device pointers with the
+// signature of ell_op_mult / stokes_op_mult_vv, so those entry points can be passed directly.  All vectors
+// stay in HBM; per iteration the host sees only the new Hessenberg column (j + 2 doubles).
+//   w = A M v_j;  h = V^T w (classical Gram-Schmidt, one pass -- PETSc's default orthogonalisation);
+//   w -= V h;  h_{j+1,j} = |w|;  Givens rotations and the triangular solve on the host.
+// Reductions are two-stage with a fixed block order: results do not depend on scheduling.
+#include "../../include/chebhip.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <new>
+#include <vector>
+
+int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+
+#define KHIPCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+constexpr int RB = 256;      // reduction blocks per dot product
+constexpr int RT = 256;      // threads per block
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  // wave reduction by DPP-free shuffles, then 4 wave sums through LDS in a fixed order
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) { for (int q = 0; q < RT / 64; q++) r += sh[q]; }
+  __syncthreads();
+  return r;   // valid in thread 0
+}
+
+// part[kk][b] = sum over chunk b of V[kk][i] * w[i],  kk = blockIdx.y < k
+__global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restrict__ V, long ldv, const double *__restrict__ w,
+                                                 double *__restrict__ part) {
+  __shared__ double sh[RT / 64];
+  const double *v = V + (long)blockIdx.y * ldv;
+  double s = 0.0;
+  for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)RB * RT) s += v[i] * w[i];
+  const double r = block_sum(s, sh);
+  if (threadIdx.x == 0) part[(long)blockIdx.y * RB + blockIdx.x] = r;
+}
+
+// out[kk] = sum_b part[kk][b] (fixed order); optional square root
+__global__ __launch_bounds__(RT) void k_reduce(const double *__restrict__ part, double *__restrict__ out, int take_sqrt) {
+  __shared__ double sh[RT / 64];
+  const double r = block_sum(part[(long)blockIdx.x * RB + threadIdx.x], sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = take_sqrt ? sqrt(r) : r;
+}
+
+// w -= sum_{kk<k} h[kk] V[kk];  part[b] = sum over chunk b of w^2
+__global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double *__restrict__ V, long ldv,
+                                                    const double *__restrict__ h, double *__restrict__ w, double *__restrict__ part) {
+  __shared__ double sh[RT / 64];
+  double s = 0.0;
+  for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)RB * RT) {
+    double x = w[i];
+    for (int kk = 0; kk < k; kk++) x -= h[kk] * V[(long)kk * ldv + i];
+    w[i] = x; s += x * x;
+  }
+  const double r = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+// y = a * x        (a read from the host value)
+__global__ void k_scale(long n, double a, const double *x, double *y) {   // x == y allowed
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = a * x[i];
+}
+
+// x += sum_{kk<k} y[kk] Z[kk]
+__global__ void k_multiaxpy(long n, int k, const double *__restrict__ Z, long ldz, const double *__restrict__ y, double *__restrict__ x) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double s = x[i];
+    for (int kk = 0; kk < k; kk++) s += y[kk] * Z[(long)kk * ldz + i];
+    x[i] = s;
+  }
+}
+
+// r = b - r
+__global__ void k_residual(long n, const double *__restrict__ b, double *__restrict__ r) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) r[i] = b[i] - r[i];
+}
+
+inline unsigned pgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+}  // namespace
+
+struct chebhip_fgmres {
+  long n = 0, ld = 0;
+  int m = 30;                       // restart (KSPGMRESSetRestart default 30)
+  double rtol = 1e-5, atol = 1e-50; // KSP defaults
+  int max_it = 10000;
+  double *V = nullptr, *Z = nullptr, *part = nullptr, *hdev = nullptr, *ydev = nullptr;
+  double *hhost = nullptr;          // pinned
+  int its = 0, reason = 0;
+  double rnorm = 0.0, rnorm0 = 0.0;
+};
+
+extern "C" int chebhip_fgmres_destroy(chebhip_fgmres *k) {
+  if (!k) return 0;
+  double *dev[] = {k->V, k->Z, k->part, k->hdev, k->ydev};
+  for (double *p : dev) if (p) (void)hipFree(p);
+  if (k->hhost) (void)hipHostFree(k->hhost);
+  delete k;
+  return 0;
+}
+
+extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (n < 1) return chebhip_fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 1", n);
+  if (restart < 1 || restart > 256) return chebhip_fail(CHEBHIP_ERR_ARG, "restart = %d must be in 1..256", restart);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return chebhip_fail(CHEBHIP_ERR_DEVICE, "no usable HIP device; libchebhip has no CPU fallback");
+  chebhip_fgmres *k = new (std::nothrow) chebhip_fgmres;
+  if (!k) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  k->n = n; k->m = restart; k->ld = (n + 1) & ~1L;       // even leading dimension: every basis vector 16-B aligned
+#define KC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { chebhip_fgmres_destroy(k); \
+    return chebhip_fail(e_ == hipErrorOutOfMemory ? CHEBHIP_ERR_MEMORY : CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+  KC(hipMalloc((void **)&k->V, (size_t)(restart + 1) * k->ld * sizeof(double)));
+  KC(hipMalloc((void **)&k->Z, (size_t)restart * k->ld * sizeof(double)));
+  KC(hipMalloc((void **)&k->part, (size_t)(restart + 2) * RB * sizeof(double)));
+  KC(hipMalloc((void **)&k->hdev, (size_t)(restart + 2) * sizeof(double)));
+  KC(hipMalloc((void **)&k->ydev, (size_t)(restart + 2) * sizeof(double)));
+  KC(hipHostMalloc((void **)&k->hhost, (size_t)(restart + 2) * sizeof(double)));
+#undef KC
+  *out = k;
+  return 0;
+}
+
+extern "C" int chebhip_fgmres_set_tolerances(chebhip_fgmres *k, double rtol, double atol, int max_it) {
+  if (!k) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  if (!(rtol >= 0.0) || !(atol >= 0.0) || max_it < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "negative tolerance or iteration limit");
+  k->rtol = rtol; k->atol = atol; k->max_it = max_it;
+  return 0;
+}
+
+extern "C" int chebhip_fgmres_iterations(const chebhip_fgmres *k) { return k ? k->its : -1; }
+extern "C" double chebhip_fgmres_residual(const chebhip_fgmres *k) { return k ? k->rnorm : -1.0; }
+extern "C" int chebhip_fgmres_reason(const chebhip_fgmres *k) { return k ? k->reason : 0; }
+
+// |v| on the device, result to the host (synchronises the stream)
+static int dev_norm(chebhip_fgmres *k, const double *v, hipStream_t st, double *out) {
+  hipLaunchKernelGGL(k_multidot, dim3(RB, 1), dim3(RT), 0, st, k->n, v, k->ld, v, k->part);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RT), 0, st, (const double *)k->part, k->hdev, 1);
+  KHIPCHK(hipMemcpyAsync(k->hhost, k->hdev, sizeof(double), hipMemcpyDeviceToHost, st));
+  KHIPCHK(hipStreamSynchronize(st));
+  *out = k->hhost[0];
+  return 0;
+}
+
+extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void *actx, chebhip_apply_fn M, void *mctx,
+                                    const double *b, double *x, int x_nonzero, void *stream) {
+  if (!k || !A || !b || !x) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long n = k->n, ld = k->ld;
+  const int m = k->m;
+  k->its = 0; k->reason = 0;
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m);
+  double bnorm = 0.0;
+  int rc = dev_norm(k, b, st, &bnorm); if (rc) return rc;
+  const double tol = std::fmax(k->rtol * bnorm, k->atol);
+  if (!x_nonzero) KHIPCHK(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), st));
+  bool first = true;
+  for (;;) {
+    // r = b - A x  into V[0]
+    double *r = k->V;
+    if (first && !x_nonzero) KHIPCHK(hipMemcpyAsync(r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    else {
+      if ((rc = A(actx, x, r, st))) return rc;
+      hipLaunchKernelGGL(k_residual, dim3(pgrid(n)), dim3(256), 0, st, n, b, r);
+    }
+    double beta = 0.0;
+    if ((rc = dev_norm(k, r, st, &beta))) return rc;
+    if (first) k->rnorm0 = beta;
+    first = false;
+    k->rnorm = beta;
+    if (!(beta == beta)) { k->reason = -9; return 0; }                  // NaN: KSP_DIVERGED_NANORINF
+    if (beta <= tol) { k->reason = beta <= k->atol ? 3 : 2; return 0; } // KSP_CONVERGED_ATOL / RTOL
+    if (k->its >= k->max_it) { k->reason = -3; return 0; }              // KSP_DIVERGED_ITS
+    hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / beta, (const double *)r, k->V);
+    g.assign(m + 1, 0.0); g[0] = beta;
+    int j = 0;
+    bool done = false;
+    for (; j < m && !done; j++) {
+      const double *vj = k->V + (long)j * ld;
+      const double *zj = vj;
+      if (M) { double *z = k->Z + (long)j * ld; if ((rc = M(mctx, vj, z, st))) return rc; zj = z; }
+      double *w = k->V + (long)(j + 1) * ld;
+      if ((rc = A(actx, zj, w, st))) return rc;
+      hipLaunchKernelGGL(k_multidot, dim3(RB, j + 1), dim3(RT), 0, st, n, (const double *)k->V, ld, (const double *)w, k->part);
+      hipLaunchKernelGGL(k_reduce, dim3(j + 1), dim3(RT), 0, st, (const double *)k->part, k->hdev, 0);
+      hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->hdev, w, k->part);
+      hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RT), 0, st, (const double *)k->part, k->hdev + (j + 1), 1);
+      KHIPCHK(hipMemcpyAsync(k->hhost, k->hdev, (size_t)(j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+      KHIPCHK(hipStreamSynchronize(st));
+      double *hc = &H[(size_t)j * (m + 1)];
+      for (int i = 0; i <= j + 1; i++) hc[i] = k->hhost[i];
+      const double hnext = hc[j + 1];
+      for (int i = 0; i < j; i++) {                                      // previous rotations
+        const double t = cs[i] * hc[i] + sn[i] * hc[i + 1];
+        hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1]; hc[i] = t;
+      }
+      const double den = std::hypot(hc[j], hc[j + 1]);
+      if (den == 0.0 || !(den == den)) { k->reason = -9; break; }          // column j is dropped
+      cs[j] = hc[j] / den; sn[j] = hc[j + 1] / den;
+      hc[j] = den; hc[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      k->its++;
+      k->rnorm = std::fabs(g[j + 1]);
+      if (k->rnorm <= tol || k->its >= k->max_it || hnext == 0.0) done = true;       // hnext == 0: happy breakdown
+      else hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / hnext, (const double *)w, w);
+    }
+    // y = H^{-1} g (upper triangular, j columns), x += Z y
+    const int kk = j;
+    for (int i = kk - 1; i >= 0; i--) {
+      double s = g[i];
+      for (int q = i + 1; q < kk; q++) s -= H[(size_t)q * (m + 1) + i] * y[q];
+      y[i] = s / H[(size_t)i * (m + 1) + i];
+    }
+    for (int i = 0; i < kk; i++) k->hhost[i] = y[i];
+    KHIPCHK(hipMemcpyAsync(k->ydev, k->hhost, (size_t)(kk > 0 ? kk : 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    if (kk > 0)
+      hipLaunchKernelGGL(k_multiaxpy, dim3(pgrid(n)), dim3(256), 0, st, n, kk, (const double *)(M ? k->Z : k->V), ld, (const double *)k->ydev, x);
+    KHIPCHK(hipStreamSynchronize(st));                                   // hhost is reused by the next cycle
+    if (k->reason == -9) return 0;
+    if (k->rnorm <= tol) { k->reason = k->rnorm <= k->atol ? 3 : 2; return 0; }
+    if (k->its >= k->max_it) { k->reason = -3; return 0; }
+    // otherwise restart: the true residual is recomputed at the top
+  }
+}

@@ -192,6 +192,11 @@ struct stokes_op {
   double *pL = nullptr, *p2 = nullptr, *gp[3] = {nullptr, nullptr, nullptr};   // workP[]
   double *dirloc = nullptr, *force = nullptr;
   std::vector<double *> w0, w1;                              // pressure extrapolation weights per dim
+  // StokesMatMultSchur: work vectors vG0, vG1 (stokes.C:530-532) and the built-in inner solver
+  double *sv0 = nullptr, *sv1 = nullptr;
+  chebhip_fgmres *inner = nullptr;
+  int in_restart = 30, in_maxit = 10000, inner_its = 0;      // KSP defaults
+  double in_rtol = 1e-5, in_atol = 1e-50;
   bool deta_nonzero = false;                                 // deta == 0 everywhere: the node loop skips S0
   int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
 };
@@ -204,6 +209,9 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
                    op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force};
   for (double *p : all) if (p) (void)hipFree(p);
+  if (op->sv0) (void)hipFree(op->sv0);
+  if (op->sv1) (void)hipFree(op->sv1);
+  if (op->inner) chebhip_fgmres_destroy(op->inner);
   for (double *p : op->w0) if (p) (void)hipFree(p);
   for (double *p : op->w1) if (p) (void)hipFree(p);
   if (op->ixL) (void)hipFree(op->ixL);
@@ -459,6 +467,41 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
   if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // :747
   ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(op->force), yG);   // :750-756
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- StokesMatMultSchur (stokes.C:523-535): y = -PV * solve(VV, VP x) ------------------------------
+__global__ void k_st_neg(long n, double *__restrict__ a) { GS_LOOP(i, n) a[i] = -1.0 * a[i]; }   // VecScale(yG,-1), :533
+
+static int st_vv_apply(void *ctx, const double *x, double *y, void *stream) { return stokes_op_mult_vv((stokes_op *)ctx, x, y, stream); }
+
+extern "C" int stokes_op_set_inner_solver(stokes_op *op, int restart, double rtol, double atol, int max_it) {
+  ARGCHK(op);
+  if (restart < 1 || restart > 256 || !(rtol >= 0.0) || !(atol >= 0.0) || max_it < 0)
+    return chebhip_fail(CHEBHIP_ERR_ARG, "restart must be in 1..256, tolerances and max_it non-negative");
+  if (op->inner && restart != op->in_restart) { chebhip_fgmres_destroy(op->inner); op->inner = nullptr; }
+  op->in_restart = restart; op->in_rtol = rtol; op->in_atol = atol; op->in_maxit = max_it;
+  return 0;
+}
+
+extern "C" int stokes_op_inner_iterations(const stokes_op *op) { return op ? op->inner_its : -1; }
+
+extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream) {
+  ARGCHK(op && pG && out);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t gv = (size_t)op->I * op->d;
+  if (!op->sv0) { int rc = st_alloc(&op->sv0, gv ? gv : 1); if (rc) return rc; if ((rc = st_alloc(&op->sv1, gv ? gv : 1))) return rc; }
+  int rc = stokes_op_mult_vp(op, pG, op->sv0, st); if (rc) return rc;                        // :530
+  if (solve) { if ((rc = solve(solve_ctx, op->sv0, op->sv1, st))) return rc; }               // KSPSolve(KSPSchurVelocity), :531
+  else {
+    if (!op->inner) { if ((rc = chebhip_fgmres_create((long)gv, op->in_restart, &op->inner))) return rc; }
+    if ((rc = chebhip_fgmres_set_tolerances(op->inner, op->in_rtol, op->in_atol, op->in_maxit))) return rc;
+    if ((rc = chebhip_fgmres_solve(op->inner, st_vv_apply, op, nullptr, nullptr, op->sv0, op->sv1, 0, st))) return rc;
+    op->inner_its = chebhip_fgmres_iterations(op->inner);
+  }
+  if ((rc = stokes_op_mult_pv(op, op->sv1, out, st))) return rc;                             // :532
+  hipLaunchKernelGGL(k_st_neg, dim3(sgrid(op->I)), dim3(256), 0, st, op->I, out);
   SHIPCHK(hipGetLastError());
   return 0;
 }

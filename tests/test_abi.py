@@ -21,6 +21,7 @@ def L():
 def _declared_functions():
     txt = open(os.path.join(sp.INCLUDE_DIR, "chebhip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"typedef[^;]*\(\s*\*[^;]*;", "", txt)          # function-pointer typedefs are not entry points
     return sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", txt)))
 
 

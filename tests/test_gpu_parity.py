@@ -240,6 +240,28 @@ def test_elliptic_nonlinear_vs_oracle(dims):
     op.destroy()
 
 
+@pytest.mark.parametrize("dims,exponent", [((130, 66), 2.0), ((20, 129, 18), 3.0), ((64, 64, 64), 2.0), ((33, 40), 2.5), ((48, 31, 16), 0.5)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else "e%g" % v)
+def test_elliptic_nonlinear_random_state(dims, exponent):
+    """FormFunction and the Jacobian apply on a positive random state, at sizes that run the KS = 16 / 32
+    kernels, odd extents (the self-mirrored mid point), integer exponents (products) and real ones (pow)."""
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED)
+    u = rng.random(op.global_size) + 0.5
+    b = rng.standard_normal(op.global_size)
+    dv = rng.random(op.dirichlet_size) + 0.5
+    op.set_dirichlet(dv)
+    rhs = op.function_host(u, b, 1.5, exponent)
+    rhs_o, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, 1.5, exponent, mode=orc.FAST)
+    assert relerr(rhs, rhs_o) < TOL
+    assert relerr(op.get_state(0), eta) < 1e-14 and relerr(op.get_state(1), deta) < 1e-14
+    U = rng.standard_normal(op.global_size)
+    V = op.mult_host(U)
+    ref = orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST)
+    assert relerr(V, ref) < TOL
+    op.destroy()
+
+
 def test_elliptic_exact_residual():
     """elliptic.C:193-209 with -exact 2: the residual of the polynomial exact solution is ~0."""
     dims = (12, 11, 10)

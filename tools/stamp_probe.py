@@ -9,7 +9,7 @@ import __graft_entry__ as ge
 sp = ge.load()
 sp.LIB_PATH = os.path.join(ROOT, "tools", "libchebhip_diag.so")
 L = sp.lib()
-P = 256
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 op = sp.EllipticOp((P, P, P))
 U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
 V = torch.empty_like(U)
@@ -22,7 +22,7 @@ for ab in (0, 3):
     torch.cuda.synchronize()
     raw = buf.cpu().numpy().reshape(256, 8, 8)
     b = raw[:, :, :4].astype(float)   # last launch (direction 2) of the last matvec
-    nsub = 16.0
+    nsub = float(os.environ.get("NSUB", "16"))
     print("ablate=%d  cycles per sub-tile per wave (mean over waves; waves 0-3 / 4-7):" % ab)
     for k, name in enumerate(("pre-chain", "chain", "post-chain", "barrier")):
         div = nsub if k < 3 else nsub / 2
