@@ -3,7 +3,8 @@
 //
 // The operator and the (right, possibly varying) preconditioner are callbacks on device pointers with the
 // signature of ell_op_mult / stokes_op_mult_vv, so those entry points can be passed directly.  All vectors
-// stay in HBM; per iteration the host sees only the new Hessenberg column (j + 2 doubles).
+// stay in HBM, the Hessenberg matrix and its Givens rotations too; per iteration the host reads one double
+// (the residual estimate, from pinned memory) and it does so one iteration late, so the device never idles.
 //   w = A M v_j;  h = V^T w (classical Gram-Schmidt, one pass -- PETSc's default orthogonalisation);
 //   w -= V h;  h_{j+1,j} = |w|;  Givens rotations and the triangular solve on the host.
 // Reductions are two-stage with a fixed block order: results do not depend on scheduling.
@@ -49,17 +50,27 @@ __global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restric
   if (threadIdx.x == 0) part[(long)blockIdx.y * RB + blockIdx.x] = r;
 }
 
-// out[kk] = sum_b part[kk][b] (fixed order); optional square root
-__global__ __launch_bounds__(RT) void k_reduce(const double *__restrict__ part, double *__restrict__ out, int take_sqrt) {
+// out[0] = sqrt(sum_b part[b]) (fixed order)
+__global__ __launch_bounds__(RT) void k_norm_finish(const double *__restrict__ part, double *__restrict__ out) {
   __shared__ double sh[RT / 64];
-  const double r = block_sum(part[(long)blockIdx.x * RB + threadIdx.x], sh);
-  if (threadIdx.x == 0) out[blockIdx.x] = take_sqrt ? sqrt(r) : r;
+  const double r = block_sum(part[threadIdx.x], sh);
+  if (threadIdx.x == 0) out[0] = sqrt(r);
 }
 
-// w -= sum_{kk<k} h[kk] V[kk];  part[b] = sum over chunk b of w^2
+// h[kk] = sum_b dpart[kk][b] (every block forms the same sums in the same order; block 0 publishes them);
+// w -= sum_{kk<k} h[kk] V[kk];  npart[b] = sum over chunk b of w^2
 __global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double *__restrict__ V, long ldv,
-                                                    const double *__restrict__ h, double *__restrict__ w, double *__restrict__ part) {
+                                                    const double *__restrict__ dpart, double *__restrict__ hcol,
+                                                    double *__restrict__ w, double *__restrict__ npart) {
   __shared__ double sh[RT / 64];
+  __shared__ double h[RT];
+  for (int kk = threadIdx.x; kk < k; kk += RT) {
+    double s = 0.0;
+    for (int q = 0; q < RB; q++) s += dpart[(long)kk * RB + q];
+    h[kk] = s;
+    if (blockIdx.x == 0) hcol[kk] = s;
+  }
+  __syncthreads();
   double s = 0.0;
   for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)RB * RT) {
     double x = w[i];
@@ -67,8 +78,57 @@ __global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double 
     w[i] = x; s += x * x;
   }
   const double r = block_sum(s, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = r;
+  if (threadIdx.x == 0) npart[blockIdx.x] = r;
 }
+
+// Column j of the Hessenberg matrix on the device: h_{j+1,j} = sqrt(sum npart), the previous Givens rotations,
+// the new one, the rotated right-hand side G_{j+1} (a fresh copy: iterations issued speculatively beyond the
+// converged one must not disturb what the solve reads), the residual estimate for the host (pinned memory)
+// and 1 / h_{j+1,j} for the normalisation of the new basis vector.
+__global__ __launch_bounds__(RT) void k_givens(int j, int m, const double *__restrict__ npart, const double *__restrict__ hcol,
+                                               double *__restrict__ H, double *__restrict__ cs, double *__restrict__ sn,
+                                               double *__restrict__ G, double *__restrict__ inv, double *__restrict__ res) {
+  __shared__ double sh[RT / 64];
+  const double ss = block_sum(npart[threadIdx.x], sh);
+  if (threadIdx.x != 0) return;
+  const double hnext = sqrt(ss);
+  double *hc = H + (long)j * (m + 1);
+  for (int i = 0; i <= j; i++) hc[i] = hcol[i];
+  hc[j + 1] = hnext;
+  for (int i = 0; i < j; i++) {
+    const double t = cs[i] * hc[i] + sn[i] * hc[i + 1];
+    hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1]; hc[i] = t;
+  }
+  const double den = hypot(hc[j], hc[j + 1]);
+  const double *g0 = G + (long)j * (m + 2);
+  double *g1 = G + (long)(j + 1) * (m + 2);
+  for (int i = 0; i < j; i++) g1[i] = g0[i];
+  if (den == 0.0 || !(den == den)) { res[j] = nan(""); inv[0] = 0.0; return; }
+  const double c = hc[j] / den, s_ = hc[j + 1] / den;
+  cs[j] = c; sn[j] = s_;
+  hc[j] = den; hc[j + 1] = 0.0;
+  g1[j] = c * g0[j]; g1[j + 1] = -s_ * g0[j];
+  res[j] = fabs(g1[j + 1]);
+  inv[0] = 1.0 / hnext;
+}
+
+// y = R^{-1} g for the leading kk columns (R upper triangular, column-major with leading dimension m + 1)
+__global__ void k_trisolve(int kk, int m, const double *__restrict__ H, const double *__restrict__ g, double *__restrict__ y) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = kk - 1; i >= 0; i--) {
+    double s = g[i];
+    for (int q = i + 1; q < kk; q++) s -= H[(long)q * (m + 1) + i] * y[q];
+    y[i] = s / H[(long)i * (m + 1) + i];
+  }
+}
+
+// w *= *a  (a on the device)
+__global__ void k_scale_dev(long n, const double *__restrict__ a, double *__restrict__ w) {
+  const double f = a[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) w[i] *= f;
+}
+
+__global__ void k_set1(double *__restrict__ p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 
 // y = a * x        (a read from the host value)
 __global__ void k_scale(long n, double a, const double *x, double *y) {   // x == y allowed
@@ -98,17 +158,20 @@ struct chebhip_fgmres {
   int m = 30;                       // restart (KSPGMRESSetRestart default 30)
   double rtol = 1e-5, atol = 1e-50; // KSP defaults
   int max_it = 10000;
-  double *V = nullptr, *Z = nullptr, *part = nullptr, *hdev = nullptr, *ydev = nullptr;
-  double *hhost = nullptr;          // pinned
+  double *V = nullptr, *Z = nullptr, *part = nullptr, *npart = nullptr, *hcol = nullptr, *ydev = nullptr;
+  double *H = nullptr, *cs = nullptr, *sn = nullptr, *G = nullptr, *inv = nullptr;
+  double *res = nullptr;            // pinned, written by the device: residual estimate after iteration j
+  std::vector<hipEvent_t> ev;
   int its = 0, reason = 0;
   double rnorm = 0.0, rnorm0 = 0.0;
 };
 
 extern "C" int chebhip_fgmres_destroy(chebhip_fgmres *k) {
   if (!k) return 0;
-  double *dev[] = {k->V, k->Z, k->part, k->hdev, k->ydev};
+  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->inv};
   for (double *p : dev) if (p) (void)hipFree(p);
-  if (k->hhost) (void)hipHostFree(k->hhost);
+  if (k->res) (void)hipHostFree(k->res);
+  for (hipEvent_t e : k->ev) (void)hipEventDestroy(e);
   delete k;
   return 0;
 }
@@ -117,21 +180,30 @@ extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) 
   if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
   *out = nullptr;
   if (n < 1) return chebhip_fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 1", n);
-  if (restart < 1 || restart > 256) return chebhip_fail(CHEBHIP_ERR_ARG, "restart = %d must be in 1..256", restart);
+  if (restart < 1 || restart > RT) return chebhip_fail(CHEBHIP_ERR_ARG, "restart = %d must be in 1..%d", restart, RT);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return chebhip_fail(CHEBHIP_ERR_DEVICE, "no usable HIP device; libchebhip has no CPU fallback");
   chebhip_fgmres *k = new (std::nothrow) chebhip_fgmres;
   if (!k) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
-  k->n = n; k->m = restart; k->ld = (n + 1) & ~1L;       // even leading dimension: every basis vector 16-B aligned
+  const int m = restart;
+  k->n = n; k->m = m; k->ld = (n + 1) & ~1L;             // even leading dimension: every basis vector 16-B aligned
 #define KC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { chebhip_fgmres_destroy(k); \
     return chebhip_fail(e_ == hipErrorOutOfMemory ? CHEBHIP_ERR_MEMORY : CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-  KC(hipMalloc((void **)&k->V, (size_t)(restart + 1) * k->ld * sizeof(double)));
-  KC(hipMalloc((void **)&k->Z, (size_t)restart * k->ld * sizeof(double)));
-  KC(hipMalloc((void **)&k->part, (size_t)(restart + 2) * RB * sizeof(double)));
-  KC(hipMalloc((void **)&k->hdev, (size_t)(restart + 2) * sizeof(double)));
-  KC(hipMalloc((void **)&k->ydev, (size_t)(restart + 2) * sizeof(double)));
-  KC(hipHostMalloc((void **)&k->hhost, (size_t)(restart + 2) * sizeof(double)));
+  KC(hipMalloc((void **)&k->V, (size_t)(m + 1) * k->ld * sizeof(double)));
+  KC(hipMalloc((void **)&k->Z, (size_t)m * k->ld * sizeof(double)));
+  KC(hipMalloc((void **)&k->part, (size_t)(m + 1) * RB * sizeof(double)));
+  KC(hipMalloc((void **)&k->npart, (size_t)RB * sizeof(double)));
+  KC(hipMalloc((void **)&k->hcol, (size_t)(m + 2) * sizeof(double)));
+  KC(hipMalloc((void **)&k->ydev, (size_t)(m + 2) * sizeof(double)));
+  KC(hipMalloc((void **)&k->H, (size_t)m * (m + 1) * sizeof(double)));
+  KC(hipMalloc((void **)&k->cs, (size_t)m * sizeof(double)));
+  KC(hipMalloc((void **)&k->sn, (size_t)m * sizeof(double)));
+  KC(hipMalloc((void **)&k->G, (size_t)(m + 1) * (m + 2) * sizeof(double)));
+  KC(hipMalloc((void **)&k->inv, sizeof(double)));
+  KC(hipHostMalloc((void **)&k->res, (size_t)(m + 2) * sizeof(double)));
+  k->ev.assign(m, nullptr);
+  for (int j = 0; j < m; j++) KC(hipEventCreateWithFlags(&k->ev[j], hipEventDisableTiming));
 #undef KC
   *out = k;
   return 0;
@@ -150,11 +222,10 @@ extern "C" int chebhip_fgmres_reason(const chebhip_fgmres *k) { return k ? k->re
 
 // |v| on the device, result to the host (synchronises the stream)
 static int dev_norm(chebhip_fgmres *k, const double *v, hipStream_t st, double *out) {
-  hipLaunchKernelGGL(k_multidot, dim3(RB, 1), dim3(RT), 0, st, k->n, v, k->ld, v, k->part);
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RT), 0, st, (const double *)k->part, k->hdev, 1);
-  KHIPCHK(hipMemcpyAsync(k->hhost, k->hdev, sizeof(double), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_multidot, dim3(RB, 1), dim3(RT), 0, st, k->n, v, k->ld, v, k->npart);
+  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->res + k->m);
   KHIPCHK(hipStreamSynchronize(st));
-  *out = k->hhost[0];
+  *out = k->res[k->m];
   return 0;
 }
 
@@ -165,7 +236,6 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
   const long n = k->n, ld = k->ld;
   const int m = k->m;
   k->its = 0; k->reason = 0;
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m);
   double bnorm = 0.0;
   int rc = dev_norm(k, b, st, &bnorm); if (rc) return rc;
   const double tol = std::fmax(k->rtol * bnorm, k->atol);
@@ -188,50 +258,43 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
     if (beta <= tol) { k->reason = beta <= k->atol ? 3 : 2; return 0; } // KSP_CONVERGED_ATOL / RTOL
     if (k->its >= k->max_it) { k->reason = -3; return 0; }              // KSP_DIVERGED_ITS
     hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / beta, (const double *)r, k->V);
-    g.assign(m + 1, 0.0); g[0] = beta;
-    int j = 0;
-    bool done = false;
-    for (; j < m && !done; j++) {
+    hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, k->G, beta);
+
+    // One cycle.  Iteration j is enqueued BEFORE the host looks at the result of iteration j - 1: the device
+    // never waits for the host.  If j - 1 turns out to have converged, iteration j was speculative; it only
+    // wrote column j of H, G_{j+1} and V[j+1], none of which the update below reads.
+    int kk = 0;            // accepted columns
+    bool stop = false;
+    auto examine = [&](int jj) {                                         // result of iteration jj (stream reached ev[jj])
+      const double rj = k->res[jj];
+      if (!(rj == rj)) { k->reason = -9; kk = jj; stop = true; return; } // breakdown: column jj is dropped
+      kk = jj + 1; k->rnorm = rj;
+      if (rj <= tol || k->its + kk >= k->max_it) stop = true;
+    };
+    int enq = 0;
+    for (int j = 0; j < m && !stop; j++) {
+      if (k->its + j >= k->max_it) break;
       const double *vj = k->V + (long)j * ld;
       const double *zj = vj;
       if (M) { double *z = k->Z + (long)j * ld; if ((rc = M(mctx, vj, z, st))) return rc; zj = z; }
       double *w = k->V + (long)(j + 1) * ld;
       if ((rc = A(actx, zj, w, st))) return rc;
       hipLaunchKernelGGL(k_multidot, dim3(RB, j + 1), dim3(RT), 0, st, n, (const double *)k->V, ld, (const double *)w, k->part);
-      hipLaunchKernelGGL(k_reduce, dim3(j + 1), dim3(RT), 0, st, (const double *)k->part, k->hdev, 0);
-      hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->hdev, w, k->part);
-      hipLaunchKernelGGL(k_reduce, dim3(1), dim3(RT), 0, st, (const double *)k->part, k->hdev + (j + 1), 1);
-      KHIPCHK(hipMemcpyAsync(k->hhost, k->hdev, (size_t)(j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
-      KHIPCHK(hipStreamSynchronize(st));
-      double *hc = &H[(size_t)j * (m + 1)];
-      for (int i = 0; i <= j + 1; i++) hc[i] = k->hhost[i];
-      const double hnext = hc[j + 1];
-      for (int i = 0; i < j; i++) {                                      // previous rotations
-        const double t = cs[i] * hc[i] + sn[i] * hc[i + 1];
-        hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1]; hc[i] = t;
-      }
-      const double den = std::hypot(hc[j], hc[j + 1]);
-      if (den == 0.0 || !(den == den)) { k->reason = -9; break; }          // column j is dropped
-      cs[j] = hc[j] / den; sn[j] = hc[j + 1] / den;
-      hc[j] = den; hc[j + 1] = 0.0;
-      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
-      k->its++;
-      k->rnorm = std::fabs(g[j + 1]);
-      if (k->rnorm <= tol || k->its >= k->max_it || hnext == 0.0) done = true;       // hnext == 0: happy breakdown
-      else hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / hnext, (const double *)w, w);
+      hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
+      hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res);
+      hipLaunchKernelGGL(k_scale_dev, dim3(pgrid(n)), dim3(256), 0, st, n, (const double *)k->inv, w);
+      KHIPCHK(hipEventRecord(k->ev[j], st));
+      enq = j + 1;
+      if (j >= 1) { KHIPCHK(hipEventSynchronize(k->ev[j - 1])); examine(j - 1); }
     }
-    // y = H^{-1} g (upper triangular, j columns), x += Z y
-    const int kk = j;
-    for (int i = kk - 1; i >= 0; i--) {
-      double s = g[i];
-      for (int q = i + 1; q < kk; q++) s -= H[(size_t)q * (m + 1) + i] * y[q];
-      y[i] = s / H[(size_t)i * (m + 1) + i];
-    }
-    for (int i = 0; i < kk; i++) k->hhost[i] = y[i];
-    KHIPCHK(hipMemcpyAsync(k->ydev, k->hhost, (size_t)(kk > 0 ? kk : 1) * sizeof(double), hipMemcpyHostToDevice, st));
-    if (kk > 0)
+    if (!stop && enq > 0) { KHIPCHK(hipEventSynchronize(k->ev[enq - 1])); examine(enq - 1); }
+    k->its += kk;
+    // y = R^{-1} g (leading kk columns, right-hand side G_kk), x += Z y
+    if (kk > 0) {
+      hipLaunchKernelGGL(k_trisolve, dim3(1), dim3(1), 0, st, kk, m, (const double *)k->H, (const double *)(k->G + (long)kk * (m + 2)), k->ydev);
       hipLaunchKernelGGL(k_multiaxpy, dim3(pgrid(n)), dim3(256), 0, st, n, kk, (const double *)(M ? k->Z : k->V), ld, (const double *)k->ydev, x);
-    KHIPCHK(hipStreamSynchronize(st));                                   // hhost is reused by the next cycle
+    }
+    KHIPCHK(hipStreamSynchronize(st));      // a speculative iteration may still be running: drain before V is reused
     if (k->reason == -9) return 0;
     if (k->rnorm <= tol) { k->reason = k->rnorm <= k->atol ? 3 : 2; return 0; }
     if (k->its >= k->max_it) { k->reason = -3; return 0; }

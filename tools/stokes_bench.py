@@ -38,4 +38,14 @@ for P, power in ((64, False), (128, True)):
     bm, bf = (680.0 if power else 600.0), 712.0
     print("stokes %d^3 %s: MatMult %.1f us (%.2f TB/s alg @%g B/node)  Function %.1f us (%.2f TB/s alg)  VV %.1f  PV %.1f  VP %.1f us" % (
         P, "power-law" if power else "linear", t_mm, bm * n / t_mm / 1e6, bm, t_fn, bf * n / t_fn / 1e6, t_vv, t_pv, t_vp))
+    if not power:
+        # config 4: one Schur apply with the built-in inner GMRES(30), bounded to 60 MatVV applies; counted per inner apply
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        op.mult_schur(p, po, restart=30, rtol=1e-5, max_it=60)
+        torch.cuda.synchronize(); e0.record()
+        op.mult_schur(p, po, restart=30, rtol=1e-5, max_it=60)
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e3
+        its = op.inner_iterations
+        print("stokes %d^3 Schur apply: %.0f us for VP + %d inner MatVV applies + PV = %.1f us per inner apply (MatVV alone %.1f us)" % (P, t, its, t / max(its, 1), t_vv))
     op.destroy()
