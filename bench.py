@@ -43,18 +43,22 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(P, threads):
-    """Oracle (port of chebyshev.c + MatMult_Elliptic pass structure) on the host: one matvec."""
+def cpu_baseline(P, threads, U, V=None):
+    """Oracle (port of chebyshev.c + MatMult_Elliptic pass structure) on the host: one matvec on the bench's
+    own input U.  With V (the GPU result for U) the oracle's output also serves as the full-size parity check."""
     import numpy as np
     import oracle_lib as orc
     dims = (P, P, P)
-    _, G, _ = orc.sizes(dims)
-    U = np.random.default_rng(SEED).standard_normal(G)
     t0 = time.perf_counter()
-    orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=threads)
+    ref = orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=threads)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "matvecs/s", "cores": threads, "kind": "port",
-            "sample": "1 full %d^3 Poisson matvec (6 ChebMult + pointwise passes), oracle FAST path, %.1f s" % (P, dt)}
+    out = {"value": 1.0 / dt, "unit": "matvecs/s", "cores": threads, "kind": "port",
+           "sample": "1 full %d^3 Poisson matvec (6 ChebMult + pointwise passes), oracle FAST path, %.1f s" % (P, dt)}
+    parity = None
+    if V is not None:
+        parity = {"rel_l2_vs_oracle": float(np.linalg.norm(V - ref) / np.linalg.norm(ref)), "tolerance": 1e-10,
+                  "input": "the timed %d^3 N(0,1) vector" % P}
+    return out, parity
 
 
 def main():
@@ -168,10 +172,13 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, args.cpu_threads)          # the faithful one: the reference is serial
+            Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
+            out["cpu_baseline"], out["parity"] = cpu_baseline(P, args.cpu_threads, Uh, Vh)   # the faithful one: the reference is serial
             ncpu = min(os.cpu_count() or 1, 16)
             if ncpu > args.cpu_threads:                                       # the generous one: OpenMP over lines
-                out["cpu_baseline_all_cores"] = cpu_baseline(P, ncpu)
+                out["cpu_baseline_all_cores"], _ = cpu_baseline(P, ncpu, Uh)
+            if out["parity"]["rel_l2_vs_oracle"] > out["parity"]["tolerance"]:
+                raise SystemExit("parity failure: GPU matvec differs from the oracle by %.3e" % out["parity"]["rel_l2_vs_oracle"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

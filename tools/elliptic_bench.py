@@ -35,4 +35,16 @@ for P in [int(a) for a in sys.argv[1:]] or [128, 256]:
     n = float(P) ** 3
     print("elliptic %d^3 gamma=4: FormFunction %.1f us (%.2f TB/s of the 160 B/pt model = %.3f)  Jacobian MatMult %.1f us (%.2f TB/s of the 208 B/pt model = %.3f)" % (
         P, t_fn, 160 * n / t_fn / 1e6, 160 * n / t_fn / 1e6 / 8.0, t_mm, 208 * n / t_mm / 1e6, 208 * n / t_mm / 1e6 / 8.0))
+    if P == 256:
+        # PCIe-inclusive rate of the host-pointer entry point (plumbing path, never the metric): linear state
+        import time, numpy as np
+        lin = sp.EllipticOp((P, P, P))
+        Uh = np.random.default_rng(1).standard_normal(lin.global_size)
+        lin.mult_host(Uh)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            lin.mult_host(Uh)
+        dt = (time.perf_counter() - t0) / 5
+        print("elliptic %d^3 linear ell_op_mult_host (H2D + matvec + D2H, pageable host memory): %.2f ms = %.0f matvec/s" % (P, dt * 1e3, 1.0 / dt))
+        lin.destroy()
     op.destroy()
