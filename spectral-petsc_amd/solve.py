@@ -1,0 +1,36 @@
+"""Newton-Krylov driver on device vectors: the roles of SNESSolve and KSPSolve(KSPFGMRES) around the elliptic
+callbacks (elliptic.C:177-185, 213), for end-to-end solves where no PETSc exists.
+
+Each Newton step evaluates FormFunction (which leaves eta, eta', grad u behind, elliptic.C:498-509), then
+solves J dx = -F with the matrix-free Jacobian MatMult_Elliptic (elliptic.C:297-339) by restarted FGMRES
+(chebhip_fgmres_*), and updates x.  Full steps, no line search; `M` is the slot for a right preconditioner
+(the reference uses ILU(2) of a finite-difference matrix, elliptic.C:184-185, which stays PETSc's).
+"""
+import torch
+
+
+def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50,
+                  ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000, M=None, monitor=None):
+    """Solve FormFunction(x) = A(x) x - b = 0 in place in x (device tensor).  Returns (newton_its, total_ksp_its, |F|)."""
+    n = op.global_size
+    F = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
+    total = 0
+    op.function(x, b, F, gamma, exponent)
+    f0 = fn = float(F.norm())
+    it = 0
+    try:
+        while it < snes_max_it and fn > max(snes_rtol * f0, snes_atol):
+            F.neg_()
+            ks.solve(op, F, dx, M=M)                    # J dx = -F, state of the last FormFunction
+            total += ks.iterations
+            x.add_(dx)
+            op.function(x, b, F, gamma, exponent)
+            fn = float(F.norm())
+            it += 1
+            if monitor:
+                monitor(it, fn, ks.iterations)
+    finally:
+        ks.destroy()
+    return it, total, fn
