@@ -269,9 +269,12 @@ __global__ void k_gather_coeff(long N, const int *__restrict__ ixL, const double
   }
 }
 
-// c_k = deta * du0_k: the coefficient of u in the linearised flux (elliptic.C:321), formed once per state
-__global__ void k_cprod(long N, const double *__restrict__ deta, const double *__restrict__ du, double *__restrict__ c) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) c[i] = deta[i] * du[i];
+// ec_k = {eta, c_k = deta * du0_k}: the two coefficients of the linearised flux eta g + c_k u (elliptic.C:321)
+// side by side, so that the Jacobian apply fetches both with one 16-byte load; formed once per state
+__global__ void k_cprod(long N, const double *__restrict__ eta, const double *__restrict__ deta, const double *__restrict__ du,
+                        double2 *__restrict__ ec) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x)
+    ec[i] = make_double2(eta[i], deta[i] * du[i]);
 }
 
 __global__ void k_fill(long N, double v, double *__restrict__ a) {
@@ -305,7 +308,7 @@ struct ell_op {
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
-  std::vector<double *> cprod;          // deta * gradu[k]: what the Jacobian apply reads (refreshed when the state changes)
+  std::vector<double *> cprod;          // pairs {eta, deta * gradu[k]} (2N doubles): what the Jacobian apply reads, refreshed when the state changes
   bool cdirty = true;
   double *eta = nullptr, *deta = nullptr, *dirloc = nullptr;
   CoeffMode mode = COEFF_UNIT;
@@ -326,7 +329,7 @@ static int ell_alloc_state(ell_op *op) {
     for (int k = 0; k < op->d; k++) {
       HIPCHK(hipMalloc((void **)&op->gradu[k], bytes));
       HIPCHK(hipMemset(op->gradu[k], 0, bytes));
-      HIPCHK(hipMalloc((void **)&op->cprod[k], bytes));
+      HIPCHK(hipMalloc((void **)&op->cprod[k], 2 * bytes));
     }
     op->cdirty = true;
   }
@@ -528,7 +531,8 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   // (elliptic.C:309-323) never leave the chip.
   if (op->cdirty) {
     for (int k = 0; k < op->d; k++)
-      hipLaunchKernelGGL(k_cprod, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->deta, (const double *)op->gradu[k], op->cprod[k]);
+      hipLaunchKernelGGL(k_cprod, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta, (const double *)op->deta,
+                         (const double *)op->gradu[k], (double2 *)op->cprod[k]);
     op->cdirty = false;
   }
   for (int k = 0; k < op->d; k++) {

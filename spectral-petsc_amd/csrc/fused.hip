@@ -21,6 +21,7 @@
 namespace chebhip {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32;
 
 template <int M> using mode_c = std::integral_constant<int, M>;
@@ -233,14 +234,17 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
       for (int r = 0; r < 4; r++) {
         cv[2 * r] = 1.0; cv[2 * r + 1] = 1.0;
         if (COEF == COEF_FULL) { cc[2 * r] = 0.0; cc[2 * r + 1] = 0.0; }
-        if (COEF != COEF_UNIT && ov[r]) {
+        if (COEF == COEF_ETA && ov[r]) {
           const int i = i0 + (JFAST ? 0 : 4 * r);
           cv[2 * r] = p.in1[ob[r] + (u32)i * inner];
           cv[2 * r + 1] = p.in1[ob[r] + (u32)(nn - i) * inner];
-          if (COEF == COEF_FULL) {
-            cc[2 * r] = p.in2[ob[r] + (u32)i * inner];
-            cc[2 * r + 1] = p.in2[ob[r] + (u32)(nn - i) * inner];
-          }
+        }
+        if (COEF == COEF_FULL && ov[r]) {                  // in2 holds the pairs {eta, c}: one 16-B load per point
+          const int i = i0 + (JFAST ? 0 : 4 * r);
+          const d2v ei = *(const d2v *)(p.in2 + 2 * (size_t)(ob[r] + (u32)i * inner));
+          const d2v em = *(const d2v *)(p.in2 + 2 * (size_t)(ob[r] + (u32)(nn - i) * inner));
+          cv[2 * r] = ei[0]; cc[2 * r] = ei[1];
+          cv[2 * r + 1] = em[0]; cc[2 * r + 1] = em[1];
         }
       }
       v4d ce, co;

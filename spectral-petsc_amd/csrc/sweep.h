@@ -44,7 +44,7 @@ struct SweepParams {
   unsigned ntiles;
   int sym;            // mirror rows are a - b (centro-symmetric matrix) instead of b - a
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
-  int coef_mode;      // fused launches only: CoefMode; eta = in1, c = deta * du0 = in2 (local layout)
+  int coef_mode;      // fused launches only: CoefMode; COEF_ETA: eta = in1; COEF_FULL: in2 = pairs {eta, c = deta * du0} (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
   int variant;        // profiling only: experimental schedule switches (CHEBHIP_VARIANT)
   int ablate;         // profiling only (see sweep_set_ablate); 0 in production
