@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <new>
 #include <string>
@@ -197,6 +198,10 @@ struct stokes_op {
   chebhip_fgmres *inner = nullptr;
   int in_restart = 30, in_maxit = 10000, inner_its = 0;      // KSP defaults
   double in_rtol = 1e-5, in_atol = 1e-50;
+  // the pressure-gradient chain (extrapolation + d scalar sweeps) is independent of the viscous chain between the
+  // gather and the final scatter: it runs on a second stream (small grids leave most CUs idle per launch)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool deta_nonzero = false;                                 // deta == 0 everywhere: the node loop skips S0
   int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
 };
@@ -212,6 +217,9 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   if (op->sv0) (void)hipFree(op->sv0);
   if (op->sv1) (void)hipFree(op->sv1);
   if (op->inner) chebhip_fgmres_destroy(op->inner);
+  if (op->aux) (void)hipStreamDestroy(op->aux);
+  if (op->ev_fork) (void)hipEventDestroy(op->ev_fork);
+  if (op->ev_join) (void)hipEventDestroy(op->ev_join);
   for (double *p : op->w0) if (p) (void)hipFree(p);
   for (double *p : op->w1) if (p) (void)hipFree(p);
   if (op->ixL) (void)hipFree(op->ixL);
@@ -281,6 +289,14 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
     OPCHK(hipMalloc((void **)&op->w1[k], (size_t)m * sizeof(double)));
     OPCHK(hipMemcpy(op->w0[k], a.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
     OPCHK(hipMemcpy(op->w1[k], b.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+  }
+  {
+    const char *e = getenv("CHEBHIP_STOKES_SERIAL");
+    if (!(e && e[0] == '1')) {
+      OPCHK(hipStreamCreateWithFlags(&op->aux, hipStreamNonBlocking));
+      OPCHK(hipEventCreateWithFlags(&op->ev_fork, hipEventDisableTiming));
+      OPCHK(hipEventCreateWithFlags(&op->ev_join, hipEventDisableTiming));
+    }
   }
   OPCHK(hipDeviceSynchronize());
 #undef OPCHK
@@ -403,6 +419,20 @@ static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   return 0;
 }
 
+// pressure chain on the second stream, between the gather (already enqueued on st) and the final scatter
+static int st_pressure_gradient_forked(stokes_op *op, hipStream_t st) {
+  if (!op->aux) return st_pressure_gradient(op, st);
+  SHIPCHK(hipEventRecord(op->ev_fork, st));
+  SHIPCHK(hipStreamWaitEvent(op->aux, op->ev_fork, 0));
+  return st_pressure_gradient(op, op->aux);
+}
+static int st_join(stokes_op *op, hipStream_t st) {
+  if (!op->aux) return 0;
+  SHIPCHK(hipEventRecord(op->ev_join, op->aux));
+  SHIPCHK(hipStreamWaitEvent(st, op->ev_join, 0));
+  return 0;
+}
+
 #define ST_OUT(...) ST_D(k_st_out, __VA_ARGS__)
 #define ARGCHK(c) do { if (!(c)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument"); } while (0)
 #define CDP(x) ((const double *)(x))
@@ -447,8 +477,9 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   // scatterGV + scatterVL (zero boundary) and scatterGP (:505-510) in one pass over xG; the same xL serves
   // MatVV (:508) and MatPV (:509), whose result is the trace written by the node loop
   st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
-  int rc = st_viscous_jacobian(op, op->p2, st); if (rc) return rc;
-  if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // MatVP (:512)
+  int rc = st_pressure_gradient_forked(op, st); if (rc) return rc;                                                               // MatVP (:512)
+  if ((rc = st_viscous_jacobian(op, op->p2, st))) return rc;
+  if ((rc = st_join(op, st))) return rc;
   ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(nullptr), yG);
   SHIPCHK(hipGetLastError());
   return 0;
@@ -460,12 +491,13 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   const int d = op->d;
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
+  { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                           // :747
   for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->strain[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :701
   ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
        op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
   op->deta_nonzero = (op->rh_kind == 1);
   int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
-  if ((rc = st_pressure_gradient(op, st))) return rc;                                                                            // :747
+  if ((rc = st_join(op, st))) return rc;
   ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(op->force), yG);   // :750-756
   SHIPCHK(hipGetLastError());
   return 0;
