@@ -78,6 +78,14 @@ int cheb_plan_create_trimmed(int rank, int tr, const int *dims, cheb_plan **out)
  * MatMult_Elliptic (elliptic.C:309-334 with eta = 1, deta = 0).  acc may be NULL, or alias y. */
 int cheb_apply_lap1d(cheb_plan *plan, const double *x_dev, const double *acc_dev, double alpha,
                      double *y_dev, void *stream);
+/* Copies between a slab (m0, M1, R) row-major and the buffer an all-to-all moves: for every peer s the
+ * block slab[:, c1[s]:c1[s+1], :] contiguously, blocks in rank order (c1: G+1 host values, 0 .. M1).
+ * pack: buf <- slab (before the forward transpose).  unpack_add: out = acc + slab-ordered(buf)
+ * (after the backward transpose; acc may be NULL or alias out). */
+int cheb_slab_pack(long m0, long M1, long R, int G, const long *c1_host, const double *slab_dev,
+                   double *buf_dev, void *stream);
+int cheb_slab_unpack_add(long m0, long M1, long R, int G, const long *c1_host, const double *buf_dev,
+                         const double *acc_dev, double *out_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Operator level: the scalar elliptic MatShell (elliptic.C:78-86,250-293).   */

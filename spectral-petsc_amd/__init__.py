@@ -29,7 +29,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 ABI_SYMBOLS = [
     "chebhip_last_error", "chebhip_version", "chebhip_arch", "chebhip_launch_count",
     "cheb_plan_create", "cheb_apply", "cheb_apply_host", "cheb_plan_destroy", "cheb_plan_size",
-    "cheb_plan_create_trimmed", "cheb_apply_lap1d",
+    "cheb_plan_create_trimmed", "cheb_apply_lap1d", "cheb_slab_pack", "cheb_slab_unpack_add",
     "ell_op_create", "ell_op_destroy", "ell_op_local_size", "ell_op_global_size",
     "ell_op_dirichlet_size", "ell_op_mult", "ell_op_mult_host", "ell_op_function",
     "ell_op_function_host", "ell_op_set_dirichlet", "ell_op_get_state", "ell_op_set_state",
@@ -75,6 +75,9 @@ def lib():
         L.cheb_apply.argtypes = [vp, vp, vp, vp]
         L.cheb_plan_create_trimmed.argtypes = [C.c_int, C.c_int, ip, C.POINTER(vp)]
         L.cheb_apply_lap1d.argtypes = [vp, vp, vp, C.c_double, vp, vp]
+        lp = C.POINTER(C.c_long)
+        L.cheb_slab_pack.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, lp, vp, vp, vp]
+        L.cheb_slab_unpack_add.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, lp, vp, vp, vp, vp]
         L.cheb_apply_host.argtypes = [vp, dp, dp]
         L.cheb_plan_destroy.argtypes = [vp]
         L.cheb_plan_size.argtypes = [vp]
@@ -207,6 +210,23 @@ class Lap1dPlan:
             self.destroy()
         except Exception:
             pass
+
+
+def slab_pack(slab, buf, m0, M1, R, c1):
+    """buf <- slab (m0, M1, R) reordered into per-peer column blocks (cheb_slab_pack)."""
+    n = int(m0) * int(M1) * int(R)
+    cs = (C.c_long * len(c1))(*[int(v) for v in c1])
+    _chk(lib().cheb_slab_pack(m0, M1, R, len(c1) - 1, cs, _dev_ptr(slab, n), _dev_ptr(buf, n), _stream()))
+    return buf
+
+
+def slab_unpack_add(buf, acc, out, m0, M1, R, c1):
+    """out = acc + slab-ordered(buf) (cheb_slab_unpack_add); acc may be None."""
+    n = int(m0) * int(M1) * int(R)
+    cs = (C.c_long * len(c1))(*[int(v) for v in c1])
+    ap = _dev_ptr(acc, n) if acc is not None else None
+    _chk(lib().cheb_slab_unpack_add(m0, M1, R, len(c1) - 1, cs, _dev_ptr(buf, n), ap, _dev_ptr(out, n), _stream()))
+    return out
 
 
 class EllipticOp:

@@ -236,6 +236,73 @@ extern "C" int cheb_plan_destroy(cheb_plan *p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// slab <-> exchange-buffer copies of the multi-GPU path (no counterpart in the serial reference)
+// ---------------------------------------------------------------------------------------------
+// A slab is (m0, M1, R) row-major.  The exchange buffer holds, for every peer s, the block
+// slab[:, c1[s]:c1[s+1], :] contiguously (blocks in rank order): what all_to_all_single sends in the forward
+// transpose and what it delivers in the backward one.
+struct SlabSplit { int G; long c1[65]; };
+
+__device__ __forceinline__ long slab_buf_index(const SlabSplit &sp, long m0, long M1, long R, long e) {
+  const long i0 = e / (M1 * R), rem = e - i0 * (M1 * R);
+  const long j = rem / R, r = rem - j * R;
+  int s = 0;
+  while (s + 1 < sp.G && j >= sp.c1[s + 1]) s++;
+  const long w = sp.c1[s + 1] - sp.c1[s];
+  return m0 * sp.c1[s] * R + (i0 * w + (j - sp.c1[s])) * R + r;
+}
+
+__global__ void k_slab_pack(SlabSplit sp, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf) {
+  const long n = m0 * M1 * R;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    buf[slab_buf_index(sp, m0, M1, R, e)] = slab[e];
+}
+
+// out = acc + buf (buf in exchange order)
+__global__ void k_slab_unpack_add(SlabSplit sp, long m0, long M1, long R, const double *__restrict__ buf,
+                                  const double *__restrict__ acc, double *__restrict__ out) {
+  const long n = m0 * M1 * R;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const double t = buf[slab_buf_index(sp, m0, M1, R, e)];
+    out[e] = acc ? acc[e] + t : t;
+  }
+}
+
+static int slab_split(int G, const long *c1, long M1, SlabSplit *sp) {
+  if (G < 1 || G > 64 || !c1) return fail(CHEBHIP_ERR_ARG, "G = %d must be in 1..64", G);
+  sp->G = G;
+  for (int s = 0; s <= G; s++) {
+    sp->c1[s] = c1[s];
+    if (c1[s] < 0 || c1[s] > M1 || (s > 0 && c1[s] < c1[s - 1])) return fail(CHEBHIP_ERR_ARG, "column splits must be non-decreasing in 0..M1");
+  }
+  if (c1[0] != 0 || c1[G] != M1) return fail(CHEBHIP_ERR_ARG, "column splits must cover 0..M1");
+  return 0;
+}
+
+extern "C" int cheb_slab_pack(long m0, long M1, long R, int G, const long *c1, const double *slab, double *buf, void *stream) {
+  if (!slab || !buf || m0 < 0 || M1 < 0 || R < 1) return fail(CHEBHIP_ERR_ARG, "bad argument");
+  SlabSplit sp; int rc = slab_split(G, c1, M1, &sp); if (rc) return rc;
+  const long n = m0 * M1 * R;
+  if (n == 0) return 0;
+  long g = (n + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_slab_pack, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, sp, m0, M1, R, slab, buf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int cheb_slab_unpack_add(long m0, long M1, long R, int G, const long *c1, const double *buf, const double *acc,
+                                    double *out, void *stream) {
+  if (!buf || !out || m0 < 0 || M1 < 0 || R < 1) return fail(CHEBHIP_ERR_ARG, "bad argument");
+  SlabSplit sp; int rc = slab_split(G, c1, M1, &sp); if (rc) return rc;
+  const long n = m0 * M1 * R;
+  if (n == 0) return 0;
+  long g = (n + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_slab_unpack_add, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, sp, m0, M1, R, buf, acc, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // pointwise kernels of the elliptic callbacks
 // ---------------------------------------------------------------------------------------------
 // w0 = VecScatter(GL)(U) then VecScatter(DL)(dirichlet): elliptic.C:486-493.

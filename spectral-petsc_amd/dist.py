@@ -52,6 +52,12 @@ class HipBackend:
     def side_stream(self):
         return torch.cuda.Stream()
 
+    def pack(self, slab, buf, m0, M1, R, c1):
+        return self.sp.slab_pack(slab, buf, m0, M1, R, c1)
+
+    def unpack_add(self, buf, acc, out, m0, M1, R, c1):
+        return self.sp.slab_unpack_add(buf, acc, out, m0, M1, R, c1)
+
 
 class DistPoissonOp:
     def __init__(self, dims, backend, group=None):
@@ -76,20 +82,15 @@ class DistPoissonOp:
         self.pencil_size = int(np.prod(self.pencil_shape))
         dev = backend.device
         # forward exchange: slab -> send buffer ordered by destination rank s = block U[:, s1[s]:s1[s+1], :]
-        idx = np.arange(self.local_size, dtype=np.int64).reshape(self.m0[r], M[1], self.R)
-        perm = np.concatenate([idx[:, self.s1[s]:self.s1[s + 1], :].ravel() for s in range(G)])
-        self.fwd_perm = torch.from_numpy(perm).to(dev)
+        # (backend.pack / backend.unpack_add: one pass each, no index tables)
+        self.c1 = [int(v) for v in self.s1]
         self.fwd_send = [self.m0[r] * self.m1[s] * self.R for s in range(G)]
         self.fwd_recv = [self.m0[s] * self.m1[r] * self.R for s in range(G)]   # lands as the pencil, no unpack
-        # backward exchange: pencil rows s0[s]:s0[s+1] are contiguous -> no pack; unpack by the inverse map
-        inv = np.empty(self.local_size, dtype=np.int64)
-        inv[perm] = np.arange(self.local_size, dtype=np.int64)
-        self.bwd_unperm = torch.from_numpy(inv).to(dev)
+        # backward exchange: pencil rows s0[s]:s0[s+1] are contiguous -> no pack; unpack fused with the final sum
         self.W = torch.empty(self.local_size, dtype=torch.float64, device=dev)
         self.sendbuf = torch.empty(self.local_size, dtype=torch.float64, device=dev)
         self.UT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
         self.TT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
-        self.T = torch.empty(self.local_size, dtype=torch.float64, device=dev)
         self.comm_stream = backend.side_stream() if G > 1 else None
 
     # ---- helpers -------------------------------------------------------------------------------
@@ -120,10 +121,10 @@ class DistPoissonOp:
             cur = torch.cuda.current_stream()
             cs.wait_stream(cur)
             with torch.cuda.stream(cs):
-                torch.index_select(U, 0, self.fwd_perm, out=self.sendbuf)
+                be.pack(U, self.sendbuf, self.m0[self.rank], M[1], self.R, self.c1)
                 self._a2a(self.UT, self.sendbuf, self.fwd_recv, self.fwd_send)
         else:
-            torch.index_select(U, 0, self.fwd_perm, out=self.sendbuf)
+            be.pack(U, self.sendbuf, self.m0[self.rank], M[1], self.R, self.c1)
             self._a2a(self.UT, self.sendbuf, self.fwd_recv, self.fwd_send)
         # local directions 1..d-1 on the slab (overlap the forward exchange)
         be.lap1d(U, self.slab_shape, 1, self.W, None, -1.0)
@@ -138,6 +139,5 @@ class DistPoissonOp:
             be.lap1d(U, self.slab_shape, k, self.W, self.W, -1.0)
         if cs is not None:
             torch.cuda.current_stream().wait_stream(cs)
-        torch.index_select(self.sendbuf, 0, self.bwd_unperm, out=self.T)
-        torch.add(self.W, self.T, out=V)
+        be.unpack_add(self.sendbuf, self.W, V, self.m0[self.rank], M[1], self.R, self.c1)   # V = W + T
         return V

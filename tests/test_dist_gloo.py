@@ -37,6 +37,23 @@ class OracleBackend:
     def side_stream(self):
         return None
 
+    def pack(self, slab, buf, m0, M1, R, c1):
+        a = slab.numpy().reshape(m0, M1, R)
+        buf.copy_(torch.from_numpy(np.concatenate([a[:, c1[s]:c1[s + 1], :].ravel() for s in range(len(c1) - 1)])))
+        return buf
+
+    def unpack_add(self, buf, acc, out, m0, M1, R, c1):
+        b = buf.numpy()
+        t = np.empty((m0, M1, R))
+        off = 0
+        for s in range(len(c1) - 1):
+            w = c1[s + 1] - c1[s]
+            t[:, c1[s]:c1[s + 1], :] = b[off:off + m0 * w * R].reshape(m0, w, R)
+            off += m0 * w * R
+        res = t.reshape(-1) + (acc.numpy() if acc is not None else 0.0)
+        out.copy_(torch.from_numpy(np.ascontiguousarray(res)))
+        return out
+
 
 def _free_port():
     s = socket.socket()

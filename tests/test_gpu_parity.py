@@ -324,6 +324,24 @@ def test_lap1d_vs_oracle(shape, axis):
     plan.destroy()
 
 
+@pytest.mark.parametrize("geom", [(5, 14, 6, (0, 5, 10, 14)), (32, 254, 254, tuple(int(v) for v in np.cumsum([0] + [32] * 6 + [31] * 2))),
+                                  (3, 7, 1, (0, 0, 7)), (4, 9, 3, (0, 9))], ids=lambda g: "%dx%dx%d-G%d" % (g[0], g[1], g[2], len(g[3]) - 1))
+def test_slab_pack_unpack(geom):
+    """cheb_slab_pack / cheb_slab_unpack_add against slicing (the exchange-buffer layout of dist.py)."""
+    m0, M1, R, c1 = geom
+    rng = np.random.default_rng(SEED)
+    a = rng.standard_normal((m0, M1, R)); acc = rng.standard_normal(m0 * M1 * R)
+    ref = np.concatenate([a[:, c1[s]:c1[s + 1], :].ravel() for s in range(len(c1) - 1)])
+    ad = torch.from_numpy(a.reshape(-1)).cuda(); buf = torch.full_like(ad, float("nan"))
+    sp.slab_pack(ad, buf, m0, M1, R, c1)
+    assert np.array_equal(buf.cpu().numpy(), ref)
+    out = torch.full_like(ad, float("nan"))
+    sp.slab_unpack_add(buf, torch.from_numpy(acc).cuda(), out, m0, M1, R, c1)
+    assert np.array_equal(out.cpu().numpy(), acc + a.reshape(-1))
+    sp.slab_unpack_add(buf, None, out, m0, M1, R, c1)
+    assert np.array_equal(out.cpu().numpy(), a.reshape(-1))
+
+
 @pytest.mark.parametrize("dims", [(20, 18, 16), (34, 33), (64, 64, 64)])
 def test_dist_driver_single_rank(dims):
     """DistPoissonOp with G = 1 (no process group) goes through pack / pencil / unpack and must equal
