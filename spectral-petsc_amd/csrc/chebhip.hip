@@ -61,36 +61,6 @@ static int require_device() {
 
 // ---------------------------------------------------------------------------------------------
 // kernel-level plan (MatCreateCheb / ChebMult / ChebDestroy, chebyshev.c:89-235)
-// ---------------------------------------------------------------------------------------------
-// Lines longer than 256 points do not fit the register-resident MFMA kernels.  cheb_apply still serves
-// them (the reference accepts any extent) with a plain dense product on the FP64 VALU: 4 lines per
-// workgroup staged in LDS, D^T streamed from L2 (coalesced over the output index).  Correctness path,
-// not a tuned one.
-__global__ __launch_bounds__(256) void k_dense_long(int P, unsigned ncols, unsigned inner, const double *__restrict__ DT,
-                                                    const double *__restrict__ x, double *__restrict__ y) {
-  extern __shared__ double xs[];                 // [4][P]
-  for (unsigned c0 = blockIdx.x * 4; c0 < ncols; c0 += gridDim.x * 4) {
-    for (int t = threadIdx.x; t < 4 * P; t += 256) {
-      const unsigned c = c0 + t / P; const int j = t % P;
-      xs[t] = c < ncols ? x[(long)(c / inner) * P * inner + (c % inner) + (long)j * inner] : 0.0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < P; i += 256) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      for (int j = 0; j < P; j++) {
-        const double d = DT[(long)j * P + i];
-        a0 += d * xs[j]; a1 += d * xs[P + j]; a2 += d * xs[2 * P + j]; a3 += d * xs[3 * P + j];
-      }
-      const double a[4] = {a0, a1, a2, a3};
-      for (int l = 0; l < 4; l++) {
-        const unsigned c = c0 + l;
-        if (c < ncols) y[(long)(c / inner) * P * inner + (c % inner) + (long)i * inner] = a[l];
-      }
-    }
-    __syncthreads();
-  }
-}
-
 struct cheb_plan {
   int rank = 0, tr = 0;
   std::vector<int> dims;
@@ -98,7 +68,6 @@ struct cheb_plan {
   unsigned inner = 1, ncols = 0;
   DiffMat mat;
   DiffMat lap;                          // trimmed plans: interior D D
-  double *longDT = nullptr;             // lines > 256 points: dense D^T (row-major, [j][i]) for k_dense_long
   bool trimmed = false;                 // created by cheb_plan_create_trimmed
   double *hx = nullptr, *hy = nullptr;  // staging for the host-pointer path
 };
@@ -115,7 +84,7 @@ static int check_geom(int rank, int tr, const int *dims, long *N, unsigned *inne
   }
   if (n < 2 || dims[tr] < 2) return fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 2", n);       // chebyshev.c:18,98
   if (dims[tr] > 256 && !allow_long)
-    return fail(CHEBHIP_ERR_ARG, "dims[tr] = %d: this build keeps the differentiation matrix in registers and supports <= 256 points per line", dims[tr]);
+    return fail(CHEBHIP_ERR_ARG, "dims[tr] = %d: the interior-layout (slab) plans support <= 256 points per line", dims[tr]);
   if (dims[tr] > 4096) return fail(CHEBHIP_ERR_ARG, "dims[tr] = %d: at most 4096 points per line", dims[tr]);
   *N = n; *inner = (unsigned)in;
   return 0;
@@ -133,16 +102,8 @@ extern "C" int cheb_plan_create(int rank, int tr, const int *dims, cheb_plan **o
   p->rank = rank; p->tr = tr; p->dims.assign(dims, dims + rank);
   p->N = N; p->inner = inner; p->ncols = (unsigned)(N / dims[tr]);
   hipError_t e = hipSuccess;
-  if (dims[tr] <= 256) e = diffmat_create(dims[tr], &p->mat);
-  else {
-    const int P = dims[tr];
-    std::vector<double> D((size_t)P * P), DT((size_t)P * P);
-    diffmat_dense_host(P, D.data());
-    for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) DT[(size_t)j * P + i] = D[(size_t)i * P + j];
-    e = hipMalloc((void **)&p->longDT, DT.size() * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpy(p->longDT, DT.data(), DT.size() * sizeof(double), hipMemcpyHostToDevice);
-  }
-  if (e != hipSuccess) { if (p->longDT) (void)hipFree(p->longDT); delete p; return fail(CHEBHIP_ERR_DEVICE, "plan matrices: %s", hipGetErrorString(e)); }
+  e = diffmat_create(dims[tr], &p->mat);          // > 256 points: dense matrix for cheb_sweep_long_kernel
+  if (e != hipSuccess) { delete p; return fail(CHEBHIP_ERR_DEVICE, "plan matrices: %s", hipGetErrorString(e)); }
   *out = p;
   return 0;
 }
@@ -197,14 +158,6 @@ extern "C" int cheb_apply(cheb_plan *p, const double *x, double *y, void *stream
   if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct (as every ChebMult call site)");
   if (p->trimmed) return fail(CHEBHIP_ERR_ARG, "plan is trimmed: use cheb_apply_lap1d");
-  if (p->longDT) {
-    const int P = p->dims[p->tr];
-    unsigned grid = (p->ncols + 3) / 4; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_dense_long, dim3(grid), dim3(256), (size_t)4 * P * sizeof(double), (hipStream_t)stream, P, p->ncols, p->inner,
-                       (const double *)p->longDT, x, y);
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
   SweepParams sp = {};
   sp.ncols = p->ncols; sp.inner = p->inner;
   sp.in0 = x; sp.out = y; sp.alpha = 1.0;
@@ -228,7 +181,6 @@ extern "C" int cheb_plan_destroy(cheb_plan *p) {
   if (!p) return 0;
   diffmat_destroy(&p->mat);
   diffmat_destroy(&p->lap);
-  if (p->longDT) (void)hipFree(p->longDT);
   if (p->hx) (void)hipFree(p->hx);
   if (p->hy) (void)hipFree(p->hy);
   delete p;
@@ -375,6 +327,7 @@ struct ell_op {
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
+  bool has_long = false;                // some extent > 256: every sweep goes through the unfused path (cheb_sweep_long_kernel)
   std::vector<double *> cprod;          // pairs {eta, deta * gradu[k]} (2N doubles): what the Jacobian apply reads, refreshed when the state changes
   bool cdirty = true;
   double *eta = nullptr, *deta = nullptr, *dirloc = nullptr;
@@ -410,7 +363,7 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
   long N = 1, G = 1;
   for (int k = 0; k < d; k++) {
     long nk; unsigned ik;
-    int rc = check_geom(d, k, dims, &nk, &ik);
+    int rc = check_geom(d, k, dims, &nk, &ik, true);
     if (rc) return rc;
     N *= dims[k]; G *= (dims[k] > 2 ? dims[k] - 2 : 0);
   }
@@ -425,7 +378,8 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
   for (int k = 0; k < d; k++)
     if (!op->mats.count(dims[k])) {
       DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m;
-      if (dims[k] > 2) { DiffMat l; OPCHK(diffmat_create_lap(dims[k], &l)); op->laps[dims[k]] = l; }
+      if (dims[k] > 256) op->has_long = true;
+      else if (dims[k] > 2) { DiffMat l; OPCHK(diffmat_create_lap(dims[k], &l)); op->laps[dims[k]] = l; }
     }
   // SetupBC (elliptic.C:372-434): ixL in BlockIt order; interior strides of the global vector
   std::vector<long> gs(d, 1);
@@ -569,7 +523,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (use_unfused()) return ell_mult_unfused(op, U, V, st);
+  if (use_unfused() || op->has_long) return ell_mult_unfused(op, U, V, st);
   if (op->mode == COEFF_UNIT) {
     // Linear state (eta == 1, deta == 0; homogeneous Dirichlet rows, elliptic.C:305-308): every
     // array of the apply lives in the interior layout of the global vectors, so there is no
@@ -627,7 +581,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
   // eta stays exactly 1 and deta exactly 0 only when gamma == 0 and no pow() can produce inf/nan
   const bool unit = (gamma == 0.0) && (exponent == std::floor(exponent)) && exponent >= 1.0;
   op->mode = unit ? COEFF_UNIT : COEFF_FULL;
-  if (use_unfused()) {
+  if (use_unfused() || op->has_long) {
     for (int k = 0; k < d; k++) {                                               // gradu[k] = D_k w0 (:497-499)
       SweepParams sp = {};
       sp.ncols = op->ncols[k]; sp.inner = op->inner[k];

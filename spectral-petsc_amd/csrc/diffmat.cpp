@@ -46,7 +46,27 @@ void diffmat_dense_host(int P, double *D) {
     for (int j = 0; j < P; j++) D[(size_t)i * P + j] = (double)dentry(i, j, n);
 }
 
+// P > 256: the matrix does not fit the register file of a workgroup; cheb_sweep_long_kernel streams the dense
+// transpose from L2 instead (a correctness path for any extent the reference accepts, not a tuned one).
+static hipError_t diffmat_create_long(int P, DiffMat *out) {
+  std::vector<double> DT((size_t)P * P);
+  const int n = P - 1;
+  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) DT[(size_t)j * P + i] = (double)dentry(i, j, n);
+  DiffMat m;
+  m.P = P; m.H = (P + 1) / 2; m.KS = 0; m.MTP = 0;
+  hipError_t e = hipMalloc((void **)&m.fragE, (8 + 1024) * sizeof(double));
+  if (e != hipSuccess) return e;
+  m.zero = m.fragE; m.sink = m.zero + 8;
+  e = hipMemset(m.zero, 0, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&m.longDT, DT.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(m.longDT, DT.data(), DT.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(m.fragE); if (m.longDT) (void)hipFree(m.longDT); return e; }
+  *out = m;
+  return hipSuccess;
+}
+
 hipError_t diffmat_create(int P, DiffMat *out) {
+  if (P > 256) return diffmat_create_long(P, out);
   const int n = P - 1;
   const int H = (P + 1) / 2;
   int KS = 4;
@@ -141,7 +161,8 @@ hipError_t diffmat_create_lap(int P, DiffMat *out) {
 void diffmat_destroy(DiffMat *m) {
   if (m->fragE) (void)hipFree(m->fragE);
   if (m->fragO) (void)hipFree(m->fragO);
-  m->fragE = m->fragO = nullptr;
+  if (m->longDT) (void)hipFree(m->longDT);
+  m->fragE = m->fragO = m->longDT = nullptr;
 }
 
 }  // namespace chebhip

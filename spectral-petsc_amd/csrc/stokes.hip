@@ -234,7 +234,7 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
   long N = 1, I = 1;
   for (int k = 0; k < d; k++) {
     if (dims[k] < 3) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d but must be >= 3", k, dims[k]);
-    if (dims[k] > 256) return chebhip_fail(CHEBHIP_ERR_ARG, "dims[%d] = %d: at most 256 points per line in this build", k, dims[k]);
+    if (dims[k] > 4096) return chebhip_fail(CHEBHIP_ERR_ARG, "dims[%d] = %d: at most 4096 points per line", k, dims[k]);
     N *= dims[k]; I *= dims[k] - 2;
     if (N * d > 0x7fffffffL) return chebhip_fail(CHEBHIP_ERR_DIMS, "tensor of more than 2^31-1 values");
   }

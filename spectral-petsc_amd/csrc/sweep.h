@@ -39,6 +39,7 @@ struct SweepParams {
   double alpha;
   int in_mode, out_mode;
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
+  const double *longDT;         // lines of more than 256 points: dense D^T ([j][i], P x P) instead of fragments
   const double *zero;           // a few zero doubles in HBM: the source of every masked-off load
   double *sink;                 // 512 x 16 B in HBM: where masked-off stores of the straight-line kernel go
   unsigned ntiles;
@@ -53,9 +54,10 @@ struct SweepParams {
 // Host description of the even/odd split differentiation matrices for P points.
 struct DiffMat {
   int P = 0, H = 0;
-  int KS = 0;          // k-steps of 4 (power of two >= 4 for the register-resident kernel)
+  int KS = 0;          // k-steps of 4 (power of two >= 4 for the register-resident kernel); 0 = long lines (longDT)
   int MTP = 0;         // padded m-tiles of 16 rows = KS/4
   double *fragE = nullptr, *fragO = nullptr;  // device, [MTP][KS][64]
+  double *longDT = nullptr;                   // device, dense D^T for P > 256 (then fragE holds only zero/sink)
   double *zero = nullptr;                     // device, 8 zero doubles (tail of the fragE allocation)
   double *sink = nullptr;                     // device, 1024 doubles after `zero`: target of masked-off stores
   int sym = 0;                                // 0: centro-antisymmetric (D), 1: centro-symmetric (interior D D)

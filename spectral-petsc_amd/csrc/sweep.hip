@@ -337,8 +337,76 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
 const double *chebhip_stamp_buf();
 namespace chebhip {
 
+// ---------------------------------------------------------------------------------------------
+// Lines of more than 256 points (the reference accepts any extent, chebyshev.c:98).  The matrix no longer
+// fits the registers of a workgroup, so this kernel is a plain dense product on the FP64 VALU: LN lines per
+// workgroup staged in LDS, D^T streamed from L2 (coalesced over the output index), the same load and store
+// modes as cheb_sweep_kernel.  A correctness path, not a tuned one.
+template <int LN>
+__global__ __launch_bounds__(256) void cheb_sweep_long_kernel(const SweepParams p) {
+  extern __shared__ double xs[];                 // [LN][P]
+  const int P = p.P;
+  const u32 inner = p.inner, ncols = p.ncols;
+  const bool need_g = (p.in_mode == IN_GATHER) || (p.out_mode == OUT_ACC_SCATTER);
+  for (u32 c0 = blockIdx.x * LN; c0 < ncols; c0 += gridDim.x * LN) {
+    for (int t = threadIdx.x; t < LN * P; t += 256) {
+      const u32 c = c0 + t / P; const int j = t % P;
+      const bool ok = c < ncols;
+      const u32 cc = ok ? c : 0u;
+      const u32 a = (cc / inner) * (u32)P * inner + (cc % inner) + (u32)j * inner;
+      const int gb = need_g ? p.gcol[cc] : -1;
+      double v;
+      switch (p.in_mode) {
+        case IN_PLAIN: v = fetch_in<IN_PLAIN>(p, a, j, gb, ok); break;
+        case IN_GATHER: v = fetch_in<IN_GATHER>(p, a, j, gb, ok); break;
+        case IN_FLUX_ETA: v = fetch_in<IN_FLUX_ETA>(p, a, j, gb, ok); break;
+        default: v = fetch_in<IN_FLUX_FULL>(p, a, j, gb, ok); break;
+      }
+      xs[t] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += 256) {
+      double acc[LN];
+#pragma unroll
+      for (int l = 0; l < LN; l++) acc[l] = 0.0;
+      for (int j = 0; j < P; j++) {
+        const double d = p.longDT[(long)j * P + i];
+#pragma unroll
+        for (int l = 0; l < LN; l++) acc[l] += d * xs[l * P + j];
+      }
+#pragma unroll
+      for (int l = 0; l < LN; l++) {
+        const u32 c = c0 + l;
+        if (c >= ncols) continue;
+        const u32 a = (c / inner) * (u32)P * inner + (c % inner) + (u32)i * inner;
+        const double r = p.alpha * acc[l];
+        if (p.out_mode == OUT_STORE) p.out[a] = r;
+        else if (p.out_mode == OUT_ACC) p.out[a] = p.acc[a] + r;
+        else {
+          const int gb = p.gcol[c];
+          if (gb >= 0 && i >= 1 && i <= P - 2) p.out[(long)gb + (long)(i - 1) * p.gstride] = (p.acc ? p.acc[a] : 0.0) + r;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
+  const int LN = p.P <= 2048 ? 4 : 2;            // LN * P * 8 B of LDS, at most 64 KiB
+  unsigned grid = (p.ncols + LN - 1) / LN; if (grid > 2048) grid = 2048;
+  if (grid == 0) return hipSuccess;
+  const size_t lds = (size_t)LN * p.P * sizeof(double);
+  if (LN == 4) hipLaunchKernelGGL((cheb_sweep_long_kernel<4>), dim3(grid), dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((cheb_sweep_long_kernel<2>), dim3(grid), dim3(256), lds, stream, p);
+  sweep_note_launch();
+  return hipGetLastError();
+}
+
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate;
+  p.longDT = m.longDT;
+  if (m.KS == 0) return m.longDT ? launch_long(p, stream) : hipErrorInvalidValue;
   {
     static int novec = -1;
     if (novec < 0) { const char *e = getenv("CHEBHIP_NOVEC"); novec = (e && e[0] == '1') ? 1 : 0; }

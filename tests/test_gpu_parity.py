@@ -198,7 +198,8 @@ def test_elliptic_golden(ell_golden):
         op.destroy()
 
 
-@pytest.mark.parametrize("dims", [(32, 32), (5, 4), (3, 3), (40,), (64, 64, 64), (20, 18, 16), (6, 5, 4, 3), (33, 70, 9)],
+@pytest.mark.parametrize("dims", [(32, 32), (5, 4), (3, 3), (40,), (64, 64, 64), (20, 18, 16), (6, 5, 4, 3), (33, 70, 9),
+                                  (12, 12, 12, 12, 12), (300, 20), (12, 260, 6), (514,)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_elliptic_mult_vs_oracle(dims):
     """MatMult_Elliptic, linear Poisson state (config 1 is -dim 32,32)."""
@@ -240,7 +241,8 @@ def test_elliptic_nonlinear_vs_oracle(dims):
     op.destroy()
 
 
-@pytest.mark.parametrize("dims,exponent", [((130, 66), 2.0), ((20, 129, 18), 3.0), ((64, 64, 64), 2.0), ((33, 40), 2.5), ((48, 31, 16), 0.5)],
+@pytest.mark.parametrize("dims,exponent", [((130, 66), 2.0), ((20, 129, 18), 3.0), ((64, 64, 64), 2.0), ((33, 40), 2.5), ((48, 31, 16), 0.5),
+                                           ((264, 24), 2.0)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else "e%g" % v)
 def test_elliptic_nonlinear_random_state(dims, exponent):
     """FormFunction and the Jacobian apply on a positive random state, at sizes that run the KS = 16 / 32

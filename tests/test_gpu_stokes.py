@@ -60,7 +60,7 @@ def test_stokes_golden(g, dims):
     op.destroy()
 
 
-@pytest.mark.parametrize("dims", [(20, 17), (33, 18), (12, 11, 10), (24, 20, 18), (64, 64, 64)],
+@pytest.mark.parametrize("dims", [(20, 17), (33, 18), (12, 11, 10), (24, 20, 18), (64, 64, 64), (260, 9), (8, 258, 7)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_stokes_mult_vs_oracle(dims):
     """StokesMatMult and its three blocks, linear state (BASELINE config 4 is -dim 64,64,64)."""
@@ -78,7 +78,7 @@ def test_stokes_mult_vs_oracle(dims):
     op.destroy()
 
 
-@pytest.mark.parametrize("dims", [(18, 16), (14, 12, 10), (32, 32, 32)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dims", [(18, 16), (14, 12, 10), (32, 32, 32), (10, 270)], ids=lambda s: "x".join(map(str, s)))
 def test_stokes_function_power_law_vs_oracle(dims):
     """StokesFunction with -rheology 1 -exponent 3 -eps 1e-4 (config 5 parameters) and the Newton-linearised
     StokesMatMult that follows it."""
