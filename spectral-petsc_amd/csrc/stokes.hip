@@ -87,6 +87,24 @@ __global__ __launch_bounds__(256) void k_st_preduce(double *__restrict__ pres, l
   }
 }
 
+// The same for lines that are contiguous in memory (the last grid dimension): one wave per line, lanes along
+// the line (coalesced), the 64 partial sums combined by a fixed shuffle tree -- deterministic.
+__global__ __launch_bounds__(256) void k_st_preduce_contig(double *__restrict__ pres, long na, long a0, long sa, long nb, long b0,
+                                                           long sb, int len, const double *__restrict__ w0,
+                                                           const double *__restrict__ w1) {
+  const int lane = threadIdx.x & 63;
+  const long nlines = na * nb;
+  const int m = len - 2;
+  for (long t = blockIdx.x * 4L + (threadIdx.x >> 6); t < nlines; t += (long)gridDim.x * 4) {
+    const long a = t / nb, b = t - a * nb;
+    double *line = pres + (a + a0) * sa + (b + b0) * sb;
+    double f0 = 0.0, f1 = 0.0;
+    for (int j = lane; j < m; j += 64) { const double v = line[j + 1]; f0 += w0[j] * v; f1 += w1[j] * v; }
+    for (int o = 32; o > 0; o >>= 1) { f0 += __shfl_down(f0, o, 64); f1 += __shfl_down(f1, o, 64); }
+    if (lane == 0) { line[0] = f0; line[len - 1] = f1; }
+  }
+}
+
 // Node loop of StokesMatMultVV, stokes.C:647-662.  V[j], S[j]: d stacked fields (component k of direction j).
 // DETA = false when deta is identically zero (linear rheology): the deta * S0 * z term vanishes and S0 is not
 // read.  The trace of the velocity gradient is the divergence StokesMatMult needs for the pressure rows
@@ -406,9 +424,11 @@ static int st_divergence(stokes_op *op, hipStream_t st) {
 static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   const int d = op->d;
   const long m = op->dims[0], n = op->dims[1], p = (d == 2) ? 1 : op->dims[2];
-  if (p > 1)    // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052)
-    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid((m - 1) * (n - 1))), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, n - 1, 1L, p, 1L,
+  if (p > 1) {  // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052): contiguous lines
+    long g = ((m - 1) * (n - 1) + 3) / 4; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_st_preduce_contig, dim3((unsigned)g), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, n - 1, 1L, p,
                        (int)p, (const double *)op->w0[2], (const double *)op->w1[2]);
+  }
   // y lines of planes i = 1..m-1, every k (stokes.C:1054-1062)
   hipLaunchKernelGGL(k_st_preduce, dim3(pgrid((m - 1) * p)), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, p, 0L, 1L, p,
                      (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
