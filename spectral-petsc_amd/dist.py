@@ -70,6 +70,9 @@ class DistPoissonOp:
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         G, M = self.G, self.M
+        if M[0] < G or M[1] < G:
+            raise ValueError("slab partition of interior extents %s over %d ranks: every rank needs at least one plane "
+                             "along dims 0 and 1" % (M[:2], G))
         self.R = int(np.prod(M[2:])) if len(M) > 2 else 1          # trailing dims flattened
         self.m0 = split_sizes(M[0], G)
         self.m1 = split_sizes(M[1], G)

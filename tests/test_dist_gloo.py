@@ -79,7 +79,7 @@ def _worker(rank, world, port, dims, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims", [(2, (12, 11, 10)), (3, (9, 10)), (2, (8, 9, 5, 4))])
+@pytest.mark.parametrize("world,dims", [(2, (12, 11, 10)), (3, (9, 10)), (2, (8, 9, 5, 4)), (8, (20, 19, 7)), (4, (6, 9, 4))])
 def test_slab_matvec_matches_serial(world, dims):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
