@@ -80,12 +80,12 @@ int cheb_apply_lap1d(cheb_plan *plan, const double *x_dev, const double *acc_dev
                      double *y_dev, void *stream);
 /* Copies between a slab (m0, M1, R) row-major and the buffer an all-to-all moves: for every peer s the
  * block slab[:, c1[s]:c1[s+1], :] contiguously, blocks in rank order (c1: G+1 host values, 0 .. M1).
- * pack: buf <- slab (before the forward transpose).  unpack_add: out = acc + slab-ordered(buf)
+ * pack: buf <- slab (before the forward transpose).  unpack_add: out = acc + alpha * slab-ordered(buf)
  * (after the backward transpose; acc may be NULL or alias out). */
 int cheb_slab_pack(long m0, long M1, long R, int G, const long *c1_host, const double *slab_dev,
                    double *buf_dev, void *stream);
 int cheb_slab_unpack_add(long m0, long M1, long R, int G, const long *c1_host, const double *buf_dev,
-                         const double *acc_dev, double *out_dev, void *stream);
+                         const double *acc_dev, double alpha, double *out_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Operator level: the scalar elliptic MatShell (elliptic.C:78-86,250-293).   */
@@ -174,6 +174,20 @@ int stokes_op_function(stokes_op *op, const double *xG_dev, double *yG_dev, void
 /* Operator state to/from the host: which = 0 eta (N), 1 deta (N), 2+j strain[j] (N*d). */
 int stokes_op_get_state(stokes_op *op, int which, double *dst_host);
 int stokes_op_set_state(stokes_op *op, int which, const double *src_host);
+
+/* Slab mode for the multi-GPU path (no counterpart in the serial reference).  The handle owns the
+ * planes [lo, hi) of grid dimension 0; its vectors are the serial ones restricted to the slab (contiguous
+ * pieces, dimension 0 being outermost).  Everything along dimension 0 is delegated to `dim0`:
+ *   kind 0: out = (acc ? acc : 0) + alpha * D_0 in   for nfields stacked slab fields of N nodes each
+ *   kind 1: out = D_0 (x-line pressure extrapolation of in)              (one field; stokes.C:1064-1074, :611)
+ * The driver (spectral-petsc_amd/dist.py) implements it as transpose -> pencil call below -> transpose.
+ * All other entry points (mult, mult_vv/pv/vp, function, set_*, get/set_state) work unchanged on the slab. */
+typedef int (*stokes_dim0_fn)(void *ctx, int kind, int nfields, const double *in_dev, const double *acc_dev,
+                              double alpha, double *out_dev, void *stream);
+int stokes_op_create_slab(int d, const int *dims, int lo, int hi, stokes_dim0_fn dim0, void *dim0_ctx, stokes_op **out);
+/* Pencil side: arrays (nfields, dims[0], ncol), lines along dimension 0 with stride ncol. */
+int stokes_op_pencil_sweep(stokes_op *op, int nfields, long ncol, const double *in_dev, double *out_dev, void *stream);
+int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil_dev, double *gp0_pencil_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Krylov driver on device vectors: the caller of the path.     */

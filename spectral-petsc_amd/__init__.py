@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
     "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
     "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
-    "stokes_op_set_state", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations",
+    "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations",
     "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
     "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason",
 ]
@@ -77,7 +77,7 @@ def lib():
         L.cheb_apply_lap1d.argtypes = [vp, vp, vp, C.c_double, vp, vp]
         lp = C.POINTER(C.c_long)
         L.cheb_slab_pack.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, lp, vp, vp, vp]
-        L.cheb_slab_unpack_add.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, lp, vp, vp, vp, vp]
+        L.cheb_slab_unpack_add.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, lp, vp, vp, C.c_double, vp, vp]
         L.cheb_apply_host.argtypes = [vp, dp, dp]
         L.cheb_plan_destroy.argtypes = [vp]
         L.cheb_plan_size.argtypes = [vp]
@@ -105,6 +105,9 @@ def lib():
             f.argtypes = [vp, vp, vp, vp]
         L.stokes_op_get_state.argtypes = [vp, C.c_int, dp]
         L.stokes_op_set_state.argtypes = [vp, C.c_int, dp]
+        L.stokes_op_create_slab.argtypes = [C.c_int, ip, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
+        L.stokes_op_pencil_sweep.argtypes = [vp, C.c_int, C.c_long, vp, vp, vp]
+        L.stokes_op_pencil_pressure.argtypes = [vp, C.c_long, vp, vp, vp]
         L.stokes_op_mult_schur.argtypes = [vp, vp, vp, vp, vp, vp]
         L.stokes_op_set_inner_solver.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int]
         L.stokes_op_inner_iterations.argtypes = [vp]
@@ -220,12 +223,12 @@ def slab_pack(slab, buf, m0, M1, R, c1):
     return buf
 
 
-def slab_unpack_add(buf, acc, out, m0, M1, R, c1):
-    """out = acc + slab-ordered(buf) (cheb_slab_unpack_add); acc may be None."""
+def slab_unpack_add(buf, acc, out, m0, M1, R, c1, alpha=1.0):
+    """out = acc + alpha * slab-ordered(buf) (cheb_slab_unpack_add); acc may be None."""
     n = int(m0) * int(M1) * int(R)
     cs = (C.c_long * len(c1))(*[int(v) for v in c1])
     ap = _dev_ptr(acc, n) if acc is not None else None
-    _chk(lib().cheb_slab_unpack_add(m0, M1, R, len(c1) - 1, cs, _dev_ptr(buf, n), ap, _dev_ptr(out, n), _stream()))
+    _chk(lib().cheb_slab_unpack_add(m0, M1, R, len(c1) - 1, cs, _dev_ptr(buf, n), ap, alpha, _dev_ptr(out, n), _stream()))
     return out
 
 
@@ -308,11 +311,27 @@ class StokesOp:
     mult <-> StokesMatMult (stokes.C:499-519); mult_vv / mult_pv / mult_vp <-> MatVV / MatPV / MatVP
     (:623-676, :557-566, :599-619); function <-> StokesFunction (:680-758)."""
 
-    def __init__(self, dims):
+    DIM0_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p)
+
+    def __init__(self, dims, slab=None, dim0=None):
+        """slab = (lo, hi): the planes [lo, hi) of grid dimension 0 (stokes_op_create_slab); dim0 is then the Python
+        callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the work along dim 0."""
         self.dims = tuple(int(d) for d in dims)
         self.d = len(self.dims)
         h = C.c_void_p()
-        _chk(lib().stokes_op_create(self.d, _ints(self.dims), C.byref(h)))
+        if slab is None:
+            _chk(lib().stokes_op_create(self.d, _ints(self.dims), C.byref(h)))
+        else:
+            def tramp(ctx, kind, nf, inp, acc, alpha, out, stream):
+                try:
+                    return int(dim0(kind, nf, inp, acc, alpha, out, stream) or 0)
+                except Exception:                      # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 5
+            self._cb = StokesOp.DIM0_FN(tramp)          # keep the trampoline alive as long as the handle
+            _chk(lib().stokes_op_create_slab(self.d, _ints(self.dims), int(slab[0]), int(slab[1]),
+                                             C.cast(self._cb, C.c_void_p), None, C.byref(h)))
         self._h = h
         sz = [lib().stokes_op_size(h, w) for w in range(6)]
         self.local_nodes, self.interior_nodes, self.velocity_size, self.pressure_size, self.global_size, self.dirichlet_size = sz
@@ -347,6 +366,14 @@ class StokesOp:
 
     def mult_vp(self, p, vout):
         return self._call(lib().stokes_op_mult_vp, p, self.pressure_size, vout, self.velocity_size)
+
+    def pencil_sweep(self, nfields, ncol, inp, out):
+        _chk(lib().stokes_op_pencil_sweep(self._h, nfields, ncol, inp.data_ptr(), out.data_ptr(), _stream()))
+        return out
+
+    def pencil_pressure(self, ncol, p_pencil, gp0_pencil):
+        _chk(lib().stokes_op_pencil_pressure(self._h, ncol, p_pencil.data_ptr(), gp0_pencil.data_ptr(), _stream()))
+        return gp0_pencil
 
     def mult_schur(self, p, pout, restart=None, rtol=None, atol=1e-50, max_it=10000):
         """StokesMatMultSchur (stokes.C:523-535) with the built-in inner GMRES on MatVV (KSP defaults unless given)."""

@@ -210,12 +210,12 @@ __global__ void k_slab_pack(SlabSplit sp, long m0, long M1, long R, const double
     buf[slab_buf_index(sp, m0, M1, R, e)] = slab[e];
 }
 
-// out = acc + buf (buf in exchange order)
+// out = acc + alpha * buf (buf in exchange order)
 __global__ void k_slab_unpack_add(SlabSplit sp, long m0, long M1, long R, const double *__restrict__ buf,
-                                  const double *__restrict__ acc, double *__restrict__ out) {
+                                  const double *acc, double alpha, double *out) {
   const long n = m0 * M1 * R;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const double t = buf[slab_buf_index(sp, m0, M1, R, e)];
+    const double t = alpha * buf[slab_buf_index(sp, m0, M1, R, e)];
     out[e] = acc ? acc[e] + t : t;
   }
 }
@@ -243,13 +243,13 @@ extern "C" int cheb_slab_pack(long m0, long M1, long R, int G, const long *c1, c
 }
 
 extern "C" int cheb_slab_unpack_add(long m0, long M1, long R, int G, const long *c1, const double *buf, const double *acc,
-                                    double *out, void *stream) {
+                                    double alpha, double *out, void *stream) {
   if (!buf || !out || m0 < 0 || M1 < 0 || R < 1) return fail(CHEBHIP_ERR_ARG, "bad argument");
   SlabSplit sp; int rc = slab_split(G, c1, M1, &sp); if (rc) return rc;
   const long n = m0 * M1 * R;
   if (n == 0) return 0;
   long g = (n + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_slab_unpack_add, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, sp, m0, M1, R, buf, acc, out);
+  hipLaunchKernelGGL(k_slab_unpack_add, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, sp, m0, M1, R, buf, acc, alpha, out);
   HIPCHK(hipGetLastError());
   return 0;
 }

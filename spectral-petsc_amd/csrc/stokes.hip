@@ -220,6 +220,12 @@ struct stokes_op {
   // gather and the final scatter: it runs on a second stream (small grids leave most CUs idle per launch)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // slab mode (multi-GPU): the handle owns the planes [lo, lo + dims[0]) of a grid whose dimension 0 has
+  // gP0 points; everything along dimension 0 (sweeps, x-line pressure extrapolation) goes through `dim0`
+  bool slab = false;
+  int gP0 = 0, lo = 0;
+  stokes_dim0_fn dim0 = nullptr;
+  void *dim0_ctx = nullptr;
   bool deta_nonzero = false;                                 // deta == 0 everywhere: the node loop skips S0
   int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
 };
@@ -245,15 +251,29 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   return 0;
 }
 
-extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
+// boundary node of the GLOBAL grid?  ind: local multi-index (dimension 0 is offset by op->lo in slab mode)
+static inline bool st_is_bdy(const stokes_op *op, const int *ind) {
+  const int g0 = ind[0] + op->lo;
+  if (g0 == 0 || g0 == op->gP0 - 1) return true;
+  for (int j = 1; j < op->d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) return true;
+  return false;
+}
+
+static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim0, void *dim0_ctx, stokes_op **out) {
   if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
   *out = nullptr;
-  if (!dims || d < 2 || d > 3) return chebhip_fail(CHEBHIP_ERR_DIMS, "d = %d: Stokes needs d = 2 or 3 (stokes.C:1036)", d);
-  long N = 1, I = 1;
+  if (!gdims || d < 2 || d > 3) return chebhip_fail(CHEBHIP_ERR_DIMS, "d = %d: Stokes needs d = 2 or 3 (stokes.C:1036)", d);
+  const bool slab = dim0 != nullptr;
   for (int k = 0; k < d; k++) {
-    if (dims[k] < 3) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d but must be >= 3", k, dims[k]);
-    if (dims[k] > 4096) return chebhip_fail(CHEBHIP_ERR_ARG, "dims[%d] = %d: at most 4096 points per line", k, dims[k]);
-    N *= dims[k]; I *= dims[k] - 2;
+    if (gdims[k] < 3) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d but must be >= 3", k, gdims[k]);
+    if (gdims[k] > 4096) return chebhip_fail(CHEBHIP_ERR_ARG, "dims[%d] = %d: at most 4096 points per line", k, gdims[k]);
+  }
+  if (slab && !(0 <= lo && lo < hi && hi <= gdims[0])) return chebhip_fail(CHEBHIP_ERR_ARG, "slab planes [%d, %d) outside 0..%d", lo, hi, gdims[0]);
+  std::vector<int> dims(gdims, gdims + d);
+  if (slab) dims[0] = hi - lo; else { lo = 0; hi = gdims[0]; }
+  long N = 1;
+  for (int k = 0; k < d; k++) {
+    N *= dims[k];
     if (N * d > 0x7fffffffL) return chebhip_fail(CHEBHIP_ERR_DIMS, "tensor of more than 2^31-1 values");
   }
   int ndev = 0;
@@ -261,21 +281,21 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
     return chebhip_fail(CHEBHIP_ERR_DEVICE, "no usable HIP device; libchebhip has no CPU fallback");
   stokes_op *op = new (std::nothrow) stokes_op;
   if (!op) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
-  op->d = d; op->dims.assign(dims, dims + d); op->N = N; op->I = I;
+  op->d = d; op->dims = dims; op->N = N;
+  op->slab = slab; op->gP0 = gdims[0]; op->lo = lo; op->dim0 = dim0; op->dim0_ctx = dim0_ctx;
 #define OPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { stokes_op_destroy(op); \
     return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
 #define OPRC(expr) do { int rc_ = (expr); if (rc_) { stokes_op_destroy(op); return rc_; } } while (0)
-  for (int k = 0; k < d; k++)
-    if (!op->mats.count(dims[k])) { DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m; }
-  {  // ixLP of StokesSetupDomain (stokes.C:791-879): interior index or -1, BlockIt order
+  for (int k = 0; k < d; k++)      // dimension 0: the global extent (in slab mode it is applied on pencils)
+    if (!op->mats.count(gdims[k])) { DiffMat m; OPCHK(diffmat_create(gdims[k], &m)); op->mats[gdims[k]] = m; }
+  {  // ixLP of StokesSetupDomain (stokes.C:791-879): interior index or -1, BlockIt order (of this slab)
     std::vector<int> ixL((size_t)N), ind(d, 0);
     long g = 0;
     for (long l = 0; l < N; l++) {
-      bool bdy = false;
-      for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == dims[j] - 1) bdy = true;
-      ixL[l] = bdy ? -1 : (int)g++;
+      ixL[l] = st_is_bdy(op, ind.data()) ? -1 : (int)g++;
       for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
     }
+    op->I = g;
     OPCHK(hipMalloc((void **)&op->ixL, (size_t)N * sizeof(int)));
     OPCHK(hipMemcpy(op->ixL, ixL.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
   }
@@ -294,7 +314,7 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
   // Lagrange weights of the interior nodes x_1..x_{P-2} at x_0 and x_{P-1} (the polyInterp functional)
   op->w0.assign(d, nullptr); op->w1.assign(d, nullptr);
   for (int k = 0; k < d; k++) {
-    const int P = dims[k], m = P - 2;
+    const int P = gdims[k], m = P - 2;
     std::vector<long double> x(P);
     for (int i = 0; i < P; i++) x[i] = cosl(3.14159265358979323846264338327950288L * i / (P - 1));
     std::vector<double> a(m), b(m);
@@ -310,7 +330,7 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
   }
   {
     const char *e = getenv("CHEBHIP_STOKES_SERIAL");
-    if (!(e && e[0] == '1')) {
+    if (!(e && e[0] == '1') && !slab) {
       OPCHK(hipStreamCreateWithFlags(&op->aux, hipStreamNonBlocking));
       OPCHK(hipEventCreateWithFlags(&op->ev_fork, hipEventDisableTiming));
       OPCHK(hipEventCreateWithFlags(&op->ev_join, hipEventDisableTiming));
@@ -322,6 +342,17 @@ extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) {
   *out = op;
   return 0;
 }
+
+extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) { return st_create(d, dims, 0, 0, nullptr, nullptr, out); }
+
+// Slab of the planes [lo, hi) of grid dimension 0 (multi-GPU).  Vector layouts are those of the serial
+// operator restricted to the slab: the global vectors hold the slab's interior nodes, the Dirichlet vector its
+// boundary nodes, both in BlockIt order (contiguous pieces of the serial vectors, dimension 0 being outermost).
+extern "C" int stokes_op_create_slab(int d, const int *dims, int lo, int hi, stokes_dim0_fn dim0, void *dim0_ctx, stokes_op **out) {
+  if (!dim0) return chebhip_fail(CHEBHIP_ERR_ARG, "slab mode needs the dimension-0 callback");
+  return st_create(d, dims, lo, hi, dim0, dim0_ctx, out);
+}
+
 
 extern "C" long stokes_op_size(const stokes_op *op, int which) {
   if (!op) return -1;
@@ -350,9 +381,7 @@ extern "C" int stokes_op_set_dirichlet(stokes_op *op, const double *values) {
   std::vector<int> ind(d, 0);
   long dd = 0;
   for (long l = 0; l < op->N; l++) {                      // ixDL order: boundary nodes in BlockIt order, d values each
-    bool bdy = false;
-    for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) bdy = true;
-    if (bdy) for (int k = 0; k < d; k++) loc[(size_t)k * op->N + l] = values[dd++];
+    if (st_is_bdy(op, ind.data())) for (int k = 0; k < d; k++) loc[(size_t)k * op->N + l] = values[dd++];
     for (int j = d - 1; j >= 0; j--) { if (++ind[j] < op->dims[j]) break; ind[j] = 0; }
   }
   if (!op->dirloc) SHIPCHK(hipMalloc((void **)&op->dirloc, loc.size() * sizeof(double)));
@@ -372,6 +401,8 @@ extern "C" int stokes_op_set_force(stokes_op *op, const double *force) {
 // DP[k] (scalar field) or DV[k] (d stacked fields: same lines, d times as many)
 static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *y, int out_mode, const double *acc,
                        double alpha, hipStream_t st) {
+  if (op->slab && k == 0)       // lines along dimension 0 cross the slabs: transposes and the pencil sweep are the driver's
+    return op->dim0(op->dim0_ctx, 0, vec ? op->d : 1, x, out_mode == OUT_ACC ? acc : nullptr, alpha, y, st);
   SweepParams sp = {};
   sp.ncols = vec ? op->ncolsV[k] : op->ncolsP[k];
   sp.inner = op->innerP[k];
@@ -424,18 +455,27 @@ static int st_divergence(stokes_op *op, hipStream_t st) {
 static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   const int d = op->d;
   const long m = op->dims[0], n = op->dims[1], p = (d == 2) ? 1 : op->dims[2];
-  if (p > 1) {  // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052): contiguous lines
-    long g = ((m - 1) * (n - 1) + 3) / 4; if (g > 8192) g = 8192; if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_st_preduce_contig, dim3((unsigned)g), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, n - 1, 1L, p,
+  // planes i = 1..m-1 of the global grid that this handle owns: local planes i_lo .. m-1
+  const long i_lo = (op->lo == 0) ? 1 : 0, ni = m - i_lo;
+  if (p > 1 && ni > 0) {  // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052): contiguous lines
+    long g = (ni * (n - 1) + 3) / 4; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_st_preduce_contig, dim3((unsigned)g), dim3(256), 0, st, op->pL, ni, i_lo, n * p, n - 1, 1L, p,
                        (int)p, (const double *)op->w0[2], (const double *)op->w1[2]);
   }
   // y lines of planes i = 1..m-1, every k (stokes.C:1054-1062)
-  hipLaunchKernelGGL(k_st_preduce, dim3(pgrid((m - 1) * p)), dim3(256), 0, st, op->pL, m - 1, 1L, n * p, p, 0L, 1L, p,
-                     (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
-  // x lines, every (j, k) (stokes.C:1064-1074)
-  hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(n * p)), dim3(256), 0, st, op->pL, n, 0L, p, p, 0L, 1L, n * p,
-                     (int)m, (const double *)op->w0[0], (const double *)op->w1[0]);
-  for (int i = 0; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
+  if (ni > 0)
+    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(ni * p)), dim3(256), 0, st, op->pL, ni, i_lo, n * p, p, 0L, 1L, p,
+                       (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
+  if (op->slab) {
+    // x lines cross the slabs: extrapolation (stokes.C:1064-1074) and DP[0] happen on pencils, in the driver.  The end
+    // planes of pL it would have filled only feed DP[1], DP[2] on those planes, which the final scatter never reads.
+    int rc = op->dim0(op->dim0_ctx, 1, 1, op->pL, nullptr, 1.0, op->gp[0], st); if (rc) return rc;
+  } else {
+    // x lines, every (j, k) (stokes.C:1064-1074)
+    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(n * p)), dim3(256), 0, st, op->pL, n, 0L, p, p, 0L, 1L, n * p,
+                       (int)m, (const double *)op->w0[0], (const double *)op->w1[0]);
+  }
+  for (int i = op->slab ? 1 : 0; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
   return 0;
 }
 
@@ -556,6 +596,29 @@ extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out
   hipLaunchKernelGGL(k_st_neg, dim3(sgrid(op->I)), dim3(256), 0, st, op->I, out);
   SHIPCHK(hipGetLastError());
   return 0;
+}
+
+// ---- pencil side of the slab mode: arrays (nfields, gP0, ncol), lines along dimension 0 with stride ncol ---------
+// out = DV[0] / DP[0] applied to nfields stacked pencil fields
+extern "C" int stokes_op_pencil_sweep(stokes_op *op, int nfields, long ncol, const double *in, double *out, void *stream) {
+  ARGCHK(op && in && out);
+  if (nfields < 1 || ncol < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad pencil geometry");
+  if (ncol == 0) return 0;
+  SweepParams sp = {};
+  sp.ncols = (unsigned)(nfields * ncol); sp.inner = (unsigned)ncol;
+  sp.in0 = in; sp.in_mode = IN_PLAIN; sp.out = out; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+  SHIPCHK(sweep_launch(op->mats[op->gP0], sp, (hipStream_t)stream));
+  return 0;
+}
+
+// x-line pressure extrapolation (stokes.C:1064-1074) in place on a pencil, then gp0 = DP[0] p
+extern "C" int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil, double *gp0_pencil, void *stream) {
+  ARGCHK(op && p_pencil && gp0_pencil);
+  if (ncol <= 0) return ncol == 0 ? 0 : chebhip_fail(CHEBHIP_ERR_ARG, "bad pencil geometry");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(ncol)), dim3(256), 0, st, p_pencil, ncol, 0L, 1L, 1L, 0L, 0L, ncol,
+                     op->gP0, (const double *)op->w0[0], (const double *)op->w1[0]);
+  return stokes_op_pencil_sweep(op, 1, ncol, p_pencil, gp0_pencil, stream);
 }
 
 // State at the ABI is in the reference's layout (strain[j]: N nodes x d components, component fastest)

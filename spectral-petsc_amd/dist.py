@@ -144,3 +144,161 @@ class DistPoissonOp:
             torch.cuda.current_stream().wait_stream(cs)
         be.unpack_add(self.sendbuf, self.W, V, self.m0[self.rank], M[1], self.R, self.c1)   # V = W + T
         return V
+
+
+class DistStokesOp:
+    """The Stokes callbacks (StokesMatMult, StokesFunction and the MatVV / MatPV / MatVP blocks) on a grid whose
+    dimension 0 is split into slabs of planes, one per rank.
+
+    Each rank owns a slab-mode operator handle (stokes_op_create_slab): gathers, node loops, sweeps along
+    dimensions 1.., pressure extrapolation along them and the final scatter are local launches on the slab.
+    Whatever runs along dimension 0 -- DV[0] / DP[0] and the x-line pressure extrapolation -- comes back to this
+    class through the handle's callback and is done on pencils (all planes, a share of dimension 1):
+
+        slab fields --pack, exchange--> pencil fields --stokes_op_pencil_*--> pencil result --exchange, unpack--> slab
+
+    One exchange moves all fields of a call as a single batch of point-to-point messages (RCCL groups them into
+    one launch).  Per StokesMatMult: gradient (d fields there and back), stress divergence (d fields there and
+    back), pressure (1 field there and back).  Vector layouts per rank are the serial ones restricted to the
+    slab: contiguous pieces of the serial vectors, dimension 0 being outermost.
+    """
+
+    def __init__(self, dims, sp, group=None):
+        self.sp = sp
+        self.dims = tuple(int(v) for v in dims)
+        d = self.d = len(self.dims)
+        self.group = group
+        self.G = G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = r = dist.get_rank(group) if dist.is_initialized() else 0
+        P0, P1 = self.dims[0], self.dims[1]
+        self.R = int(np.prod(self.dims[2:])) if d > 2 else 1
+        if P0 < G or P1 < G:
+            raise ValueError("slab partition of extents %s over %d ranks: every rank needs a plane along dims 0 and 1" % (self.dims[:2], G))
+        self.m0 = split_sizes(P0, G); self.m1 = split_sizes(P1, G)
+        self.s0 = [int(v) for v in np.concatenate([[0], np.cumsum(self.m0)])]
+        self.s1 = [int(v) for v in np.concatenate([[0], np.cumsum(self.m1)])]
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.op = sp.StokesOp(self.dims, slab=(self.s0[r], self.s0[r + 1]), dim0=self._dim0)
+        self.Ns = self.m0[r] * P1 * self.R                     # nodes of the slab
+        self.ncol = self.m1[r] * self.R                        # lines of the pencil
+        self.Np = P0 * self.ncol
+        nf = d
+        z = lambda n: torch.empty(n, dtype=torch.float64, device=self.device)
+        self.sendbuf, self.recvbuf = z(nf * self.Ns), z(nf * self.Ns)
+        self.pen_in, self.pen_out = z(nf * self.Np), z(nf * self.Np)
+        for name in ("global_size", "velocity_size", "pressure_size", "dirichlet_size", "local_nodes", "interior_nodes"):
+            setattr(self, name, getattr(self.op, name))
+
+    # where this rank's pieces sit in the serial vectors (dimension 0 outermost => contiguous)
+    def serial_ranges(self):
+        inner_int = int(np.prod([v - 2 for v in self.dims[1:]]))
+        inner_all = int(np.prod(self.dims[1:]))
+        lo, hi = self.s0[self.rank], self.s0[self.rank + 1]
+        P0 = self.dims[0]
+        ilo, ihi = max(lo, 1) - 1, max(min(hi, P0 - 1) - 1, max(lo, 1) - 1)     # interior planes before / up to this slab
+        def bnodes(plane_hi):      # boundary nodes in planes [0, plane_hi)
+            full = min(plane_hi, 1) + max(plane_hi - (P0 - 1), 0)
+            return full * inner_all + (plane_hi - full) * (inner_all - inner_int)
+        return (ilo * inner_int, ihi * inner_int), (bnodes(lo), bnodes(hi))
+
+    # ---- exchanges: every field of a call in one batch of point-to-point messages ------------------------------
+    def _exchange(self, sends, recvs):
+        """sends / recvs: per peer s a list of contiguous tensors (views)."""
+        if self.G == 1:
+            for a, b in zip(sends[0], recvs[0]):
+                b.copy_(a)
+            return
+        staged = sends[0][0].is_cuda and dist.get_backend(self.group) == "gloo"      # rehearsal: several ranks on one GPU
+        ops, back = [], []
+        for a, b in zip(sends[self.rank], recvs[self.rank]):       # own block: no message
+            b.copy_(a)
+        for s in range(self.G):
+            if s == self.rank:
+                continue
+            for t in recvs[s]:
+                if t.numel():
+                    buf = torch.empty(t.shape, dtype=t.dtype) if staged else t
+                    if staged:
+                        back.append((t, buf))
+                    ops.append(dist.P2POp(dist.irecv, buf, s, self.group))
+            for t in sends[s]:
+                if t.numel():
+                    ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, s, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, buf in back:
+            t.copy_(buf)
+
+    def _to_pencil(self, nf, inp):
+        """nf slab fields at device address inp -> self.pen_in as (nf, P0, m1, R)."""
+        r, P1, R = self.rank, self.dims[1], self.R
+        src = _view(inp, nf * self.Ns, self.device)
+        for f in range(nf):
+            self.sp.slab_pack(src[f * self.Ns:(f + 1) * self.Ns], self.sendbuf[f * self.Ns:(f + 1) * self.Ns], self.m0[r], P1, R, self.s1)
+        sends, recvs = [], []
+        for s in range(self.G):
+            blk = self.m0[r] * self.m1[s] * R
+            off = self.m0[r] * self.s1[s] * R
+            sends.append([self.sendbuf[f * self.Ns + off: f * self.Ns + off + blk] for f in range(nf)])
+            rows = self.m0[s] * self.ncol
+            roff = self.s0[s] * self.ncol
+            recvs.append([self.pen_in[f * self.Np + roff: f * self.Np + roff + rows] for f in range(nf)])
+        self._exchange(sends, recvs)
+
+    def _to_slab(self, nf, acc, alpha, out):
+        """self.pen_out (nf, P0, m1, R) -> out = acc + alpha * slab fields."""
+        r, P1, R = self.rank, self.dims[1], self.R
+        sends, recvs = [], []
+        for s in range(self.G):
+            rows = self.m0[s] * self.ncol
+            roff = self.s0[s] * self.ncol
+            sends.append([self.pen_out[f * self.Np + roff: f * self.Np + roff + rows] for f in range(nf)])
+            blk = self.m0[r] * self.m1[s] * R
+            off = self.m0[r] * self.s1[s] * R
+            recvs.append([self.recvbuf[f * self.Ns + off: f * self.Ns + off + blk] for f in range(nf)])
+        self._exchange(sends, recvs)
+        dst = _view(out, nf * self.Ns, self.device)
+        accv = _view(acc, nf * self.Ns, self.device) if acc else None
+        for f in range(nf):
+            sl = slice(f * self.Ns, (f + 1) * self.Ns)
+            self.sp.slab_unpack_add(self.recvbuf[sl], accv[sl] if accv is not None else None, dst[sl], self.m0[r], P1, R, self.s1, alpha)
+
+    def _dim0(self, kind, nf, inp, acc, alpha, out, stream):
+        # the handle's launches and ours share torch's current stream (the callers pass it down)
+        self._to_pencil(nf, inp)
+        if kind == 0:
+            self.op.pencil_sweep(nf, self.ncol, self.pen_in, self.pen_out)
+        else:
+            self.op.pencil_pressure(self.ncol, self.pen_in, self.pen_out)
+        self._to_slab(nf, acc, alpha, out)
+        return 0
+
+    # ---- the callbacks, on this rank's pieces of the vectors ---------------------------------------------------
+    def mult(self, x, y):
+        return self.op.mult(x, y)
+
+    def function(self, x, y):
+        return self.op.function(x, y)
+
+    def mult_vv(self, v, out):
+        return self.op.mult_vv(v, out)
+
+    def mult_pv(self, v, pout):
+        return self.op.mult_pv(v, pout)
+
+    def mult_vp(self, p, vout):
+        return self.op.mult_vp(p, vout)
+
+    def destroy(self):
+        self.op.destroy()
+
+
+def _view(ptr, n, device):
+    """A float64 tensor over n doubles of device memory owned by the operator handle (no copy)."""
+    import ctypes
+    class _Arr:
+        pass
+    a = _Arr()
+    a.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
+    return torch.as_tensor(a, device=device)
