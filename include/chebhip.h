@@ -199,7 +199,12 @@ int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil_dev, do
 /* HBM; the host sees one Hessenberg column per iteration.                     */
 /* ------------------------------------------------------------------------- */
 typedef struct chebhip_fgmres chebhip_fgmres;
+/* Sums `count` device doubles over the ranks in place, ordered on `stream` (ncclAllReduce of a few doubles per
+ * iteration). */
+typedef int (*chebhip_reduce_fn)(void *ctx, double *vals_dev, int count, void *stream);
 int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out);
+/* Vectors distributed over ranks (n = local entries): inner products are completed by `reduce`. NULL = one rank. */
+int chebhip_fgmres_set_reduce(chebhip_fgmres *k, chebhip_reduce_fn reduce, void *ctx);
 int chebhip_fgmres_destroy(chebhip_fgmres *k);
 int chebhip_fgmres_set_tolerances(chebhip_fgmres *k, double rtol, double atol, int max_it);
 /* x_nonzero = 0: zero initial guess (x is overwritten); 1: x_dev holds the initial guess. */

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
     "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations",
     "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
-    "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason",
+    "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason", "chebhip_fgmres_set_reduce",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
         L.chebhip_fgmres_residual.argtypes = [vp]
         L.chebhip_fgmres_residual.restype = C.c_double
         L.chebhip_fgmres_reason.argtypes = [vp]
+        L.chebhip_fgmres_set_reduce.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -148,6 +149,17 @@ def _dev_ptr(t, n):
 def _stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def device_view(ptr, n):
+    """A float64 tensor over n doubles of device memory owned by someone else (no copy)."""
+    import torch
+
+    class _Arr:
+        pass
+    a = _Arr()
+    a.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
+    return torch.as_tensor(a, device=torch.device("cuda", torch.cuda.current_device()))
 
 
 class ChebPlan:
@@ -429,14 +441,53 @@ class Fgmres:
         self._h = h
         _chk(lib().chebhip_fgmres_set_tolerances(h, rtol, atol, max_it))
 
-    @staticmethod
-    def _fn(op, entry):
+    APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+    def _fn(self, op, entry):
+        """C entry point + handle of an operator object, or a trampoline around a Python callable (x, y) on
+        device tensors (used by the multi-rank drivers of dist.py, whose matvec includes the exchanges)."""
         if op is None:
             return None, None
-        name = {"EllipticOp": "ell_op_", "StokesOp": "stokes_op_"}[type(op).__name__] + entry
-        return C.cast(getattr(lib(), name), C.c_void_p), op._h
+        kind = type(op).__name__
+        if kind in ("EllipticOp", "StokesOp"):
+            name = {"EllipticOp": "ell_op_", "StokesOp": "stokes_op_"}[kind] + entry
+            return C.cast(getattr(lib(), name), C.c_void_p), op._h
+        n = self.n
+
+        def tramp(ctx, xp, yp, stream):
+            try:
+                op(device_view(xp, n), device_view(yp, n))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 5
+        cb = Fgmres.APPLY_FN(tramp)
+        self._keep.append(cb)
+        return C.cast(cb, C.c_void_p), None
+
+    def set_reduce(self, group=None):
+        """Vectors are distributed over the ranks of `group`: complete every inner product with an all-reduce."""
+        import torch.distributed as dist
+
+        def red(ctx, ptr, count, stream):
+            try:
+                t = device_view(ptr, count)
+                if dist.get_backend(group) == "gloo":          # rehearsal on one GPU: stage through the host
+                    h = t.cpu(); dist.all_reduce(h, group=group); t.copy_(h)
+                else:
+                    dist.all_reduce(t, group=group)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 5
+        self._red = Fgmres.REDUCE_FN(red)
+        _chk(lib().chebhip_fgmres_set_reduce(self._h, C.cast(self._red, C.c_void_p), None))
 
     def solve(self, A, b, x, M=None, x_nonzero=False, a_entry="mult", m_entry="mult"):
+        self._keep = []
         fa, ca = self._fn(A, a_entry)
         fm, cm = self._fn(M, m_entry)
         _chk(lib().chebhip_fgmres_solve(self._h, fa, ca, fm, cm, _dev_ptr(b, self.n), _dev_ptr(x, self.n),

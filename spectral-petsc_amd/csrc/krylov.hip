@@ -50,25 +50,27 @@ __global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restric
   if (threadIdx.x == 0) part[(long)blockIdx.y * RB + blockIdx.x] = r;
 }
 
-// out[0] = sqrt(sum_b part[b]) (fixed order)
-__global__ __launch_bounds__(RT) void k_norm_finish(const double *__restrict__ part, double *__restrict__ out) {
+// out[row] = sum_b part[row][b] (fixed order), optionally the square root; one block per row
+__global__ __launch_bounds__(RT) void k_rows_finish(const double *__restrict__ part, double *__restrict__ out, int take_sqrt) {
   __shared__ double sh[RT / 64];
-  const double r = block_sum(part[threadIdx.x], sh);
-  if (threadIdx.x == 0) out[0] = sqrt(r);
+  const double r = block_sum(part[(long)blockIdx.x * RB + threadIdx.x], sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = take_sqrt ? sqrt(r) : r;
 }
+
+__global__ void k_sqrt1(double *__restrict__ p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = sqrt(p[0]); }
 
 // h[kk] = sum_b dpart[kk][b] (every block forms the same sums in the same order; block 0 publishes them);
 // w -= sum_{kk<k} h[kk] V[kk];  npart[b] = sum over chunk b of w^2
 __global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double *__restrict__ V, long ldv,
-                                                    const double *__restrict__ dpart, double *__restrict__ hcol,
+                                                    const double *__restrict__ dpart, double *hcol,
                                                     double *__restrict__ w, double *__restrict__ npart) {
   __shared__ double sh[RT / 64];
   __shared__ double h[RT];
   for (int kk = threadIdx.x; kk < k; kk += RT) {
     double s = 0.0;
-    for (int q = 0; q < RB; q++) s += dpart[(long)kk * RB + q];
+    if (dpart) { for (int q = 0; q < RB; q++) s += dpart[(long)kk * RB + q]; if (blockIdx.x == 0) hcol[kk] = s; }
+    else s = hcol[kk];                            // several ranks: the sums were completed by the reduction callback
     h[kk] = s;
-    if (blockIdx.x == 0) hcol[kk] = s;
   }
   __syncthreads();
   double s = 0.0;
@@ -87,11 +89,12 @@ __global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double 
 // and 1 / h_{j+1,j} for the normalisation of the new basis vector.
 __global__ __launch_bounds__(RT) void k_givens(int j, int m, const double *__restrict__ npart, const double *__restrict__ hcol,
                                                double *__restrict__ H, double *__restrict__ cs, double *__restrict__ sn,
-                                               double *__restrict__ G, double *__restrict__ inv, double *__restrict__ res) {
+                                               double *__restrict__ G, double *__restrict__ inv, double *__restrict__ res,
+                                               const double *__restrict__ nsq) {
   __shared__ double sh[RT / 64];
-  const double ss = block_sum(npart[threadIdx.x], sh);
+  const double ss = npart ? block_sum(npart[threadIdx.x], sh) : 0.0;
   if (threadIdx.x != 0) return;
-  const double hnext = sqrt(ss);
+  const double hnext = sqrt(npart ? ss : nsq[0]);   // nsq: |w|^2 summed over the ranks by the reduction callback
   double *hc = H + (long)j * (m + 1);
   for (int i = 0; i <= j; i++) hc[i] = hcol[i];
   hc[j + 1] = hnext;
@@ -162,13 +165,16 @@ struct chebhip_fgmres {
   double *H = nullptr, *cs = nullptr, *sn = nullptr, *G = nullptr, *inv = nullptr;
   double *res = nullptr;            // pinned, written by the device: residual estimate after iteration j
   std::vector<hipEvent_t> ev;
+  chebhip_reduce_fn reduce = nullptr;   // several ranks: sums device doubles over the ranks, in place, stream-ordered
+  void *reduce_ctx = nullptr;
+  double *nsq = nullptr;                // device scalar for the reduced |w|^2
   int its = 0, reason = 0;
   double rnorm = 0.0, rnorm0 = 0.0;
 };
 
 extern "C" int chebhip_fgmres_destroy(chebhip_fgmres *k) {
   if (!k) return 0;
-  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->inv};
+  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->inv, k->nsq};
   for (double *p : dev) if (p) (void)hipFree(p);
   if (k->res) (void)hipHostFree(k->res);
   for (hipEvent_t e : k->ev) (void)hipEventDestroy(e);
@@ -201,6 +207,7 @@ extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) 
   KC(hipMalloc((void **)&k->sn, (size_t)m * sizeof(double)));
   KC(hipMalloc((void **)&k->G, (size_t)(m + 1) * (m + 2) * sizeof(double)));
   KC(hipMalloc((void **)&k->inv, sizeof(double)));
+  KC(hipMalloc((void **)&k->nsq, sizeof(double)));
   KC(hipHostMalloc((void **)&k->res, (size_t)(m + 2) * sizeof(double)));
   k->ev.assign(m, nullptr);
   for (int j = 0; j < m; j++) KC(hipEventCreateWithFlags(&k->ev[j], hipEventDisableTiming));
@@ -216,6 +223,15 @@ extern "C" int chebhip_fgmres_set_tolerances(chebhip_fgmres *k, double rtol, dou
   return 0;
 }
 
+// Vectors distributed over several ranks (each holds n local entries): every inner product is completed by
+// `reduce`, which must sum `count` device doubles over the ranks in place, ordered on the given stream
+// (ncclAllReduce).  NULL restores the single-rank behaviour.
+extern "C" int chebhip_fgmres_set_reduce(chebhip_fgmres *k, chebhip_reduce_fn reduce, void *ctx) {
+  if (!k) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  k->reduce = reduce; k->reduce_ctx = ctx;
+  return 0;
+}
+
 extern "C" int chebhip_fgmres_iterations(const chebhip_fgmres *k) { return k ? k->its : -1; }
 extern "C" double chebhip_fgmres_residual(const chebhip_fgmres *k) { return k ? k->rnorm : -1.0; }
 extern "C" int chebhip_fgmres_reason(const chebhip_fgmres *k) { return k ? k->reason : 0; }
@@ -223,7 +239,13 @@ extern "C" int chebhip_fgmres_reason(const chebhip_fgmres *k) { return k ? k->re
 // |v| on the device, result to the host (synchronises the stream)
 static int dev_norm(chebhip_fgmres *k, const double *v, hipStream_t st, double *out) {
   hipLaunchKernelGGL(k_multidot, dim3(RB, 1), dim3(RT), 0, st, k->n, v, k->ld, v, k->npart);
-  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->res + k->m);
+  if (!k->reduce) hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->res + k->m, 1);
+  else {
+    hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->nsq, 0);
+    int rc = k->reduce(k->reduce_ctx, k->nsq, 1, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_sqrt1, dim3(1), dim3(1), 0, st, k->nsq);
+    KHIPCHK(hipMemcpyAsync(k->res + k->m, k->nsq, sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   KHIPCHK(hipStreamSynchronize(st));
   *out = k->res[k->m];
   return 0;
@@ -280,8 +302,19 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       double *w = k->V + (long)(j + 1) * ld;
       if ((rc = A(actx, zj, w, st))) return rc;
       hipLaunchKernelGGL(k_multidot, dim3(RB, j + 1), dim3(RT), 0, st, n, (const double *)k->V, ld, (const double *)w, k->part);
-      hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
-      hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res);
+      if (!k->reduce) {
+        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
+        hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
+                           (const double *)nullptr);
+      } else {            // several ranks: local sums -> all-reduce -> update; the same for |w|^2
+        hipLaunchKernelGGL(k_rows_finish, dim3(j + 1), dim3(RT), 0, st, (const double *)k->part, k->hcol, 0);
+        if ((rc = k->reduce(k->reduce_ctx, k->hcol, j + 1, st))) return rc;
+        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)nullptr, k->hcol, w, k->npart);
+        hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->nsq, 0);
+        if ((rc = k->reduce(k->reduce_ctx, k->nsq, 1, st))) return rc;
+        hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)nullptr, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
+                           (const double *)k->nsq);
+      }
       hipLaunchKernelGGL(k_scale_dev, dim3(pgrid(n)), dim3(256), 0, st, n, (const double *)k->inv, w);
       KHIPCHK(hipEventRecord(k->ev[j], st));
       enq = j + 1;

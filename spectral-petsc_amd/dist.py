@@ -233,7 +233,7 @@ class DistStokesOp:
     def _to_pencil(self, nf, inp):
         """nf slab fields at device address inp -> self.pen_in as (nf, P0, m1, R)."""
         r, P1, R = self.rank, self.dims[1], self.R
-        src = _view(inp, nf * self.Ns, self.device)
+        src = self.sp.device_view(inp, nf * self.Ns)
         for f in range(nf):
             self.sp.slab_pack(src[f * self.Ns:(f + 1) * self.Ns], self.sendbuf[f * self.Ns:(f + 1) * self.Ns], self.m0[r], P1, R, self.s1)
         sends, recvs = [], []
@@ -258,8 +258,8 @@ class DistStokesOp:
             off = self.m0[r] * self.s1[s] * R
             recvs.append([self.recvbuf[f * self.Ns + off: f * self.Ns + off + blk] for f in range(nf)])
         self._exchange(sends, recvs)
-        dst = _view(out, nf * self.Ns, self.device)
-        accv = _view(acc, nf * self.Ns, self.device) if acc else None
+        dst = self.sp.device_view(out, nf * self.Ns)
+        accv = self.sp.device_view(acc, nf * self.Ns) if acc else None
         for f in range(nf):
             sl = slice(f * self.Ns, (f + 1) * self.Ns)
             self.sp.slab_unpack_add(self.recvbuf[sl], accv[sl] if accv is not None else None, dst[sl], self.m0[r], P1, R, self.s1, alpha)
@@ -292,13 +292,3 @@ class DistStokesOp:
 
     def destroy(self):
         self.op.destroy()
-
-
-def _view(ptr, n, device):
-    """A float64 tensor over n doubles of device memory owned by the operator handle (no copy)."""
-    import ctypes
-    class _Arr:
-        pass
-    a = _Arr()
-    a.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
-    return torch.as_tensor(a, device=device)

@@ -98,3 +98,50 @@ def test_slab_ranks_match_oracle(world, dims):
     ref_m = orc.stokes_mult(dims, x, eta, deta, strain, mode=orc.DIRECT)
     assert yf.size == g
     assert relerr(yf, ref_f) < 1e-9 and relerr(ym, ref_m) < 1e-9
+
+
+# ---- Krylov on slabs: the solver's inner products become all-reduces -----------------------------
+def _solve_worker(rank, world, port, dims, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = ge.load(); dsp = ge.load_dist()
+        op = dsp.DistPoissonOp(dims, backend=dsp.HipBackend(sp))
+        G = int(np.prod([v - 2 for v in dims]))
+        b = np.random.default_rng(SEED).standard_normal(G)
+        inner = G // (dims[0] - 2)
+        lo, hi = int(op.s0[rank]) * inner, int(op.s0[rank + 1]) * inner
+        bl = torch.from_numpy(b[lo:hi].copy()).cuda(); xl = torch.empty_like(bl)
+        ks = sp.Fgmres(op.local_size, restart=60, rtol=1e-11, max_it=3000)
+        ks.set_reduce()
+        ks.solve(lambda x, y: op.mult(x, y), bl, xl)
+        torch.cuda.synchronize()
+        q.put((rank, lo, xl.cpu().numpy(), ks.iterations, ks.reason))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, (10, 9, 8)), (3, (12, 11))], ids=str)
+def test_distributed_poisson_solve(world, dims):
+    """FGMRES with all-reduced inner products around the slab matvec: x = A^{-1} b as on one rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_solve_worker, args=(r, world, port, dims, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[1])
+    x = np.concatenate([r[2] for r in res])
+    assert all(r[4] == 2 for r in res) and len({r[3] for r in res}) == 1      # same decisions on every rank
+    G = x.size
+    A = np.empty((G, G)); e = np.zeros(G)
+    for j in range(G):
+        e[j] = 1.0; A[:, j] = orc.elliptic_mult(dims, e, mode=orc.DIRECT); e[j] = 0.0
+    b = np.random.default_rng(SEED).standard_normal(G)
+    assert np.linalg.norm(b - A @ x) <= 1e-10 * np.linalg.norm(b)
+    assert np.linalg.norm(x - np.linalg.solve(A, b)) <= 1e-7 * np.linalg.norm(x)
