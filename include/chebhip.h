@@ -128,6 +128,16 @@ int ell_op_get_state(ell_op *op, int which, double *dst_host);
 /* Overwrites operator state from the host (same `which` codes). */
 int ell_op_set_state(ell_op *op, int which, const double *src_host);
 
+/* Slab mode for the multi-GPU path (no counterpart in the serial reference): the handle owns the planes
+ * [lo, hi) of grid dimension 0 and its vectors are the serial ones restricted to the slab (contiguous pieces).
+ * Sweeps along dimension 0 are delegated: dim0(ctx, 0, 1, in, NULL, alpha, out, stream) must produce
+ * out = alpha * D_0 in for one slab field (transpose -> ell_op_pencil_sweep on (dims[0], ncol) -> transpose).
+ * ell_op_mult / ell_op_function / set_* / get_state work unchanged on the slab, for any coefficient state. */
+typedef int (*ell_dim0_fn)(void *ctx, int kind, int nfields, const double *in_dev, const double *acc_dev,
+                           double alpha, double *out_dev, void *stream);
+int ell_op_create_slab(int d, const int *dims, int lo, int hi, ell_dim0_fn dim0, void *dim0_ctx, ell_op **out);
+int ell_op_pencil_sweep(ell_op *op, long ncol, const double *in_dev, double *out_dev, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Operator level: the Stokes MatShells (StokesCtx stokes.C:40-65,             */
 /* StokesCreate :257-344) with -boundary 0: every boundary node is a velocity  */

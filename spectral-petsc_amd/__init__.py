@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "ell_op_create", "ell_op_destroy", "ell_op_local_size", "ell_op_global_size",
     "ell_op_dirichlet_size", "ell_op_mult", "ell_op_mult_host", "ell_op_function",
     "ell_op_function_host", "ell_op_set_dirichlet", "ell_op_get_state", "ell_op_set_state",
+    "ell_op_create_slab", "ell_op_pencil_sweep",
     "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
     "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
     "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
@@ -84,6 +85,8 @@ def lib():
         L.cheb_plan_size.restype = C.c_long
         L.ell_op_create.argtypes = [C.c_int, ip, C.POINTER(vp)]
         L.ell_op_destroy.argtypes = [vp]
+        L.ell_op_create_slab.argtypes = [C.c_int, ip, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
+        L.ell_op_pencil_sweep.argtypes = [vp, C.c_long, vp, vp, vp]
         for f in (L.ell_op_local_size, L.ell_op_global_size, L.ell_op_dirichlet_size):
             f.argtypes = [vp]
             f.restype = C.c_long
@@ -244,13 +247,34 @@ def slab_unpack_add(buf, acc, out, m0, M1, R, c1, alpha=1.0):
     return out
 
 
+DIM0_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p)
+
+
+def _dim0_trampoline(dim0):
+    def tramp(ctx, kind, nf, inp, acc, alpha, out, stream):
+        try:
+            return int(dim0(kind, nf, inp, acc, alpha, out, stream) or 0)
+        except Exception:                      # never unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 5
+    return DIM0_FN(tramp)
+
+
 class EllipticOp:
     """The scalar elliptic MatShell (MatCreate_Elliptic, elliptic.C:250-293)."""
 
-    def __init__(self, dims):
+    def __init__(self, dims, slab=None, dim0=None):
+        """slab = (lo, hi): the planes [lo, hi) of grid dimension 0 (ell_op_create_slab); dim0 is then the Python
+        callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the sweeps along dim 0."""
         self.dims = tuple(int(d) for d in dims)
         h = C.c_void_p()
-        _chk(lib().ell_op_create(len(self.dims), _ints(self.dims), C.byref(h)))
+        if slab is None:
+            _chk(lib().ell_op_create(len(self.dims), _ints(self.dims), C.byref(h)))
+        else:
+            self._cb = _dim0_trampoline(dim0)           # keep the trampoline alive as long as the handle
+            _chk(lib().ell_op_create_slab(len(self.dims), _ints(self.dims), int(slab[0]), int(slab[1]),
+                                          C.cast(self._cb, C.c_void_p), None, C.byref(h)))
         self._h = h
         self.local_size = lib().ell_op_local_size(h)
         self.global_size = lib().ell_op_global_size(h)
@@ -260,6 +284,10 @@ class EllipticOp:
         """MatMult_Elliptic (elliptic.C:297-339) on device tensors of global_size."""
         _chk(lib().ell_op_mult(self._h, _dev_ptr(U, self.global_size), _dev_ptr(V, self.global_size), _stream()))
         return V
+
+    def pencil_sweep(self, ncol, inp, out):
+        _chk(lib().ell_op_pencil_sweep(self._h, ncol, inp.data_ptr(), out.data_ptr(), _stream()))
+        return out
 
     def mult_host(self, U):
         import numpy as np
@@ -323,8 +351,6 @@ class StokesOp:
     mult <-> StokesMatMult (stokes.C:499-519); mult_vv / mult_pv / mult_vp <-> MatVV / MatPV / MatVP
     (:623-676, :557-566, :599-619); function <-> StokesFunction (:680-758)."""
 
-    DIM0_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p)
-
     def __init__(self, dims, slab=None, dim0=None):
         """slab = (lo, hi): the planes [lo, hi) of grid dimension 0 (stokes_op_create_slab); dim0 is then the Python
         callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the work along dim 0."""
@@ -334,14 +360,7 @@ class StokesOp:
         if slab is None:
             _chk(lib().stokes_op_create(self.d, _ints(self.dims), C.byref(h)))
         else:
-            def tramp(ctx, kind, nf, inp, acc, alpha, out, stream):
-                try:
-                    return int(dim0(kind, nf, inp, acc, alpha, out, stream) or 0)
-                except Exception:                      # never unwind through the C frames
-                    import traceback
-                    traceback.print_exc()
-                    return 5
-            self._cb = StokesOp.DIM0_FN(tramp)          # keep the trampoline alive as long as the handle
+            self._cb = _dim0_trampoline(dim0)           # keep the trampoline alive as long as the handle
             _chk(lib().stokes_op_create_slab(self.d, _ints(self.dims), int(slab[0]), int(slab[1]),
                                              C.cast(self._cb, C.c_void_p), None, C.byref(h)))
         self._h = h

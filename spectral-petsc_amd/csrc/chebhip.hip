@@ -296,6 +296,17 @@ __global__ void k_cprod(long N, const double *__restrict__ eta, const double *__
     ec[i] = make_double2(eta[i], deta[i] * du[i]);
 }
 
+// f = eta * g (+ deta * u * du0): the pointwise flux of elliptic.C:319-323 / :511 as a pass of its own (slab mode,
+// where the divergence sweep along dimension 0 takes a plain array); in place on g
+__global__ void k_flux(long N, const double *__restrict__ eta, const double *__restrict__ deta, const double *__restrict__ u,
+                       const double *__restrict__ du0, double *__restrict__ g) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    double f = eta[i] * g[i];
+    if (deta) f = f + deta[i] * u[i] * du0[i];
+    g[i] = f;
+  }
+}
+
 __global__ void k_fill(long N, double v, double *__restrict__ a) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) a[i] = v;
 }
@@ -327,6 +338,12 @@ struct ell_op {
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
+  // slab mode (multi-GPU): the handle owns the planes [lo, lo + dims[0]) of a grid whose dimension 0 has
+  // gP0 points; sweeps along dimension 0 go through `dim0` (transposes + pencil sweep in the driver)
+  bool slab = false;
+  int gP0 = 0, lo = 0;
+  ell_dim0_fn dim0 = nullptr;
+  void *dim0_ctx = nullptr;
   bool has_long = false;                // some extent > 256: every sweep goes through the unfused path (cheb_sweep_long_kernel)
   std::vector<double *> cprod;          // pairs {eta, deta * gradu[k]} (2N doubles): what the Jacobian apply reads, refreshed when the state changes
   bool cdirty = true;
@@ -356,42 +373,69 @@ static int ell_alloc_state(ell_op *op) {
   return 0;
 }
 
-extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
+static inline bool ell_is_bdy(const ell_op *op, const int *ind) {
+  const int g0 = ind[0] + op->lo;
+  if (g0 == 0 || g0 == op->gP0 - 1) return true;
+  for (int j = 1; j < op->d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) return true;
+  return false;
+}
+
+static int ell_create(int d, const int *gdims, int lo, int hi, ell_dim0_fn dim0, void *dim0_ctx, ell_op **out) {
   if (!out) return fail(CHEBHIP_ERR_ARG, "out is NULL");
   *out = nullptr;
+  const bool slab = dim0 != nullptr;
+  if (slab && (!gdims || d < 2)) return fail(CHEBHIP_ERR_DIMS, "slab mode needs d >= 2");
+  std::vector<int> dimv;
+  if (gdims && d >= 1 && d <= 10) {
+    dimv.assign(gdims, gdims + d);
+    if (slab) {
+      if (!(0 <= lo && lo < hi && hi <= gdims[0])) return fail(CHEBHIP_ERR_ARG, "slab planes [%d, %d) outside 0..%d", lo, hi, gdims[0]);
+      if (gdims[0] < 3) return fail(CHEBHIP_ERR_SIZE, "slab mode needs dims[0] >= 3");
+      dimv[0] = hi - lo;
+    } else lo = 0;
+  }
+  const int *dims = dimv.empty() ? gdims : dimv.data();
   if (!dims || d < 1 || d > 10) return fail(CHEBHIP_ERR_DIMS, "d = %d must be in 1..10 (elliptic.C:137)", d);
   long N = 1, G = 1;
   for (int k = 0; k < d; k++) {
     long nk; unsigned ik;
-    int rc = check_geom(d, k, dims, &nk, &ik, true);
+    int rc = check_geom(d, k, gdims, &nk, &ik, true);
     if (rc) return rc;
-    N *= dims[k]; G *= (dims[k] > 2 ? dims[k] - 2 : 0);
+    N *= dims[k];
+    if (!(slab && k == 0)) G *= (dims[k] > 2 ? dims[k] - 2 : 0);
+  }
+  long nint0 = 0;                                       // interior planes of dimension 0 owned by this handle
+  if (slab) {
+    for (int i = lo; i < hi; i++) if (i > 0 && i < gdims[0] - 1) nint0++;
+    G *= nint0;
+    if (N > 0x7fffffffL) return fail(CHEBHIP_ERR_DIMS, "tensor of more than 2^31-1 points");
   }
   int rc = require_device();
   if (rc) return rc;
   ell_op *op = new (std::nothrow) ell_op;
   if (!op) return fail(CHEBHIP_ERR_MEMORY, "out of host memory");
   op->d = d; op->dims.assign(dims, dims + d); op->N = N; op->G = G;
+  op->slab = slab; op->gP0 = gdims[0]; op->lo = lo; op->dim0 = dim0; op->dim0_ctx = dim0_ctx;
   // from here on failures go through ell_op_destroy
 #define OPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ell_op_destroy(op); \
     return fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-  for (int k = 0; k < d; k++)
-    if (!op->mats.count(dims[k])) {
-      DiffMat m; OPCHK(diffmat_create(dims[k], &m)); op->mats[dims[k]] = m;
-      if (dims[k] > 256) op->has_long = true;
-      else if (dims[k] > 2) { DiffMat l; OPCHK(diffmat_create_lap(dims[k], &l)); op->laps[dims[k]] = l; }
+  for (int k = 0; k < d; k++) {      // dimension 0: the global extent (in slab mode it is applied on pencils)
+    const int Pk = (k == 0) ? gdims[0] : dims[k];
+    if (!op->mats.count(Pk)) {
+      DiffMat m; OPCHK(diffmat_create(Pk, &m)); op->mats[Pk] = m;
+      if (Pk > 256) op->has_long = true;
+      else if (Pk > 2 && !slab) { DiffMat l; OPCHK(diffmat_create_lap(Pk, &l)); op->laps[Pk] = l; }
     }
+  }
   // SetupBC (elliptic.C:372-434): ixL in BlockIt order; interior strides of the global vector
   std::vector<long> gs(d, 1);
-  for (int k = d - 2; k >= 0; k--) gs[k] = gs[k + 1] * (dims[k + 1] - 2);
+  for (int k = d - 2; k >= 0; k--) gs[k] = gs[k + 1] * (dims[k + 1] - 2);    // dims[k+1], k+1 >= 1: never the split dimension
   {
     std::vector<int> ixL((size_t)N);
     std::vector<int> ind(d, 0);
     long g = 0;
     for (long l = 0; l < N; l++) {
-      bool bdy = false;
-      for (int j = 0; j < d; j++) if (ind[j] == 0 || ind[j] == dims[j] - 1) bdy = true;
-      ixL[l] = bdy ? -1 : (int)g++;
+      ixL[l] = ell_is_bdy(op, ind.data()) ? -1 : (int)g++;
       for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
     }
     OPCHK(hipMalloc((void **)&op->ixL, (size_t)N * sizeof(int)));
@@ -401,7 +445,7 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
   op->inner_g.resize(d); op->ncols_g.resize(d);
   for (int k = 0; k < d; k++) {
     op->inner_g[k] = (unsigned)gs[k];
-    op->ncols_g[k] = dims[k] > 2 ? (unsigned)(G / (dims[k] - 2)) : 0u;
+    op->ncols_g[k] = (dims[k] > 2 && !slab) ? (unsigned)(G / (dims[k] - 2)) : 0u;
   }
   for (int k = 0; k < d; k++) {
     unsigned in = 1; for (int r = k + 1; r < d; r++) in *= dims[r];
@@ -411,12 +455,14 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
     std::vector<int> ind(d, 0);
     for (unsigned c = 0; c < op->ncols[k]; c++) {
       bool interior = true; long gi = 0;
+      const int off0 = (lo == 0) ? 1 : 0;               // local plane of the first interior plane of this handle
       for (int r = 0; r < d; r++) {
         if (r == k) continue;
-        if (ind[r] == 0 || ind[r] == dims[r] - 1) interior = false;
-        gi += (long)(ind[r] - 1) * gs[r];
+        const int gr = ind[r] + (r == 0 ? lo : 0), Pr = (r == 0) ? gdims[0] : dims[r];
+        if (gr == 0 || gr == Pr - 1) interior = false;
+        gi += (long)(ind[r] - (r == 0 ? off0 : 1)) * gs[r];
       }
-      tab[c] = (interior && dims[k] > 2) ? (int)gi : -1;
+      tab[c] = (interior && dims[k] > 2 && !(slab && k == 0)) ? (int)gi : -1;
       for (int r = d - 1; r >= 0; r--) { if (r == k) continue; if (++ind[r] < dims[r]) break; ind[r] = 0; }
     }
     OPCHK(hipMalloc((void **)&op->gcol[k], tab.size() * sizeof(int)));
@@ -427,6 +473,26 @@ extern "C" int ell_op_create(int d, const int *dims, ell_op **out) {
   OPCHK(hipMalloc((void **)&op->W, (size_t)N * sizeof(double)));
 #undef OPCHK
   *out = op;
+  return 0;
+}
+
+extern "C" int ell_op_create(int d, const int *dims, ell_op **out) { return ell_create(d, dims, 0, 0, nullptr, nullptr, out); }
+
+// Slab of the planes [lo, hi) of grid dimension 0 (multi-GPU): vectors are the serial ones restricted to
+// the slab (contiguous pieces, dimension 0 being outermost); sweeps along dimension 0 are delegated to `dim0`.
+extern "C" int ell_op_create_slab(int d, const int *dims, int lo, int hi, ell_dim0_fn dim0, void *dim0_ctx, ell_op **out) {
+  if (!dim0) return fail(CHEBHIP_ERR_ARG, "slab mode needs the dimension-0 callback");
+  return ell_create(d, dims, lo, hi, dim0, dim0_ctx, out);
+}
+
+// Pencil side of the slab mode: out = D_0 in on an array (dims[0], ncol), lines along dimension 0 with stride ncol
+extern "C" int ell_op_pencil_sweep(ell_op *op, long ncol, const double *in, double *out, void *stream) {
+  if (!op || !in || !out || ncol < 0) return fail(CHEBHIP_ERR_ARG, "bad argument");
+  if (ncol == 0) return 0;
+  SweepParams sp = {};
+  sp.ncols = (unsigned)ncol; sp.inner = (unsigned)ncol;
+  sp.in0 = in; sp.in_mode = IN_PLAIN; sp.out = out; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+  HIPCHK(sweep_launch(op->mats[op->gP0], sp, (hipStream_t)stream));
   return 0;
 }
 
@@ -519,8 +585,51 @@ static int ell_mult_unfused(ell_op *op, const double *U, double *V, hipStream_t 
   return ell_divergence(op, IN_FLUX_FULL, op->g.data(), V, st);
 }
 
+// One sweep D_k of the slab mode: along dimension 0 through the driver, otherwise a local launch
+static int ell_slab_sweep(ell_op *op, int k, const double *x, double *y, hipStream_t st) {
+  if (k == 0) return op->dim0(op->dim0_ctx, 0, 1, x, nullptr, 1.0, y, st);
+  SweepParams sp = {};
+  sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+  sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+  HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  return 0;
+}
+
+// out_global = scatter( -sum_k D_k f_k ) in slab mode; f_k = flux(src[k]) is formed by a pointwise pass for k = 0
+// (the sweep along dimension 0 takes a plain array) and on load for the others.  mode: IN_PLAIN / IN_FLUX_ETA / IN_FLUX_FULL
+static int ell_slab_divergence(ell_op *op, int in_mode, double *const *src, double *out_global, hipStream_t st) {
+  const int d = op->d;
+  if (in_mode != IN_PLAIN)
+    hipLaunchKernelGGL(k_flux, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta,
+                       (const double *)(in_mode == IN_FLUX_FULL ? op->deta : nullptr), (const double *)op->w0,
+                       (const double *)(in_mode == IN_FLUX_FULL ? op->gradu[0] : nullptr), src[0]);
+  int rc = op->dim0(op->dim0_ctx, 0, 1, src[0], nullptr, -1.0, op->W, st);          // W = -D_0 f_0
+  if (rc) return rc;
+  for (int k = 1; k < d; k++) {
+    SweepParams sp = {};
+    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+    sp.in0 = src[k]; sp.in1 = op->eta; sp.in2 = op->deta; sp.in3 = op->w0;
+    sp.in4 = op->gradu.empty() ? nullptr : op->gradu[k];
+    sp.in_mode = in_mode; sp.alpha = -1.0;
+    if (k == d - 1) { sp.out_mode = OUT_ACC_SCATTER; sp.out = out_global; sp.acc = op->W; sp.gcol = op->gcol[k]; sp.gstride = op->gstride[k]; }
+    else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
+    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  }
+  return 0;
+}
+
+static int ell_mult_slab(ell_op *op, const double *U, double *V, hipStream_t st) {
+  int rc = ell_alloc_state(op); if (rc) return rc;                    // w0
+  hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U, (const double *)nullptr, op->w0);
+  for (int k = 0; k < op->d; k++) if ((rc = ell_slab_sweep(op, k, op->w0, op->g[k], st))) return rc;
+  // a rank without interior nodes still takes part in the exchanges of the others
+  if (op->G == 0) return op->dim0(op->dim0_ctx, 0, 1, op->g[0], nullptr, -1.0, op->W, st);
+  return ell_slab_divergence(op, op->mode == COEFF_UNIT ? IN_PLAIN : IN_FLUX_FULL, op->g.data(), V, st);
+}
+
 extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
   if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (op->slab) return ell_mult_slab(op, U, V, (hipStream_t)stream);
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (use_unfused() || op->has_long) return ell_mult_unfused(op, U, V, st);
@@ -581,6 +690,19 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
   // eta stays exactly 1 and deta exactly 0 only when gamma == 0 and no pow() can produce inf/nan
   const bool unit = (gamma == 0.0) && (exponent == std::floor(exponent)) && exponent >= 1.0;
   op->mode = unit ? COEFF_UNIT : COEFF_FULL;
+  if (op->slab) {
+    for (int k = 0; k < d; k++) if ((rc = ell_slab_sweep(op, k, op->w0, op->gradu[k], st))) return rc;     // :497-499
+    // w_k = eta * gradu[k] (:511): dimension 0 needs it as an array (g[0]); the others form it on load
+    HIPCHK(hipMemcpyAsync(op->g[0], op->gradu[0], (size_t)op->N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    std::vector<double *> src(op->gradu); src[0] = op->g[0];
+    if (op->G == 0) { hipLaunchKernelGGL(k_flux, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta, (const double *)nullptr,
+                                         (const double *)nullptr, (const double *)nullptr, src[0]);
+                      return op->dim0(op->dim0_ctx, 0, 1, src[0], nullptr, -1.0, op->W, st); }
+    if ((rc = ell_slab_divergence(op, IN_FLUX_ETA, src.data(), rhs, st))) return rc;
+    if (b) hipLaunchKernelGGL(k_axpy, dim3(pw_grid(op->G)), dim3(256), 0, st, op->G, -1.0, b, rhs);  // :530
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (use_unfused() || op->has_long) {
     for (int k = 0; k < d; k++) {                                               // gradu[k] = D_k w0 (:497-499)
       SweepParams sp = {};
@@ -645,9 +767,7 @@ extern "C" int ell_op_set_dirichlet(ell_op *op, const double *values) {
   std::vector<int> ind(op->d, 0);
   long dd = 0;
   for (long l = 0; l < op->N; l++) {
-    bool bdy = false;
-    for (int j = 0; j < op->d; j++) if (ind[j] == 0 || ind[j] == op->dims[j] - 1) bdy = true;
-    if (bdy) loc[l] = values[dd++];
+    if (ell_is_bdy(op, ind.data())) loc[l] = values[dd++];
     for (int j = op->d - 1; j >= 0; j--) { if (++ind[j] < op->dims[j]) break; ind[j] = 0; }
   }
   if (!op->dirloc) HIPCHK(hipMalloc((void **)&op->dirloc, (size_t)op->N * sizeof(double)));

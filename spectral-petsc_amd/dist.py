@@ -149,24 +149,17 @@ class DistPoissonOp:
         return V
 
 
-class DistStokesOp:
-    """The Stokes callbacks (StokesMatMult, StokesFunction and the MatVV / MatPV / MatVP blocks) on a grid whose
-    dimension 0 is split into slabs of planes, one per rank.
+class _SlabPencil:
+    """Slab <-> pencil machinery shared by the slab-mode drivers: the grid's dimension 0 is split into slabs of
+    planes, one per rank; work along dimension 0 is done on pencils (all planes, a share of dimension 1):
 
-    Each rank owns a slab-mode operator handle (stokes_op_create_slab): gathers, node loops, sweeps along
-    dimensions 1.., pressure extrapolation along them and the final scatter are local launches on the slab.
-    Whatever runs along dimension 0 -- DV[0] / DP[0] and the x-line pressure extrapolation -- comes back to this
-    class through the handle's callback and is done on pencils (all planes, a share of dimension 1):
-
-        slab fields --pack, exchange--> pencil fields --stokes_op_pencil_*--> pencil result --exchange, unpack--> slab
+        slab fields --pack, exchange--> pencil fields --pencil launch--> pencil result --exchange, unpack--> slab
 
     One exchange moves all fields of a call as a single batch of point-to-point messages (RCCL groups them into
-    one launch).  Per StokesMatMult: gradient (d fields there and back), stress divergence (d fields there and
-    back), pressure (1 field there and back).  Vector layouts per rank are the serial ones restricted to the
-    slab: contiguous pieces of the serial vectors, dimension 0 being outermost.
-    """
+    one launch).  The full local grid (boundary planes included) is split: Dirichlet rows and, for Stokes, the
+    pressure end points take part in the sweeps."""
 
-    def __init__(self, dims, sp, group=None):
+    def _setup(self, dims, sp, group, nf_max):
         self.sp = sp
         self.dims = tuple(int(v) for v in dims)
         d = self.d = len(self.dims)
@@ -181,18 +174,14 @@ class DistStokesOp:
         self.s0 = [int(v) for v in np.concatenate([[0], np.cumsum(self.m0)])]
         self.s1 = [int(v) for v in np.concatenate([[0], np.cumsum(self.m1)])]
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.op = sp.StokesOp(self.dims, slab=(self.s0[r], self.s0[r + 1]), dim0=self._dim0)
         self.Ns = self.m0[r] * P1 * self.R                     # nodes of the slab
         self.ncol = self.m1[r] * self.R                        # lines of the pencil
         self.Np = P0 * self.ncol
-        nf = d
         z = lambda n: torch.empty(n, dtype=torch.float64, device=self.device)
-        self.sendbuf, self.recvbuf = z(nf * self.Ns), z(nf * self.Ns)
-        self.pen_in, self.pen_out = z(nf * self.Np), z(nf * self.Np)
-        for name in ("global_size", "velocity_size", "pressure_size", "dirichlet_size", "local_nodes", "interior_nodes"):
-            setattr(self, name, getattr(self.op, name))
+        self.sendbuf, self.recvbuf = z(nf_max * self.Ns), z(nf_max * self.Ns)
+        self.pen_in, self.pen_out = z(nf_max * self.Np), z(nf_max * self.Np)
 
-    # where this rank's pieces sit in the serial vectors (dimension 0 outermost => contiguous)
+    # where this rank's pieces sit in the serial vectors (dimension 0 outermost => contiguous): node ranges
     def serial_ranges(self):
         inner_int = int(np.prod([v - 2 for v in self.dims[1:]]))
         inner_all = int(np.prod(self.dims[1:]))
@@ -207,14 +196,12 @@ class DistStokesOp:
     # ---- exchanges: every field of a call in one batch of point-to-point messages ------------------------------
     def _exchange(self, sends, recvs):
         """sends / recvs: per peer s a list of contiguous tensors (views)."""
+        for a, b in zip(sends[self.rank], recvs[self.rank]):       # own block: no message
+            b.copy_(a)
         if self.G == 1:
-            for a, b in zip(sends[0], recvs[0]):
-                b.copy_(a)
             return
         staged = sends[0][0].is_cuda and dist.get_backend(self.group) == "gloo"      # rehearsal: several ranks on one GPU
         ops, back = [], []
-        for a, b in zip(sends[self.rank], recvs[self.rank]):       # own block: no message
-            b.copy_(a)
         for s in range(self.G):
             if s == self.rank:
                 continue
@@ -270,14 +257,58 @@ class DistStokesOp:
     def _dim0(self, kind, nf, inp, acc, alpha, out, stream):
         # the handle's launches and ours share torch's current stream (the callers pass it down)
         self._to_pencil(nf, inp)
+        self._pencil(kind, nf)
+        self._to_slab(nf, acc, alpha, out)
+        return 0
+
+    def destroy(self):
+        self.op.destroy()
+
+
+class DistEllipticOp(_SlabPencil):
+    """MatMult_Elliptic and FormFunction (elliptic.C:297-339, 481-533) for ANY coefficient state on slabs of planes
+    (SURVEY 8e).  Each rank owns a slab-mode handle (ell_op_create_slab); per callback the gradient and the
+    divergence along dimension 0 each make one round trip to pencils (4 exchanges), everything else is local.
+    For the linear state DistPoissonOp above needs only 2 exchanges and one fused launch per direction; this class
+    is the general path (nonlinear residuals and Jacobians)."""
+
+    def __init__(self, dims, sp, group=None):
+        self._setup(dims, sp, group, 1)
+        r = self.rank
+        self.op = sp.EllipticOp(self.dims, slab=(self.s0[r], self.s0[r + 1]), dim0=self._dim0)
+        self.global_size, self.dirichlet_size, self.local_size = self.op.global_size, self.op.dirichlet_size, self.op.local_size
+
+    def _pencil(self, kind, nf):
+        self.op.pencil_sweep(self.ncol, self.pen_in, self.pen_out)
+
+    def mult(self, U, V):
+        return self.op.mult(U, V)
+
+    def function(self, U, b, rhs, gamma=0.0, exponent=2.0):
+        return self.op.function(U, b, rhs, gamma, exponent)
+
+
+class DistStokesOp(_SlabPencil):
+    """The Stokes callbacks (StokesMatMult, StokesFunction and the MatVV / MatPV / MatVP blocks) on slabs of planes
+    (SURVEY 8e).  Each rank owns a slab-mode handle (stokes_op_create_slab): gathers, node loops, sweeps along
+    dimensions 1.., pressure extrapolation along them and the final scatter are local launches on the slab;
+    DV[0] / DP[0] and the x-line pressure extrapolation come back here through the handle's callback.
+    Per StokesMatMult: gradient (d fields there and back), stress divergence (d fields there and back), pressure
+    (1 field there and back)."""
+
+    def __init__(self, dims, sp, group=None):
+        self._setup(dims, sp, group, len(dims))
+        r = self.rank
+        self.op = sp.StokesOp(self.dims, slab=(self.s0[r], self.s0[r + 1]), dim0=self._dim0)
+        for name in ("global_size", "velocity_size", "pressure_size", "dirichlet_size", "local_nodes", "interior_nodes"):
+            setattr(self, name, getattr(self.op, name))
+
+    def _pencil(self, kind, nf):
         if kind == 0:
             self.op.pencil_sweep(nf, self.ncol, self.pen_in, self.pen_out)
         else:
             self.op.pencil_pressure(self.ncol, self.pen_in, self.pen_out)
-        self._to_slab(nf, acc, alpha, out)
-        return 0
 
-    # ---- the callbacks, on this rank's pieces of the vectors ---------------------------------------------------
     def mult(self, x, y):
         return self.op.mult(x, y)
 
@@ -292,6 +323,3 @@ class DistStokesOp:
 
     def mult_vp(self, p, vout):
         return self.op.mult_vp(p, vout)
-
-    def destroy(self):
-        self.op.destroy()

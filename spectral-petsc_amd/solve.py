@@ -10,15 +10,18 @@ import torch
 
 
 def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50,
-                  ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000, M=None, monitor=None):
-    """Solve FormFunction(x) = A(x) x - b = 0 in place in x (device tensor).  Returns (newton_its, total_ksp_its, |F|)."""
+                  ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000, M=None, monitor=None, norm=None):
+    """Solve FormFunction(x) = A(x) x - b = 0 in place in x (device tensor).  Returns (newton_its, total_ksp_its, |F|).
+    On several ranks (vectors = this rank's pieces) `op` is a callable driver of dist.py, `sp.Fgmres` must return a
+    solver with its reduction set, and `norm` the global 2-norm."""
     n = op.global_size
+    norm = norm or (lambda t: float(t.norm()))
     F = torch.empty_like(x)
     dx = torch.empty_like(x)
     ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
     total = 0
     op.function(x, b, F, gamma, exponent)
-    f0 = fn = float(F.norm())
+    f0 = fn = norm(F)
     it = 0
     try:
         while it < snes_max_it and fn > max(snes_rtol * f0, snes_atol):
@@ -27,7 +30,7 @@ def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_at
             total += ks.iterations
             x.add_(dx)
             op.function(x, b, F, gamma, exponent)
-            fn = float(F.norm())
+            fn = norm(F)
             it += 1
             if monitor:
                 monitor(it, fn, ks.iterations)

@@ -145,3 +145,97 @@ def test_distributed_poisson_solve(world, dims):
     b = np.random.default_rng(SEED).standard_normal(G)
     assert np.linalg.norm(b - A @ x) <= 1e-10 * np.linalg.norm(b)
     assert np.linalg.norm(x - np.linalg.solve(A, b)) <= 1e-7 * np.linalg.norm(x)
+
+
+# ---- the general (variable-coefficient) elliptic operator on slabs -------------------------------------------
+@pytest.mark.parametrize("dims", [(14, 12), (10, 9, 8), (20, 33, 6), (7, 6, 5, 4)], ids=lambda s: "x".join(map(str, s)))
+def test_elliptic_single_rank_matches_serial_operator(dims):
+    sp = ge.load(); dsp = ge.load_dist()
+    ser = sp.EllipticOp(dims); par = dsp.DistEllipticOp(dims, sp)
+    assert par.global_size == ser.global_size and par.dirichlet_size == ser.dirichlet_size
+    rng = np.random.default_rng(SEED)
+    u = dev(rng.random(ser.global_size) + 0.5); b = dev(rng.standard_normal(ser.global_size))
+    dv = rng.random(ser.dirichlet_size) + 0.5
+    ser.set_dirichlet(dv); par.op.set_dirichlet(dv)
+    x = dev(rng.standard_normal(ser.global_size))
+    r1, r2 = torch.empty_like(u), torch.empty_like(u)
+    ser.mult(x, r1); par.mult(x, r2)                                    # linear state
+    assert relerr(r2.cpu().numpy(), r1.cpu().numpy()) < 1e-12
+    ser.function(u, b, r1, 1.5, 3.0); par.function(u, b, r2, 1.5, 3.0)
+    assert relerr(r2.cpu().numpy(), r1.cpu().numpy()) < 1e-12
+    ser.mult(x, r1); par.mult(x, r2)                                    # Jacobian at the nonlinear state
+    assert relerr(r2.cpu().numpy(), r1.cpu().numpy()) < 1e-12
+    ser.destroy(); par.destroy()
+
+
+def _ell_worker(rank, world, port, dims, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = ge.load(); dsp = ge.load_dist()
+        from importlib import import_module
+        solve = import_module(sp.__name__ + ".solve")
+        op = dsp.DistEllipticOp(dims, sp)
+        (n0, n1), (b0, b1) = op.serial_ranges()
+        u, u2, dv = orc.elliptic_exact(dims, 0, gamma=4.0, exponent=2.0, cos_scale=3.0)
+        op.op.set_dirichlet(dv[b0:b1])
+        rng = np.random.default_rng(SEED)
+        xs = rng.random(u.size) + 0.5; bs = rng.standard_normal(u.size); vs = rng.standard_normal(u.size)
+        xl, bl, vl = (torch.from_numpy(a[n0:n1].copy()).cuda() for a in (xs, bs, vs))
+        rf, rm = torch.empty_like(xl), torch.empty_like(xl)
+        op.function(xl, bl, rf, 4.0, 2.0)
+        op.mult(vl, rm)
+        # the reference's acceptance test on slabs: Newton + FGMRES with all-reduced inner products, from x = 0
+        b = torch.from_numpy(u2[n0:n1].copy()).cuda(); x = torch.zeros_like(b)
+
+        class Shim:                       # what solve.newton_krylov needs from `sp` and the operator
+            @staticmethod
+            def Fgmres(n, **kw):
+                ks = sp.Fgmres(n, **kw); ks.set_reduce(); return ks
+        opshim = type("O", (), {"global_size": op.global_size, "function": staticmethod(op.function), "__call__": lambda self, a, y: op.mult(a, y)})()
+        G = int(np.prod([v - 2 for v in dims]))
+
+        def gnorm(t):
+            s = (t * t).sum().cpu(); dist.all_reduce(s); return float(s.sqrt())
+        its, kits, fn = solve.newton_krylov(Shim, opshim, b, x, 4.0, 2.0, snes_rtol=1e-11, ksp_rtol=1e-12,
+                                            ksp_restart=min(256, G), ksp_max_it=20000, norm=gnorm)
+        torch.cuda.synchronize()
+        q.put((rank, n0, rf.cpu().numpy(), rm.cpu().numpy(), x.cpu().numpy(), its))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, (16, 16)), (3, (10, 9, 8))], ids=str)
+def test_elliptic_slab_ranks_match_oracle_and_solve(world, dims):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ell_worker, args=(r, world, port, dims, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[1])
+    rf = np.concatenate([r[2] for r in res]); rm = np.concatenate([r[3] for r in res]); x = np.concatenate([r[4] for r in res])
+    u, u2, dv = orc.elliptic_exact(dims, 0, gamma=4.0, exponent=2.0, cos_scale=3.0)
+    rng = np.random.default_rng(SEED)
+    xs = rng.random(u.size) + 0.5; bs = rng.standard_normal(u.size); vs = rng.standard_normal(u.size)
+    ref_f, eta, deta, gradu = orc.elliptic_function(dims, xs, bs, dv, 4.0, 2.0, mode=orc.DIRECT)
+    ref_m = orc.elliptic_mult(dims, vs, eta, deta, gradu, mode=orc.DIRECT)
+    assert relerr(rf, ref_f) < TOL and relerr(rm, ref_m) < TOL
+    # the distributed Newton-Krylov solve lands on the same discrete solution as a dense Newton on the oracle
+    n = u.size
+    xo = np.zeros(n)
+    for _ in range(15):
+        F, eta, deta, gradu = orc.elliptic_function(dims, xo, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
+        if np.linalg.norm(F) < 1e-13 * np.linalg.norm(u2):
+            break
+        J = np.empty((n, n)); e = np.zeros(n)
+        for j in range(n):
+            e[j] = 1.0; J[:, j] = orc.elliptic_mult(dims, e, eta, deta, gradu, mode=orc.DIRECT); e[j] = 0.0
+        xo = xo - np.linalg.solve(J, F)
+    assert len({r[5] for r in res}) == 1
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
