@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep against the CPU oracle (one-off hardening run, not part of the test-suite):
+random ranks, extents, directions and coefficient states for cheb_apply, the elliptic callbacks, the Stokes
+callbacks and the slab-mode drivers at one rank.  usage: fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import __graft_entry__ as ge
+import oracle_lib as orc
+sp = ge.load(); dsp = ge.load_dist()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+worst = {}
+def note(kind, e, what):
+    if e > worst.get(kind, (0, None))[0]:
+        worst[kind] = (e, what)
+    assert e < 1e-10, (kind, e, what)
+
+def rand_dims(rank, lo, hi, cap):
+    while True:
+        d = tuple(int(v) for v in rng.integers(lo, hi + 1, size=rank))
+        if np.prod(d) <= cap:
+            return d
+
+t0 = time.time(); n = 0
+while time.time() - t0 < budget:
+    kind = rng.integers(0, 5)
+    if kind == 0:        # ChebMult
+        rank = int(rng.integers(1, 5)); dims = rand_dims(rank, 2, 70 if rank > 1 else 300, 400000); tr = int(rng.integers(0, rank))
+        if dims[tr] < 2: continue
+        x = rng.standard_normal(dims)
+        plan = sp.ChebPlan(dims, tr); y = torch.empty(x.size, dtype=torch.float64, device="cuda")
+        plan.mult(dev(x.ravel()), y); plan.destroy()
+        note("cheb", rel(y.cpu().numpy().reshape(dims), orc.cheb_mult(x, tr, orc.FAST)), (dims, tr))
+    elif kind == 1:      # elliptic, linear + nonlinear
+        rank = int(rng.integers(1, 4)); dims = rand_dims(rank, 3, 48 if rank > 1 else 200, 120000)
+        op = sp.EllipticOp(dims)
+        U = rng.standard_normal(op.global_size)
+        note("ell-lin", rel(op.mult_host(U), orc.elliptic_mult(dims, U, mode=orc.FAST)), dims)
+        u = rng.random(op.global_size) + 0.5; b = rng.standard_normal(op.global_size); dv = rng.random(op.dirichlet_size) + 0.5
+        gam, ex = float(rng.random() * 3), float(rng.choice([1.0, 2.0, 3.0, 2.5]))
+        op.set_dirichlet(dv)
+        r = op.function_host(u, b, gam, ex)
+        ro, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, gam, ex, mode=orc.FAST)
+        note("ell-fn", rel(r, ro), (dims, gam, ex))
+        note("ell-jac", rel(op.mult_host(U), orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST)), (dims, gam, ex))
+        op.destroy()
+    elif kind == 2:      # Stokes
+        d = int(rng.integers(2, 4)); dims = rand_dims(d, 3, 40 if d == 2 else 22, 12000)
+        op = sp.StokesOp(dims)
+        power = (1, 1.0, float(rng.choice([1.0, 2.0, 3.0])), 10.0 ** -float(rng.integers(1, 5)), 1.0)
+        x = rng.standard_normal(op.global_size); dv = rng.standard_normal(op.dirichlet_size); f = rng.standard_normal(op.global_size)
+        op.set_rheology(*power); op.set_dirichlet(dv); op.set_force(f)
+        y = torch.empty(op.global_size, dtype=torch.float64, device="cuda")
+        op.function(dev(x), y)
+        yo, eta, deta, strain = orc.stokes_function(dims, x, dv, f, rheology=power, mode=orc.FAST)
+        note("st-fn", rel(y.cpu().numpy(), yo) / 10, (dims, power))          # 1e-9 bar (pressure extrapolation)
+        op.mult(dev(x), y)
+        note("st-mult", rel(y.cpu().numpy(), orc.stokes_mult(dims, x, eta, deta, strain, mode=orc.FAST)) / 10, (dims, power))
+        op.destroy()
+    elif kind == 3:      # slab-mode elliptic at one rank vs serial handle
+        rank = int(rng.integers(2, 4)); dims = rand_dims(rank, 3, 40, 60000)
+        ser = sp.EllipticOp(dims); par = dsp.DistEllipticOp(dims, sp)
+        u = dev(rng.random(ser.global_size) + 0.5); b = dev(rng.standard_normal(ser.global_size)); dv = rng.random(ser.dirichlet_size) + 0.5
+        ser.set_dirichlet(dv); par.op.set_dirichlet(dv)
+        r1, r2 = torch.empty_like(u), torch.empty_like(u)
+        ser.function(u, b, r1, 1.0, 2.0); par.function(u, b, r2, 1.0, 2.0)
+        note("slab-ell", rel(r2.cpu().numpy(), r1.cpu().numpy()), dims)
+        ser.destroy(); par.destroy()
+    else:                # slab-mode Stokes at one rank vs serial handle
+        d = int(rng.integers(2, 4)); dims = rand_dims(d, 3, 36 if d == 2 else 20, 9000)
+        ser = sp.StokesOp(dims); par = dsp.DistStokesOp(dims, sp)
+        x = dev(rng.standard_normal(ser.global_size)); dv = rng.standard_normal(ser.dirichlet_size)
+        for o in (ser, par.op):
+            o.set_rheology(1, 1.0, 3.0, 1e-3, 1.0); o.set_dirichlet(dv)
+        y1, y2 = torch.empty_like(x), torch.empty_like(x)
+        ser.function(x, y1); par.function(x, y2)
+        note("slab-st", rel(y2.cpu().numpy(), y1.cpu().numpy()), dims)
+        ser.destroy(); par.destroy()
+    n += 1
+print("fuzz: %d cases in %.0f s, all within tolerance; worst per kind:" % (n, time.time() - t0))
+for k, (e, what) in sorted(worst.items()):
+    print("   %-9s %.2e  %s" % (k, e, what))
