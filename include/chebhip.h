@@ -48,6 +48,9 @@ const char *chebhip_arch(void);
 /* A linear map on device vectors: y = A x.  ell_op_mult, stokes_op_mult and stokes_op_mult_vv have
  * exactly this shape (ctx = the operator handle) and can be passed as is. */
 typedef int (*chebhip_apply_fn)(void *ctx, const double *x_dev, double *y_dev, void *stream);
+/* Sums `count` device doubles over the ranks in place, ordered on `stream` (ncclAllReduce of a few doubles per
+ * Krylov iteration): what a multi-rank host gives the solvers below. */
+typedef int (*chebhip_reduce_fn)(void *ctx, double *vals_dev, int count, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Kernel level: the N-D Chebyshev derivative (chebyshev.h:18-24,31-34).      */
@@ -179,6 +182,8 @@ int stokes_op_mult_schur(stokes_op *op, const double *pG_dev, double *pG_out_dev
                          chebhip_apply_fn inner_solve, void *inner_ctx, void *stream);
 int stokes_op_set_inner_solver(stokes_op *op, int restart, double rtol, double atol, int max_it);
 int stokes_op_inner_iterations(const stokes_op *op);   /* MatVV applies of the last built-in inner solve */
+/* Slab mode: the built-in inner solve runs on distributed velocity vectors (see chebhip_fgmres_set_reduce). */
+int stokes_op_set_inner_reduce(stokes_op *op, chebhip_reduce_fn reduce, void *ctx);
 /* StokesFunction (:680-758): yG = F(xG) - force; refreshes eta, deta, strain. */
 int stokes_op_function(stokes_op *op, const double *xG_dev, double *yG_dev, void *stream);
 /* Operator state to/from the host: which = 0 eta (N), 1 deta (N), 2+j strain[j] (N*d). */
@@ -209,9 +214,6 @@ int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil_dev, do
 /* HBM; the host sees one Hessenberg column per iteration.                     */
 /* ------------------------------------------------------------------------- */
 typedef struct chebhip_fgmres chebhip_fgmres;
-/* Sums `count` device doubles over the ranks in place, ordered on `stream` (ncclAllReduce of a few doubles per
- * iteration). */
-typedef int (*chebhip_reduce_fn)(void *ctx, double *vals_dev, int count, void *stream);
 int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out);
 /* Vectors distributed over ranks (n = local entries): inner products are completed by `reduce`. NULL = one rank. */
 int chebhip_fgmres_set_reduce(chebhip_fgmres *k, chebhip_reduce_fn reduce, void *ctx);

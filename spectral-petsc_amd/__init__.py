@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
     "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
     "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
-    "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations",
+    "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations", "stokes_op_set_inner_reduce",
     "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
     "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason", "chebhip_fgmres_set_reduce",
 ]
@@ -114,6 +114,7 @@ def lib():
         L.stokes_op_mult_schur.argtypes = [vp, vp, vp, vp, vp, vp]
         L.stokes_op_set_inner_solver.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int]
         L.stokes_op_inner_iterations.argtypes = [vp]
+        L.stokes_op_set_inner_reduce.argtypes = [vp, vp, vp]
         L.chebhip_fgmres_create.argtypes = [C.c_long, C.c_int, C.POINTER(vp)]
         L.chebhip_fgmres_destroy.argtypes = [vp]
         L.chebhip_fgmres_set_tolerances.argtypes = [vp, C.c_double, C.c_double, C.c_int]
@@ -163,6 +164,28 @@ def device_view(ptr, n):
     a = _Arr()
     a.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
     return torch.as_tensor(a, device=torch.device("cuda", torch.cuda.current_device()))
+
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
+def allreduce_trampoline(group=None):
+    """A chebhip_reduce_fn that sums device doubles over the ranks of `group` with torch.distributed."""
+    import torch.distributed as dist
+
+    def red(ctx, ptr, count, stream):
+        try:
+            t = device_view(ptr, count)
+            if dist.get_backend(group) == "gloo":          # rehearsal on one GPU: stage through the host
+                h = t.cpu(); dist.all_reduce(h, group=group); t.copy_(h)
+            else:
+                dist.all_reduce(t, group=group)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 5
+    return REDUCE_FN(red)
 
 
 class ChebPlan:
@@ -413,6 +436,11 @@ class StokesOp:
         _chk(lib().stokes_op_mult_schur(self._h, _dev_ptr(p, self.pressure_size), _dev_ptr(pout, self.pressure_size), None, None, _stream()))
         return pout
 
+    def set_inner_reduce(self, group=None):
+        """Slab mode: the built-in inner solve of mult_schur works on distributed velocity vectors."""
+        self._red = allreduce_trampoline(group)
+        _chk(lib().stokes_op_set_inner_reduce(self._h, C.cast(self._red, C.c_void_p), None))
+
     @property
     def inner_iterations(self):
         return lib().stokes_op_inner_iterations(self._h)
@@ -488,21 +516,7 @@ class Fgmres:
 
     def set_reduce(self, group=None):
         """Vectors are distributed over the ranks of `group`: complete every inner product with an all-reduce."""
-        import torch.distributed as dist
-
-        def red(ctx, ptr, count, stream):
-            try:
-                t = device_view(ptr, count)
-                if dist.get_backend(group) == "gloo":          # rehearsal on one GPU: stage through the host
-                    h = t.cpu(); dist.all_reduce(h, group=group); t.copy_(h)
-                else:
-                    dist.all_reduce(t, group=group)
-                return 0
-            except Exception:
-                import traceback
-                traceback.print_exc()
-                return 5
-        self._red = Fgmres.REDUCE_FN(red)
+        self._red = allreduce_trampoline(group)
         _chk(lib().chebhip_fgmres_set_reduce(self._h, C.cast(self._red, C.c_void_p), None))
 
     def solve(self, A, b, x, M=None, x_nonzero=False, a_entry="mult", m_entry="mult"):

@@ -215,6 +215,8 @@ struct stokes_op {
   double *sv0 = nullptr, *sv1 = nullptr;
   chebhip_fgmres *inner = nullptr;
   int in_restart = 30, in_maxit = 10000, inner_its = 0;      // KSP defaults
+  chebhip_reduce_fn in_reduce = nullptr;                     // slab mode: completes the inner solver's inner products
+  void *in_reduce_ctx = nullptr;
   double in_rtol = 1e-5, in_atol = 1e-50;
   // the pressure-gradient chain (extrapolation + d scalar sweeps) is independent of the viscous chain between the
   // gather and the final scatter: it runs on a second stream (small grids leave most CUs idle per launch)
@@ -579,6 +581,13 @@ extern "C" int stokes_op_set_inner_solver(stokes_op *op, int restart, double rto
 
 extern "C" int stokes_op_inner_iterations(const stokes_op *op) { return op ? op->inner_its : -1; }
 
+// Slab mode: the velocity vectors of the built-in inner solve are distributed; see chebhip_fgmres_set_reduce.
+extern "C" int stokes_op_set_inner_reduce(stokes_op *op, chebhip_reduce_fn reduce, void *ctx) {
+  ARGCHK(op);
+  op->in_reduce = reduce; op->in_reduce_ctx = ctx;
+  return 0;
+}
+
 extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream) {
   ARGCHK(op && pG && out);
   hipStream_t st = (hipStream_t)stream;
@@ -589,6 +598,7 @@ extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out
   else {
     if (!op->inner) { if ((rc = chebhip_fgmres_create((long)gv, op->in_restart, &op->inner))) return rc; }
     if ((rc = chebhip_fgmres_set_tolerances(op->inner, op->in_rtol, op->in_atol, op->in_maxit))) return rc;
+    if ((rc = chebhip_fgmres_set_reduce(op->inner, op->in_reduce, op->in_reduce_ctx))) return rc;
     if ((rc = chebhip_fgmres_solve(op->inner, st_vv_apply, op, nullptr, nullptr, op->sv0, op->sv1, 0, st))) return rc;
     op->inner_its = chebhip_fgmres_iterations(op->inner);
   }

@@ -323,3 +323,11 @@ class DistStokesOp(_SlabPencil):
 
     def mult_vp(self, p, vout):
         return self.op.mult_vp(p, vout)
+
+    def mult_schur(self, p, pout, **kw):
+        """StokesMatMultSchur (stokes.C:523-535) on slabs: VP and PV are slab calls, the built-in inner GMRES on
+        MatVV completes its inner products with all-reduces."""
+        if self.G > 1 and not getattr(self, "_inner_reduce", False):
+            self.op.set_inner_reduce(self.group)
+            self._inner_reduce = True
+        return self.op.mult_schur(p, pout, **kw)

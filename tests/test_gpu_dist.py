@@ -71,8 +71,14 @@ def _worker(rank, world, port, dims, q):
         yf, ym = torch.empty_like(xl), torch.empty_like(xl)
         op.function(xl, yf)
         op.mult(xl, ym)
+        # Schur complement apply on slabs (linear state, as config 4): -PV VV^{-1} VP
+        op.op.set_rheology(0, 1.0, 1.0, 1.0, 1.0)
+        op.function(xl, yf.clone())
+        pvec = rng.standard_normal(gp)
+        pl = torch.from_numpy(pvec[n0:n1].copy()).cuda(); sl = torch.empty_like(pl)
+        op.mult_schur(pl, sl, restart=60, rtol=1e-12, max_it=5000)
         torch.cuda.synchronize()
-        q.put((rank, n0, yf.cpu().numpy(), ym.cpu().numpy()))
+        q.put((rank, n0, yf.cpu().numpy(), ym.cpu().numpy(), sl.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -98,6 +104,19 @@ def test_slab_ranks_match_oracle(world, dims):
     ref_m = orc.stokes_mult(dims, x, eta, deta, strain, mode=orc.DIRECT)
     assert yf.size == g
     assert relerr(yf, ref_f) < 1e-9 and relerr(ym, ref_m) < 1e-9
+    # Schur apply: dense -PV VV^{-1} VP from the oracle's operators (linear state)
+    ys = np.concatenate([r[4] for r in res])
+    def dense(apply, n, m):
+        A = np.empty((m, n)); e = np.zeros(n)
+        for j in range(n):
+            e[j] = 1.0; A[:, j] = apply(e); e[j] = 0.0
+        return A
+    VV = dense(lambda e: orc.stokes_mult_vv(dims, e), gv, gv)
+    VP = dense(lambda e: orc.stokes_mult_vp(dims, e), gp, gv)
+    PV = dense(lambda e: orc.stokes_divergence(dims, e), gv, gp)
+    pvec = rng.standard_normal(gp)
+    ref_s = -PV @ np.linalg.solve(VV, VP @ pvec)
+    assert np.linalg.norm(ys - ref_s) <= 1e-7 * np.linalg.norm(ref_s)
 
 
 # ---- Krylov on slabs: the solver's inner products become all-reduces -----------------------------
