@@ -307,6 +307,14 @@ __global__ void k_flux(long N, const double *__restrict__ eta, const double *__r
   }
 }
 
+// V = VecScatter(LG)(W): interior nodes of the local vector to the global one (elliptic.C:336)
+__global__ void k_scatter_lg(long N, const int *__restrict__ ixL, const double *__restrict__ W, double *__restrict__ V) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const int g = ixL[i];
+    if (g >= 0) V[g] = W[i];
+  }
+}
+
 __global__ void k_fill(long N, double v, double *__restrict__ a) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) a[i] = v;
 }
@@ -618,6 +626,38 @@ static int ell_slab_divergence(ell_op *op, int in_mode, double *const *src, doub
   return 0;
 }
 
+// Long lines (some extent > 256): every sweep is a PLAIN one, so that it can take the library-GEMM route of
+// sweep_launch; gather, flux and scatter are pointwise passes -- literally the reference's structure.
+static int ell_plain_sweep(ell_op *op, int k, const double *x, double *y, int out_mode, const double *acc, double alpha, hipStream_t st) {
+  SweepParams sp = {};
+  sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
+  sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.out_mode = out_mode; sp.acc = acc; sp.alpha = alpha;
+  HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  return 0;
+}
+
+// V = scatter(-sum_k D_k flux_k(src[k])); flux: 0 none, 1 eta * g, 2 eta * g + deta * w0 * gradu[k]; src is overwritten
+static int ell_plain_divergence(ell_op *op, int flux, double *const *src, double *V, hipStream_t st) {
+  for (int k = 0; k < op->d; k++) {
+    if (flux)
+      hipLaunchKernelGGL(k_flux, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta,
+                         (const double *)(flux == 2 ? op->deta : nullptr), (const double *)op->w0,
+                         (const double *)(flux == 2 ? op->gradu[k] : nullptr), src[k]);
+    int rc = ell_plain_sweep(op, k, src[k], op->W, k == 0 ? OUT_STORE : OUT_ACC, op->W, -1.0, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_scatter_lg, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const int *)op->ixL, (const double *)op->W, V);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int ell_mult_plain(ell_op *op, const double *U, double *V, hipStream_t st) {
+  int rc = ell_alloc_state(op); if (rc) return rc;
+  hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U, (const double *)nullptr, op->w0);
+  for (int k = 0; k < op->d; k++) if ((rc = ell_plain_sweep(op, k, op->w0, op->g[k], OUT_STORE, nullptr, 1.0, st))) return rc;
+  return ell_plain_divergence(op, op->mode == COEFF_UNIT ? 0 : 2, op->g.data(), V, st);
+}
+
 static int ell_mult_slab(ell_op *op, const double *U, double *V, hipStream_t st) {
   int rc = ell_alloc_state(op); if (rc) return rc;                    // w0
   hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U, (const double *)nullptr, op->w0);
@@ -632,7 +672,8 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   if (op->slab) return ell_mult_slab(op, U, V, (hipStream_t)stream);
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (use_unfused() || op->has_long) return ell_mult_unfused(op, U, V, st);
+  if (op->has_long) return ell_mult_plain(op, U, V, st);
+  if (use_unfused()) return ell_mult_unfused(op, U, V, st);
   if (op->mode == COEFF_UNIT) {
     // Linear state (eta == 1, deta == 0; homogeneous Dirichlet rows, elliptic.C:305-308): every
     // array of the apply lives in the interior layout of the global vectors, so there is no
@@ -703,7 +744,17 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     HIPCHK(hipGetLastError());
     return 0;
   }
-  if (use_unfused() || op->has_long) {
+  if (op->has_long) {
+    for (int k = 0; k < d; k++) if ((rc = ell_plain_sweep(op, k, op->w0, op->gradu[k], OUT_STORE, nullptr, 1.0, st))) return rc;   // :497-499
+    if (op->G == 0) return 0;
+    for (int k = 0; k < d; k++)                                                 // w_k = eta * gradu[k] (:511), formed in g[k]
+      HIPCHK(hipMemcpyAsync(op->g[k], op->gradu[k], (size_t)op->N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = ell_plain_divergence(op, 1, op->g.data(), rhs, st))) return rc;
+    if (b) hipLaunchKernelGGL(k_axpy, dim3(pw_grid(op->G)), dim3(256), 0, st, op->G, -1.0, b, rhs);  // :530
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  if (use_unfused()) {
     for (int k = 0; k < d; k++) {                                               // gradu[k] = D_k w0 (:497-499)
       SweepParams sp = {};
       sp.ncols = op->ncols[k]; sp.inner = op->inner[k];

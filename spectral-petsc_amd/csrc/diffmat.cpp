@@ -49,9 +49,9 @@ void diffmat_dense_host(int P, double *D) {
 // P > 256: the matrix does not fit the register file of a workgroup; cheb_sweep_long_kernel streams the dense
 // transpose from L2 instead (a correctness path for any extent the reference accepts, not a tuned one).
 static hipError_t diffmat_create_long(int P, DiffMat *out) {
-  std::vector<double> DT((size_t)P * P);
+  std::vector<double> DT((size_t)P * P), D((size_t)P * P);
   const int n = P - 1;
-  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) DT[(size_t)j * P + i] = (double)dentry(i, j, n);
+  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) { const double v = (double)dentry(i, j, n); DT[(size_t)j * P + i] = v; D[(size_t)i * P + j] = v; }
   DiffMat m;
   m.P = P; m.H = (P + 1) / 2; m.KS = 0; m.MTP = 0;
   hipError_t e = hipMalloc((void **)&m.fragE, (8 + 1024) * sizeof(double));
@@ -60,7 +60,9 @@ static hipError_t diffmat_create_long(int P, DiffMat *out) {
   e = hipMemset(m.zero, 0, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void **)&m.longDT, DT.size() * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m.longDT, DT.data(), DT.size() * sizeof(double), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(m.fragE); if (m.longDT) (void)hipFree(m.longDT); return e; }
+  if (e == hipSuccess) e = hipMalloc((void **)&m.longD, D.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(m.longD, D.data(), D.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(m.fragE); if (m.longDT) (void)hipFree(m.longDT); if (m.longD) (void)hipFree(m.longD); return e; }
   *out = m;
   return hipSuccess;
 }
@@ -162,7 +164,8 @@ void diffmat_destroy(DiffMat *m) {
   if (m->fragE) (void)hipFree(m->fragE);
   if (m->fragO) (void)hipFree(m->fragO);
   if (m->longDT) (void)hipFree(m->longDT);
-  m->fragE = m->fragO = m->longDT = nullptr;
+  if (m->longD) (void)hipFree(m->longD);
+  m->fragE = m->fragO = m->longDT = m->longD = nullptr;
 }
 
 }  // namespace chebhip

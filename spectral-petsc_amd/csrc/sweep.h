@@ -40,6 +40,7 @@ struct SweepParams {
   int in_mode, out_mode;
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
   const double *longDT;         // lines of more than 256 points: dense D^T ([j][i], P x P) instead of fragments
+  const double *longD;          // ... and dense D (row-major) for the library-GEMM route
   const double *zero;           // a few zero doubles in HBM: the source of every masked-off load
   double *sink;                 // 512 x 16 B in HBM: where masked-off stores of the straight-line kernel go
   unsigned ntiles;
@@ -58,6 +59,7 @@ struct DiffMat {
   int MTP = 0;         // padded m-tiles of 16 rows = KS/4
   double *fragE = nullptr, *fragO = nullptr;  // device, [MTP][KS][64]
   double *longDT = nullptr;                   // device, dense D^T for P > 256 (then fragE holds only zero/sink)
+  double *longD = nullptr;                    // device, dense D (row-major) for the library-GEMM route of long lines
   double *zero = nullptr;                     // device, 8 zero doubles (tail of the fragE allocation)
   double *sink = nullptr;                     // device, 1024 doubles after `zero`: target of masked-off stores
   int sym = 0;                                // 0: centro-antisymmetric (D), 1: centro-symmetric (interior D D)

@@ -23,6 +23,7 @@
 // MFMA is kept off the per-element path: offsets are 32-bit and tile-invariant, the mode
 // switches are hoisted around the unrolled loops, LDS fragment reads run one group ahead.
 #include "sweep.h"
+#include <dlfcn.h>
 #include <atomic>
 #include <type_traits>
 #include <cstdlib>
@@ -392,7 +393,72 @@ __global__ __launch_bounds__(256) void cheb_sweep_long_kernel(const SweepParams 
   }
 }
 
+// Plain sweeps (IN_PLAIN, STORE / ACC) of long lines are plain strided-batched DGEMMs: Y_o = D X_o per outer block.
+// That is the one place where a library GEMM is the right tool: rocBLAS is looked up at run time (the copy the
+// process already has, e.g. PyTorch's, else the system one) and never linked; without it, or for the gather /
+// flux / scatter modes, cheb_sweep_long_kernel above runs.
+namespace {
+struct RocblasApi {
+  void *lib = nullptr, *handle = nullptr;
+  int (*create)(void **) = nullptr;
+  int (*set_stream)(void *, hipStream_t) = nullptr;
+  int (*dgemm_sb)(void *, int, int, int, int, int, const double *, const double *, int, long long, const double *, int, long long,
+                  const double *, double *, int, long long, int) = nullptr;
+  bool tried = false;
+};
+RocblasApi g_rb;
+
+bool rocblas_ready() {
+  if (g_rb.tried) return g_rb.handle != nullptr;
+  g_rb.tried = true;
+  const char *off = getenv("CHEBHIP_NO_ROCBLAS");
+  if (off && off[0] == '1') return false;
+  const char *names[] = {"librocblas.so.5", "librocblas.so.4", "librocblas.so"};
+  for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // already in the process?
+  for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  if (!g_rb.lib) return false;
+  g_rb.create = (int (*)(void **))dlsym(g_rb.lib, "rocblas_create_handle");
+  g_rb.set_stream = (int (*)(void *, hipStream_t))dlsym(g_rb.lib, "rocblas_set_stream");
+  g_rb.dgemm_sb = (decltype(g_rb.dgemm_sb))dlsym(g_rb.lib, "rocblas_dgemm_strided_batched");
+  if (!g_rb.create || !g_rb.set_stream || !g_rb.dgemm_sb) return false;
+  void *h = nullptr;
+  if (g_rb.create(&h) != 0 || !h) return false;
+  g_rb.handle = h;
+  return true;
+}
+}  // namespace
+
+static hipError_t launch_long_gemm(const SweepParams &p, hipStream_t stream, bool *done) {
+  *done = false;
+  if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC) || !p.longD || !rocblas_ready()) return hipSuccess;
+  constexpr int OP_N = 111, OP_T = 112;                     // rocblas_operation_none / _transpose
+  if (p.out_mode == OUT_ACC && p.acc != p.out) {
+    hipError_t e = hipMemcpyAsync(p.out, p.acc, (size_t)p.ncols * p.P * sizeof(double), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+  }
+  const double alpha = p.alpha, beta = (p.out_mode == OUT_ACC) ? 1.0 : 0.0;
+  if (g_rb.set_stream(g_rb.handle, stream) != 0) return hipErrorUnknown;
+  const int P = p.P;
+  int st;
+  if (p.inner == 1)        // lines contiguous: Y (P x ncols, column-major) = D X
+    st = g_rb.dgemm_sb(g_rb.handle, OP_T, OP_N, P, (int)p.ncols, P, &alpha, p.longD, P, 0, p.in0, P, 0, &beta, p.out, P, 0, 1);
+  else {                   // per outer block o: Y_o^T (inner x P, column-major) = X_o^T D^T
+    const long long blk = (long long)P * p.inner;
+    st = g_rb.dgemm_sb(g_rb.handle, OP_N, OP_N, (int)p.inner, P, P, &alpha, p.in0, (int)p.inner, blk, p.longD, P, 0, &beta,
+                       p.out, (int)p.inner, blk, (int)(p.ncols / p.inner));
+  }
+  if (st != 0) return hipErrorUnknown;
+  sweep_note_launch();
+  *done = true;
+  return hipSuccess;
+}
+
 static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
+  {
+    bool done = false;
+    hipError_t e = launch_long_gemm(p, stream, &done);
+    if (e != hipSuccess || done) return e;
+  }
   const int LN = p.P <= 2048 ? 4 : 2;            // LN * P * 8 B of LDS, at most 64 KiB
   unsigned grid = (p.ncols + LN - 1) / LN; if (grid > 2048) grid = 2048;
   if (grid == 0) return hipSuccess;
@@ -405,7 +471,7 @@ static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate;
-  p.longDT = m.longDT;
+  p.longDT = m.longDT; p.longD = m.longD;
   if (m.KS == 0) return m.longDT ? launch_long(p, stream) : hipErrorInvalidValue;
   {
     static int novec = -1;
