@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--spinup", type=int, default=200, help="untimed setup matvecs before the W warm-up steps")
     ap.add_argument("--size", type=int, default=256, help="points per dimension P (BASELINE: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings of the other BASELINE configs")
     ap.add_argument("--cpu-threads", type=int, default=1)
     return ap.parse_args()
 
@@ -59,6 +60,47 @@ def cpu_baseline(P, threads, U, V=None):
         parity = {"rel_l2_vs_oracle": float(np.linalg.norm(V - ref) / np.linalg.norm(ref)), "tolerance": 1e-10,
                   "input": "the timed %d^3 N(0,1) vector" % P}
     return out, parity
+
+
+def extras(sp, torch):
+    """Secondary timings (us per call, sustained loops, HIP events) of the other callbacks on the hot path, taken
+    AFTER the timed region of the metric: BASELINE configs 2, 4, 5 and the variable-coefficient callbacks at the
+    metric's size.  Informational; DESIGN.md section 6 has the byte models they are priced against."""
+    import numpy as np
+
+    def t_us(fn, reps):
+        for _ in range(max(reps // 4, 5)):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+    out = {}
+    rnd = lambda n: torch.randn(n, dtype=torch.float64, device="cuda")
+    op = sp.EllipticOp((128, 128, 128)); U = rnd(op.global_size); V = torch.empty_like(U)
+    out["poisson_128_matvec_us"] = t_us(lambda: op.mult(U, V), 300)
+    op.destroy()
+    op = sp.EllipticOp((256, 256, 256)); U = torch.rand(op.global_size, dtype=torch.float64, device="cuda") + 0.5
+    X = rnd(op.global_size); b = rnd(op.global_size); R = torch.empty_like(U)
+    out["formfunction_256_gamma4_us"] = t_us(lambda: op.function(U, b, R, 4.0, 2.0), 40)
+    out["jacobian_apply_256_gamma4_us"] = t_us(lambda: op.mult(X, R), 60)
+    op.destroy()
+    x = rnd(256 ** 3); y = torch.empty_like(x); pl = sp.ChebPlan((256, 256, 256), 1)
+    out["chebmult_256_us"] = t_us(lambda: pl.mult(x, y), 100)
+    pl.destroy(); del x, y
+    for P, power, key in ((64, False, "stokes_64_linear"), (128, True, "stokes_128_powerlaw")):
+        op = sp.StokesOp((P, P, P))
+        if power:
+            op.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
+        op.set_dirichlet(np.zeros(op.dirichlet_size)); op.set_force(np.zeros(op.global_size))
+        xs = rnd(op.global_size); ys = torch.empty_like(xs)
+        out[key + "_function_us"] = t_us(lambda: op.function(xs, ys), 60)
+        out[key + "_matmult_us"] = t_us(lambda: op.mult(xs, ys), 100)
+        op.destroy()
+    return out
 
 
 def main():
@@ -179,6 +221,8 @@ def main():
                 out["cpu_baseline_all_cores"], _ = cpu_baseline(P, ncpu, Uh)
             if out["parity"]["rel_l2_vs_oracle"] > out["parity"]["tolerance"]:
                 raise SystemExit("parity failure: GPU matvec differs from the oracle by %.3e" % out["parity"]["rel_l2_vs_oracle"])
+        if world == 1 and not args.no_extras:
+            out["extras_us"] = extras(sp, torch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
