@@ -71,3 +71,31 @@ def test_no_cpu_fallback(L):
     assert b"no CPU fallback" in L.chebhip_last_error()
     with pytest.raises(sp.ChebhipError):
         sp.EllipticOp((8, 8))
+
+
+def test_argument_errors_of_the_wider_abi(L):
+    """Slab-mode creates, the Krylov driver and the slab copies check their arguments before touching a device."""
+    h = C.c_void_p()
+    ints = lambda v: (C.c_int * len(v))(*v)
+    cb = sp.DIM0_FN(lambda *a: 0)
+    cbp = C.cast(cb, C.c_void_p)
+    assert L.chebhip_fgmres_create(0, 30, C.byref(h)) == 1                      # n < 1
+    assert L.chebhip_fgmres_create(100, 0, C.byref(h)) == 4                     # restart out of range
+    assert L.chebhip_fgmres_create(100, 100000, C.byref(h)) == 4
+    assert L.chebhip_fgmres_set_tolerances(None, 1e-5, 1e-50, 10) == 4
+    assert L.chebhip_fgmres_solve(None, None, None, None, None, None, None, 0, None) == 4
+    assert L.ell_op_create_slab(1, ints([8]), 0, 4, cbp, None, C.byref(h)) == 3              # slab mode needs d >= 2
+    assert L.ell_op_create_slab(2, ints([8, 8]), 5, 3, cbp, None, C.byref(h)) == 4           # empty / reversed plane range
+    assert L.ell_op_create_slab(2, ints([8, 8]), 0, 9, cbp, None, C.byref(h)) == 4           # beyond the grid
+    assert L.ell_op_create_slab(2, ints([8, 8]), 0, 4, None, None, C.byref(h)) == 4          # no callback
+    assert L.stokes_op_create_slab(3, ints([8, 8, 8]), 4, 4, cbp, None, C.byref(h)) == 4
+    assert L.stokes_op_create_slab(4, ints([8, 8, 8, 8]), 0, 4, cbp, None, C.byref(h)) == 3  # d = 2 or 3 (stokes.C:1036)
+    assert L.stokes_op_create_slab(3, ints([8, 8, 8]), 0, 4, None, None, C.byref(h)) == 4
+    assert L.stokes_op_mult_schur(None, None, None, None, None, None) == 4
+    longs = lambda v: (C.c_long * len(v))(*v)
+    one = C.c_void_p(8)                                                          # never dereferenced: the checks come first
+    assert L.cheb_slab_pack(4, 6, 2, 2, longs([0, 3, 5]), one, one, None) == 4   # splits do not cover 0..M1
+    assert L.cheb_slab_pack(4, 6, 2, 2, longs([0, 7, 6]), one, one, None) == 4   # not monotone / out of range
+    assert L.cheb_slab_pack(4, 6, 2, 0, longs([0]), one, one, None) == 4         # G < 1
+    assert L.cheb_slab_unpack_add(4, 6, 2, 2, longs([0, 3, 6]), None, None, 1.0, one, None) == 4
+    assert h.value is None
