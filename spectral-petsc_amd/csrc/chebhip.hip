@@ -668,7 +668,8 @@ static int ell_mult_slab(ell_op *op, const double *U, double *V, hipStream_t st)
 }
 
 extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
-  if (!op || !U || !V) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  // empty vectors (a slab that owns only boundary planes) may be NULL
+  if (!op || ((!U || !V) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (op->slab) return ell_mult_slab(op, U, V, (hipStream_t)stream);
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -719,7 +720,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
 
 extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const double *U,
                                const double *b, double *rhs, void *stream) {
-  if (!op || !U || !rhs) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!op || ((!U || !rhs) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
   int rc = ell_alloc_state(op);
   if (rc) return rc;

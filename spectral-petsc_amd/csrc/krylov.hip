@@ -185,7 +185,7 @@ extern "C" int chebhip_fgmres_destroy(chebhip_fgmres *k) {
 extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) {
   if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
   *out = nullptr;
-  if (n < 1) return chebhip_fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 1", n);
+  if (n < 0) return chebhip_fail(CHEBHIP_ERR_SIZE, "n = %ld but must be >= 0", n);     // 0: a rank without unknowns
   if (restart < 1 || restart > RT) return chebhip_fail(CHEBHIP_ERR_ARG, "restart = %d must be in 1..%d", restart, RT);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -193,7 +193,7 @@ extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) 
   chebhip_fgmres *k = new (std::nothrow) chebhip_fgmres;
   if (!k) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
   const int m = restart;
-  k->n = n; k->m = m; k->ld = (n + 1) & ~1L;             // even leading dimension: every basis vector 16-B aligned
+  k->n = n; k->m = m; k->ld = n > 0 ? ((n + 1) & ~1L) : 2;             // even leading dimension: every basis vector 16-B aligned
 #define KC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { chebhip_fgmres_destroy(k); \
     return chebhip_fail(e_ == hipErrorOutOfMemory ? CHEBHIP_ERR_MEMORY : CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
   KC(hipMalloc((void **)&k->V, (size_t)(m + 1) * k->ld * sizeof(double)));
@@ -253,7 +253,7 @@ static int dev_norm(chebhip_fgmres *k, const double *v, hipStream_t st, double *
 
 extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void *actx, chebhip_apply_fn M, void *mctx,
                                     const double *b, double *x, int x_nonzero, void *stream) {
-  if (!k || !A || !b || !x) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!k || !A || ((!b || !x) && k->n > 0)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
   const long n = k->n, ld = k->ld;
   const int m = k->m;
@@ -261,12 +261,12 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
   double bnorm = 0.0;
   int rc = dev_norm(k, b, st, &bnorm); if (rc) return rc;
   const double tol = std::fmax(k->rtol * bnorm, k->atol);
-  if (!x_nonzero) KHIPCHK(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), st));
+  if (!x_nonzero && n > 0) KHIPCHK(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), st));
   bool first = true;
   for (;;) {
     // r = b - A x  into V[0]
     double *r = k->V;
-    if (first && !x_nonzero) KHIPCHK(hipMemcpyAsync(r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (first && !x_nonzero) { if (n > 0) KHIPCHK(hipMemcpyAsync(r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st)); }
     else {
       if ((rc = A(actx, x, r, st))) return rc;
       hipLaunchKernelGGL(k_residual, dim3(pgrid(n)), dim3(256), 0, st, n, b, r);

@@ -497,10 +497,12 @@ static int st_join(stokes_op *op, hipStream_t st) {
 
 #define ST_OUT(...) ST_D(k_st_out, __VA_ARGS__)
 #define ARGCHK(c) do { if (!(c)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument"); } while (0)
+// a vector of the handle may be NULL when it is empty (a slab that owns only boundary planes has no unknowns)
+#define VEC_OK(ptr) ((ptr) != nullptr || op->I == 0)
 #define CDP(x) ((const double *)(x))
 
 extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
-  ARGCHK(op && vG && out);
+  ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(out));
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
@@ -511,7 +513,7 @@ extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, v
 }
 
 extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, void *stream) {
-  ARGCHK(op && vG && pout);
+  ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(pout));
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
@@ -522,7 +524,7 @@ extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, 
 }
 
 extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, void *stream) {
-  ARGCHK(op && pG && vout);
+  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(vout));
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
@@ -533,7 +535,7 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
 }
 
 extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void *stream) {
-  ARGCHK(op && xG && yG);
+  ARGCHK(op); ARGCHK(VEC_OK(xG) && VEC_OK(yG));
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   // scatterGV + scatterVL (zero boundary) and scatterGP (:505-510) in one pass over xG; the same xL serves
@@ -548,7 +550,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
 }
 
 extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, void *stream) {
-  ARGCHK(op && xG && yG);
+  ARGCHK(op); ARGCHK(VEC_OK(xG) && VEC_OK(yG));
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
@@ -589,7 +591,7 @@ extern "C" int stokes_op_set_inner_reduce(stokes_op *op, chebhip_reduce_fn reduc
 }
 
 extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream) {
-  ARGCHK(op && pG && out);
+  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(out));
   hipStream_t st = (hipStream_t)stream;
   const size_t gv = (size_t)op->I * op->d;
   if (!op->sv0) { int rc = st_alloc(&op->sv0, gv ? gv : 1); if (rc) return rc; if ((rc = st_alloc(&op->sv1, gv ? gv : 1))) return rc; }

@@ -79,7 +79,7 @@ def test_argument_errors_of_the_wider_abi(L):
     ints = lambda v: (C.c_int * len(v))(*v)
     cb = sp.DIM0_FN(lambda *a: 0)
     cbp = C.cast(cb, C.c_void_p)
-    assert L.chebhip_fgmres_create(0, 30, C.byref(h)) == 1                      # n < 1
+    assert L.chebhip_fgmres_create(-1, 30, C.byref(h)) == 1                     # n < 0 (0 = a rank without unknowns)
     assert L.chebhip_fgmres_create(100, 0, C.byref(h)) == 4                     # restart out of range
     assert L.chebhip_fgmres_create(100, 100000, C.byref(h)) == 4
     assert L.chebhip_fgmres_set_tolerances(None, 1e-5, 1e-50, 10) == 4
