@@ -106,3 +106,23 @@ def test_split_sizes():
     dsp = ge.load_dist()
     assert dsp.split_sizes(254, 8) == [32] * 6 + [31] * 2
     assert sum(dsp.split_sizes(7, 3)) == 7
+
+
+def test_serial_ranges_against_brute_force():
+    """Where a rank's pieces sit in the serial vectors (slab-mode drivers): closed form vs counting nodes."""
+    dsp = ge.load_dist()
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        d = int(rng.integers(2, 5))
+        dims = tuple(int(v) for v in rng.integers(3, 9, size=d))
+        G = int(rng.integers(1, dims[0] + 1))
+        m0 = dsp.split_sizes(dims[0], G)
+        s0 = [0] + list(np.cumsum(m0))
+        inner = list(np.ndindex(*dims[1:]))
+        is_b = lambda i0, rest: i0 in (0, dims[0] - 1) or any(r in (0, n - 1) for r, n in zip(rest, dims[1:]))
+        for r in range(G):
+            stub = type("S", (), {"dims": dims, "s0": [int(v) for v in s0], "rank": r})()
+            (n0, n1), (b0, b1) = dsp._SlabPencil.serial_ranges(stub)
+            cnt = lambda lo, hi, want: sum(1 for i0 in range(lo, hi) for rest in inner if is_b(i0, rest) == want)
+            assert n0 == cnt(0, s0[r], False) and n1 == cnt(0, s0[r + 1], False), (dims, G, r)
+            assert b0 == cnt(0, s0[r], True) and b1 == cnt(0, s0[r + 1], True), (dims, G, r)
