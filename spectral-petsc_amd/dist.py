@@ -173,7 +173,8 @@ class _SlabPencil:
         self.m0 = split_sizes(P0, G); self.m1 = split_sizes(P1, G)
         self.s0 = [int(v) for v in np.concatenate([[0], np.cumsum(self.m0)])]
         self.s1 = [int(v) for v in np.concatenate([[0], np.cumsum(self.m1)])]
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        # (CPU tensors only in the exchange tests of tests/test_dist_gloo.py, which supply their own pack / unpack)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.Ns = self.m0[r] * P1 * self.R                     # nodes of the slab
         self.ncol = self.m1[r] * self.R                        # lines of the pencil
         self.Np = P0 * self.ncol

@@ -126,3 +126,68 @@ def test_serial_ranges_against_brute_force():
             cnt = lambda lo, hi, want: sum(1 for i0 in range(lo, hi) for rest in inner if is_b(i0, rest) == want)
             assert n0 == cnt(0, s0[r], False) and n1 == cnt(0, s0[r + 1], False), (dims, G, r)
             assert b0 == cnt(0, s0[r], True) and b1 == cnt(0, s0[r + 1], True), (dims, G, r)
+
+
+# ---- the slab <-> pencil exchange of the slab-mode drivers (DistEllipticOp / DistStokesOp), on CPU tensors ----------
+class _CpuCopies:
+    """Stand-in for the three library calls the exchange machinery makes (pack, unpack, view), on CPU tensors."""
+    def __init__(self):
+        self.keep = {}
+
+    def register(self, t):
+        self.keep[t.data_ptr()] = t
+        return t.data_ptr()
+
+    def device_view(self, ptr, n):
+        t = self.keep[ptr]
+        assert t.numel() == n
+        return t
+
+    def slab_pack(self, slab, buf, m0, M1, R, c1):
+        return OracleBackend().pack(slab, buf, m0, M1, R, c1)
+
+    def slab_unpack_add(self, buf, acc, out, m0, M1, R, c1, alpha=1.0):
+        return OracleBackend().unpack_add(buf * alpha, acc, out, m0, M1, R, c1)
+
+
+def _exchange_worker(rank, world, port, dims, nf, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dsp = ge.load_dist()
+        sp = _CpuCopies()
+        ex = dsp._SlabPencil()
+        ex._setup(dims, sp, None, nf)
+        P0, P1 = dims[0], dims[1]
+        R = int(np.prod(dims[2:])) if len(dims) > 2 else 1
+        full = np.arange(nf * P0 * P1 * R, dtype=np.float64).reshape(nf, P0, P1, R)     # field f, node (i0, i1, r)
+        lo, hi = ex.s0[rank], ex.s0[rank + 1]
+        slab = torch.from_numpy(np.ascontiguousarray(full[:, lo:hi]).reshape(-1))
+        ex._to_pencil(nf, sp.register(slab))
+        c0, c1 = ex.s1[rank], ex.s1[rank + 1]
+        want = np.ascontiguousarray(full[:, :, c0:c1]).reshape(-1)
+        ok_fwd = np.array_equal(ex.pen_in.numpy()[:want.size], want)
+        ex._pencil = lambda kind, n: ex.pen_out.copy_(ex.pen_in)                       # identity on the pencil
+        acc = torch.ones_like(slab); out = torch.empty_like(slab)
+        ex._dim0(0, nf, sp.register(slab), sp.register(acc), -2.0, sp.register(out), None)
+        ok_back = np.array_equal(out.numpy(), 1.0 - 2.0 * slab.numpy())
+        q.put((rank, ok_fwd, ok_back))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,nf", [(2, (7, 6, 5), 3), (3, (8, 9), 1), (4, (5, 7, 3), 2)], ids=str)
+def test_slab_pencil_round_trip(world, dims, nf):
+    """Every field of a slab reaches the pencils in the right place, and the way back restores it (with the AXPY)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, dims, nf, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res), res
