@@ -140,3 +140,49 @@ PetscErrorCode MatDestroy_Elliptic_hip(Mat A) {
   ell_op_destroy(op);
   PetscFunctionReturn(PETSC_SUCCESS);
 }
+
+/* ---- operator level: what stokes.C registers at :153, :309-325 --------------------------------- */
+/* StokesCtx (stokes.C:40-65) keeps its PETSc side (KSPs, scatters between the global vector and its velocity /
+ * pressure parts, MatVVPC); the Chebyshev work vectors, DP/DV plans, eta, deta and strain are replaced by one
+ * stokes_op handle.  The callbacks below take HIP vectors (-vec_type hip): nothing crosses PCIe inside the Krylov
+ * loops.  StokesCreate (:257-344) -> stokes_op_create(d, dim, &c->op); stokes_op_set_rheology / _set_dirichlet /
+ * _set_force at the places where stokes.C fills options->rheology (:470-480), c->dirichlet (:2003) and c->force. */
+typedef struct { stokes_op *op; KSP KSPSchurVelocity; Vec vG0, vG1; } StokesCtxHip;
+
+#define STOKES_SHELL(NAME, CALL)                                                            \
+  PetscErrorCode NAME(Mat A, Vec xG, Vec yG) {                                              \
+    StokesCtxHip *c; const PetscScalar *x; PetscScalar *y;                                  \
+    PetscFunctionBegin;                                                                     \
+    PetscCall(MatShellGetContext(A, &c));                                                   \
+    PetscCall(VecHIPGetArrayRead(xG, &x)); PetscCall(VecHIPGetArrayWrite(yG, &y));          \
+    PetscCall(cheb_err(CALL));                                                              \
+    PetscCall(VecHIPRestoreArrayWrite(yG, &y)); PetscCall(VecHIPRestoreArrayRead(xG, &x));  \
+    PetscFunctionReturn(PETSC_SUCCESS);                                                     \
+  }
+STOKES_SHELL(StokesMatMult_hip, stokes_op_mult(c->op, x, y, NULL))        /* stokes.C:499-519 */
+STOKES_SHELL(StokesMatMultVV_hip, stokes_op_mult_vv(c->op, x, y, NULL))   /* stokes.C:623-676 */
+STOKES_SHELL(StokesMatMultPV_hip, stokes_op_mult_pv(c->op, x, y, NULL))   /* stokes.C:557-566 */
+STOKES_SHELL(StokesMatMultVP_hip, stokes_op_mult_vp(c->op, x, y, NULL))   /* stokes.C:599-619 */
+
+/* the inner solve of the Schur complement stays the user's KSP (options prefix svel_, stokes.C:338-341) */
+static int stokes_svel_solve(void *ctx, const double *rhs_dev, double *sol_dev, void *stream) {
+  StokesCtxHip *c = (StokesCtxHip *)ctx;
+  PetscErrorCode ierr;
+  (void)stream;
+  ierr = VecHIPPlaceArray(c->vG0, rhs_dev); if (ierr) return (int)ierr;
+  ierr = VecHIPPlaceArray(c->vG1, sol_dev); if (ierr) return (int)ierr;
+  ierr = KSPSolve(c->KSPSchurVelocity, c->vG0, c->vG1);                                     /* stokes.C:531 */
+  VecHIPResetArray(c->vG0); VecHIPResetArray(c->vG1);
+  return (int)ierr;
+}
+STOKES_SHELL(StokesMatMultSchur_hip, stokes_op_mult_schur(c->op, x, y, stokes_svel_solve, c, NULL))   /* stokes.C:523-535 */
+
+PetscErrorCode StokesFunction_hip(SNES snes, Vec xG, Vec yG, void *void_ctx) {               /* stokes.C:680-758 */
+  StokesCtxHip *c = (StokesCtxHip *)void_ctx; const PetscScalar *x; PetscScalar *y;
+  (void)snes;
+  PetscFunctionBegin;
+  PetscCall(VecHIPGetArrayRead(xG, &x)); PetscCall(VecHIPGetArrayWrite(yG, &y));
+  PetscCall(cheb_err(stokes_op_function(c->op, x, y, NULL)));
+  PetscCall(VecHIPRestoreArrayWrite(yG, &y)); PetscCall(VecHIPRestoreArrayRead(xG, &x));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
