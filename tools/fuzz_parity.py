@@ -30,6 +30,8 @@ while time.time() - t0 < budget:
     kind = rng.integers(0, 5)
     if kind == 0:        # ChebMult
         rank = int(rng.integers(1, 5)); dims = rand_dims(rank, 2, 70 if rank > 1 else 300, 400000); tr = int(rng.integers(0, rank))
+        if rank in (2, 3) and rng.random() < 0.15:        # a long line (> 256 points) inside a small tensor
+            dl = list(rand_dims(rank, 2, 12, 2000)); dl[tr] = int(rng.integers(257, 600)); dims = tuple(dl)
         if dims[tr] < 2: continue
         x = rng.standard_normal(dims)
         plan = sp.ChebPlan(dims, tr); y = torch.empty(x.size, dtype=torch.float64, device="cuda")
@@ -37,6 +39,8 @@ while time.time() - t0 < budget:
         note("cheb", rel(y.cpu().numpy().reshape(dims), orc.cheb_mult(x, tr, orc.FAST)), (dims, tr))
     elif kind == 1:      # elliptic, linear + nonlinear
         rank = int(rng.integers(1, 4)); dims = rand_dims(rank, 3, 48 if rank > 1 else 200, 120000)
+        if rank == 2 and rng.random() < 0.1:
+            dims = (int(rng.integers(257, 400)), int(rng.integers(3, 12)))[::int(rng.choice([1, -1]))]
         op = sp.EllipticOp(dims)
         U = rng.standard_normal(op.global_size)
         note("ell-lin", rel(op.mult_host(U), orc.elliptic_mult(dims, U, mode=orc.FAST)), dims)
