@@ -431,7 +431,7 @@ static int ell_create(int d, const int *gdims, int lo, int hi, ell_dim0_fn dim0,
     const int Pk = (k == 0) ? gdims[0] : dims[k];
     if (!op->mats.count(Pk)) {
       DiffMat m; OPCHK(diffmat_create(Pk, &m)); op->mats[Pk] = m;
-      if (Pk > 256) op->has_long = true;
+      if (m.KS == 0) op->has_long = true;
       else if (Pk > 2 && !slab) { DiffMat l; OPCHK(diffmat_create_lap(Pk, &l)); op->laps[Pk] = l; }
     }
   }

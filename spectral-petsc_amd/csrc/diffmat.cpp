@@ -17,6 +17,7 @@
 //     y_i = (ME e)_i + (MO o)_i,      y_{n-i} = (MO o)_i - (ME e)_i,     i < H.
 #include "sweep.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace chebhip {
@@ -68,7 +69,10 @@ static hipError_t diffmat_create_long(int P, DiffMat *out) {
 }
 
 hipError_t diffmat_create(int P, DiffMat *out) {
-  if (P > 256) return diffmat_create_long(P, out);
+  // CHEBHIP_FORCE_GEMM=1 (A/B measurements only): every extent takes the long-line route, i.e. a library DGEMM
+  static int force = -1;
+  if (force < 0) { const char *e = getenv("CHEBHIP_FORCE_GEMM"); force = (e && e[0] == '1') ? 1 : 0; }
+  if (P > 256 || (force && P >= 4)) return diffmat_create_long(P, out);
   const int n = P - 1;
   const int H = (P + 1) / 2;
   int KS = 4;
