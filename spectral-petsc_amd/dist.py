@@ -97,7 +97,10 @@ class DistPoissonOp:
         self.UT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
         self.TT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
         forced = dist.is_initialized() and os.environ.get("CHEBHIP_DIST_FORCE_A2A") == "1"
-        self.comm_stream = backend.side_stream() if (G > 1 or forced) else None
+        # CHEBHIP_DIST_SERIAL=1: everything on the caller's stream (no overlap of the local sweeps with the exchanges,
+        # but no cross-stream dependencies either)
+        serial = os.environ.get("CHEBHIP_DIST_SERIAL") == "1"
+        self.comm_stream = backend.side_stream() if ((G > 1 or forced) and not serial) else None
 
     # ---- helpers -------------------------------------------------------------------------------
     def random_input(self, seed):

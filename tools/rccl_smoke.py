@@ -40,17 +40,22 @@ assert its == ks2.iterations
 # cost of the two collectives of a matvec as RCCL sees them with one rank (self copy of the whole slab): a floor
 # for the per-call overhead, not a bandwidth figure
 import time
-big = dsp.DistPoissonOp((34, 256, 256), backend=dsp.HipBackend(sp))
-Ub = big.random_input(3); Vb = torch.empty_like(Ub)
-for forced in ("1", "0"):
-    os.environ["CHEBHIP_DIST_FORCE_A2A"] = forced
-    for _ in range(20):
-        big.mult(Ub, Vb)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(100):
-        big.mult(Ub, Vb)
-    torch.cuda.synchronize()
-    print("slab 32x254x254 matvec, exchanges through %s: %.1f us" % ("RCCL all_to_all_single (1 rank)" if forced == "1" else "a device copy", (time.perf_counter() - t0) * 1e4))
+for serial in ("0", "1"):
+    os.environ["CHEBHIP_DIST_SERIAL"] = serial
+    os.environ["CHEBHIP_DIST_FORCE_A2A"] = "1"
+    big = dsp.DistPoissonOp((34, 256, 256), backend=dsp.HipBackend(sp))
+    Ub = big.random_input(3); Vb = torch.empty_like(Ub)
+    for forced in ("1", "0"):
+        os.environ["CHEBHIP_DIST_FORCE_A2A"] = forced
+        for _ in range(20):
+            big.mult(Ub, Vb)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(200):
+            big.mult(Ub, Vb)
+        torch.cuda.synchronize()
+        print("slab 32x254x254 matvec (%s), exchanges through %s: %.1f us" % (
+            "one stream" if serial == "1" else "side stream for the exchanges",
+            "RCCL all_to_all_single (1 rank)" if forced == "1" else "a device copy", (time.perf_counter() - t0) * 1e6 / 200))
 dist.barrier()
 dist.destroy_process_group()
 print("rccl smoke ok")
