@@ -43,6 +43,8 @@ extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 // Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
 extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
+// Undocumented profiling hook: schedule switches of the 16-byte kernels (sweep_vec.hip v3: 1 = no stagger, 2 = no setprio, 4 = dense W)
+extern "C" void chebhip_debug_variant(int bits) { sweep_set_variant(bits); }
 // Diagnostic builds (-DCHEB_STAMPS) only: device buffer of 256*8*4 uint64 receiving per-wave phase cycle sums.
 static const double *g_stamp_buf = nullptr;
 extern "C" void chebhip_debug_stamp_buffer(const void *dev) { g_stamp_buf = (const double *)dev; }
@@ -344,6 +346,7 @@ struct ell_op {
   int *ixL = nullptr;                   // device [N]: global index or -1 (c->isL, elliptic.C:426)
   std::vector<double *> g;              // d work vectors: gradients / fluxes (c->w[1..d])
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
+  unsigned wpad = 0;                    // constant-coefficient path: row pitch of W in its padded interior layout (0: dense)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
   // slab mode (multi-GPU): the handle owns the planes [lo, lo + dims[0]) of a grid whose dimension 0 has
@@ -478,7 +481,20 @@ static int ell_create(int d, const int *gdims, int lo, int hi, ell_dim0_fn dim0,
   }
   op->g.assign(d, nullptr);
   for (int k = 0; k < d; k++) OPCHK(hipMalloc((void **)&op->g[k], (size_t)N * sizeof(double)));
-  OPCHK(hipMalloc((void **)&op->W, (size_t)N * sizeof(double)));
+  size_t wsize = (size_t)N;
+  if (!slab && !op->has_long && (d == 2 || d == 3)) {
+    // padded accumulator of the constant-coefficient path (ell_op_mult): needs the 16-byte kernel's v3
+    // (interior lines of more than 64 points) and even interior extents
+    bool ok = true;
+    for (int k = 0; k < d; k++) ok = ok && dims[k] - 2 > 64 && ((dims[k] - 2) & 1) == 0 && dims[k] <= 256;
+    if (ok) {
+      op->wpad = (unsigned)((dims[d - 1] - 2 + 15) / 16 * 16);
+      size_t need = op->wpad;
+      for (int k = 0; k < d - 1; k++) need *= (size_t)(dims[k] - 2);
+      if (need > wsize) wsize = need;
+    }
+  }
+  OPCHK(hipMalloc((void **)&op->W, wsize * sizeof(double)));
 #undef OPCHK
   *out = op;
   return 0;
@@ -684,6 +700,34 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
     //            of D D (constant coefficient), cheb_sweep_kernel, half the MFMA work;
     //  two-stage (CHEBHIP_TWO_STAGE=1 / chebhip_debug_two_stage): the same fused gradient ->
     //            flux -> divergence kernel the variable-coefficient path uses.
+    if (op->wpad && !use_two_stage() && !(sweep_get_variant() & 4)) {
+      // d = 2, 3 with lines of more than 64 points: the accumulator W keeps its rows padded to a multiple of
+      // 128 B (pitch wpad), so that the strided launches read and write whole cache lines of it; U and V stay
+      // dense.  Tiles of the strided directions are (outer index, 32 neighbouring points of the last dimension).
+      const int d = op->d;
+      const unsigned nl = (unsigned)op->dims[d - 1] - 2, nm = d == 3 ? (unsigned)op->dims[1] - 2 : 1u, wp = op->wpad;
+      for (int k = 0; k < d; k++) {
+        SweepParams sp = {};
+        sp.in0 = U; sp.in_mode = IN_PLAIN; sp.alpha = -1.0;
+        if (k == 0) { sp.out_mode = OUT_STORE; sp.out = op->W; }
+        else if (k == d - 1) { sp.out_mode = OUT_ACC; sp.out = V; sp.acc = op->W; }
+        else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
+        if (k == d - 1) {                                          // contiguous lines
+          sp.ncols = op->ncols_g[k]; sp.inner = 1;
+          sp.in_os = nl; sp.acc_os = wp; sp.out_os = nl;
+        } else {
+          const bool first = (k == 0 && d == 3);                   // lines along dimension 0 of a 3-D grid: outer index = dimension 1
+          sp.ncols = op->ncols_g[k]; sp.qmax = nl;
+          sp.nouter = d == 2 ? 1u : (first ? nm : (unsigned)op->dims[0] - 2);
+          sp.in_rs = d == 2 ? nl : (first ? nm * nl : nl);  sp.in_os = d == 2 ? nl : (first ? nl : nm * nl);
+          const unsigned w_rs = d == 2 ? wp : (first ? nm * wp : wp), w_os = d == 2 ? wp : (first ? wp : nm * wp);
+          sp.acc_rs = sp.out_rs = w_rs; sp.acc_os = sp.out_os = w_os;
+          sp.inner = sp.in_rs;
+        }
+        HIPCHK(sweep_launch(op->laps[op->dims[k]], sp, st));
+      }
+      return 0;
+    }
     for (int k = 0; k < op->d; k++) {
       SweepParams sp = {};
       sp.ncols = op->ncols_g[k]; sp.inner = op->inner_g[k];

@@ -365,7 +365,7 @@ static hipError_t launch_f(const SweepParams &p0, hipStream_t stream) {
 hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   if (p.in_mode != IN_PLAIN && p.in_mode != IN_GATHER) return hipErrorInvalidValue;
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.ablate = sweep_get_ablate();
-  { static int v = -1; if (v < 0) { const char *e = getenv("CHEBHIP_VARIANT"); v = e ? atoi(e) : 0; } p.variant = v; }
+  p.variant = sweep_get_variant();
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_f<4, true>(p, stream) : launch_f<4, false>(p, stream);

@@ -48,6 +48,15 @@ struct SweepParams {
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
   int coef_mode;      // fused launches only: CoefMode; COEF_ETA: eta = in1; COEF_FULL: in2 = pairs {eta, c = deta * du0} (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
+  // Per-array geometry of the 16-byte kernels (sweep_vec.hip, v3); 0 = derive from P / inner / ncols.
+  //   COLFAST: a tile is (outer block o, NT neighbouring columns q < qmax); element (o, q, point j) of
+  //            array X sits at o * X_os + q + j * X_rs.  The default is the dense tensor: nouter =
+  //            ncols / inner, qmax = inner, X_os = P * inner, X_rs = inner.
+  //   JFAST:   line c of array X starts at c * X_os (default X_os = P), points are contiguous.
+  // Lets the accumulator of the constant-coefficient operator keep rows padded to 128 B while the
+  // MatShell vectors stay in the reference's dense interior layout.
+  unsigned nouter, qmax;
+  unsigned in_os, in_rs, acc_os, acc_rs, out_os, out_rs;
   int variant;        // profiling only: experimental schedule switches (CHEBHIP_VARIANT)
   int ablate;         // profiling only (see sweep_set_ablate); 0 in production
 };
@@ -89,5 +98,7 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
 
 long sweep_launch_count();
 void sweep_set_ablate(int bits);
+void sweep_set_variant(int bits);
+int sweep_get_variant();
 
 }  // namespace chebhip

@@ -38,6 +38,12 @@ static int g_ablate = 0;   // profiling only: bit0 no global loads, bit1 no stor
 long sweep_launch_count() { return g_launches.load(); }
 void sweep_set_ablate(int bits) { g_ablate = bits; }
 int sweep_get_ablate() { return g_ablate; }
+static int g_variant = -1;  // profiling only: schedule switches of the 16-byte kernels (CHEBHIP_VARIANT / chebhip_debug_variant)
+void sweep_set_variant(int bits) { g_variant = bits; }
+int sweep_get_variant() {
+  if (g_variant < 0) { const char *e = getenv("CHEBHIP_VARIANT"); g_variant = e ? atoi(e) : 0; }
+  return g_variant;
+}
 void sweep_note_launch() { g_launches.fetch_add(1); }
 
 template <int M> using mode_c = std::integral_constant<int, M>;
@@ -470,7 +476,7 @@ static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate;
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate; p.variant = sweep_get_variant();
   p.longDT = m.longDT; p.longD = m.longD;
   if (m.KS == 0) return m.longDT ? launch_long(p, stream) : hipErrorInvalidValue;
   {

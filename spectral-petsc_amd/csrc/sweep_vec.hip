@@ -578,6 +578,307 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec2_kernel(const SweepParams 
   if (w >= 4) run(std::true_type{}); else run(std::false_type{});
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: v2 plus
+//   * per-array geometry (sweep.h): input, VecAXPY operand and output may have different row pitches,
+//     so the accumulator of the constant-coefficient operator can keep its rows 128-B aligned while
+//     the MatShell vectors stay dense;
+//   * prefetches past the last tile of a workgroup read the zero word instead of re-reading the
+//     current tile (v2 clamped the tile index: 1.5 extra tile loads per workgroup of 8 tiles, +19 %
+//     input traffic);
+//   * STAGGER: the two waves of a SIMD run the same program between the same barriers, so they reach
+//     their matrix chains and their epilogues together and the matrix pipe idles during both
+//     epilogues.  Waves 4-7 defer the epilogue of a tile's second sub-tile to the start of the next
+//     tile (sums and operand stay in registers across the barrier): from then on one wave of a SIMD
+//     is in its chain while the other stores (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+template <int KS, bool JFAST, bool ACC>
+__global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams p) {
+  constexpr int MTP = KS / 4;
+  constexpr int NG = 8 / MTP;
+  constexpr int HP = 4 * KS;
+  constexpr int NSUB = 2;
+  constexpr int NT = 16 * NG * NSUB;
+  constexpr int LDJ = HP + 2;
+  constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
+  constexpr int ITEMS = HP * NT / 2 / 512;
+  constexpr int CH = ITEMS / NSUB;
+  constexpr int QSTEP = JFAST ? 512 / (HP / 2) : 512 / (NT / 2);
+  constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
+  constexpr int KSTR = JFAST ? 4 : 4 * NT;
+  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
+  constexpr int KR = KS - NFL;
+  static_assert(KS >= 16 && CH >= 1, "v3 needs two sub-tiles per tile");
+  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mt = w % MTP, ng = w / MTP;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int odd = l16 & 1, l16e = l16 & ~1;
+  const int nn = p.P - 1, H = p.H;
+  const u32 qmax = p.qmax, ncols = p.ncols;
+  const u32 in_os = p.in_os, in_rs = p.in_rs;
+
+  double ae[KS], ao[KR > 0 ? KR : 1];
+  double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
+    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
+    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  const u32 tpo = JFAST ? 1u : (qmax + NT - 1) / NT;
+  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
+  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
+  const u32 t_step = gridDim.x / nxcd;
+
+  const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
+  const int ld_b = JFAST ? tid / (HP / 2) : tid / (NT / 2);
+  const int ld_lds0 = JFAST ? ld_b * LDJ + 2 * ld_a : ld_b * NT + ((2 * ld_a) ^ ((ld_b & 1) << 4));
+  const d2 *zero2 = (const d2 *)p.zero;
+  d2 *sink2 = (d2 *)p.sink + tid;
+  const int i0 = mt * 16 + (JFAST ? l16 : kq);
+  const double alpha = p.alpha;
+
+  d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
+  d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];
+
+  // `valid` false (a tile past the workgroup's last): every slot reads the zero word
+  auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
+    if (!JFAST) {
+      const u32 o = tl / tpo, q0 = (tl - o * tpo) * NT;
+      const u32 q = q0 + 2 * ld_a;
+      const bool cv = valid & (q < qmax);                    // qmax is even: the pair is in or out together
+      const u32 base = o * in_os + q;
+      int jp = ld_b + chunk * CH * QSTEP;
+      u32 rel = (u32)jp * in_rs;
+      const u32 top = base + (u32)nn * in_rs;
+      asm volatile("" : "+v"(rel), "+v"(jp));
+#pragma unroll
+      for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * in_rs) {
+        const bool ok = cv & (jp < H);
+        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
+        rm[s] = *((ok & (nn - jp != jp)) ? (const d2 *)(p.in0 + (top - rel)) : zero2);
+      }
+    } else {
+      const int j = 2 * ld_a;
+#pragma unroll
+      for (int s = 0; s < CH; s++) {
+        const u32 c = tl * NT + ld_b + (chunk * CH + s) * QSTEP;
+        const bool ok = valid & (c < ncols) & (j < H);
+        const u32 base = (ok ? c : 0u) * in_os;
+        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
+        rm[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
+      }
+    }
+  };
+  auto park_chunk = [&](int buf, int chunk, const d2 (&rj)[CH], const d2 (&rm)[CH]) {
+    double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
+#pragma unroll
+    for (int s = 0; s < CH; s++) {
+      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
+      d2 e, o;
+      if (!JFAST) {
+        const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn;
+        e = rj[s] + rm[s];
+        o = rj[s] - rm[s];
+        if (mid) o = d2{0.0, 0.0};
+      } else {
+        const bool v1 = 2 * ld_a + 1 < H;
+        e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
+        o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
+      }
+      *(d2 *)(dE + idx) = e;
+      *(d2 *)(dO + idx) = o;
+    }
+  };
+  // offsets of the two 16-B pieces (row i / mirror row n-i) of pair rp in an array of geometry (os, rs)
+  auto geom = [&](u32 tl, bool valid, int sub, u32 os, u32 rs, u32 (&a_hi)[2], u32 (&a_lo)[2], bool (&ok_hi)[2], bool (&ok_lo)[2], bool (&fold)[2]) {
+    const int nb = (ng * NSUB + sub) * 16;
+    const u32 g_o = tl / tpo, g_q0 = (tl - g_o * tpo) * NT;
+    int i0o = i0;
+    asm volatile("" : "+v"(i0o));
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) {
+      const int r = 2 * rp + odd;
+      if (!JFAST) {
+        const u32 q = g_q0 + nb + l16e;
+        const int i = i0o + 4 * r;
+        const u32 b = g_o * os + q;
+        ok_hi[rp] = valid & (q < qmax) & (i < H);
+        ok_lo[rp] = ok_hi[rp] & (nn - i != i);
+        fold[rp] = false;
+        a_hi[rp] = b + (u32)i * rs;
+        a_lo[rp] = b + (u32)(nn - i) * rs;
+      } else {
+        const u32 c = tl * NT + nb + 4 * r + kq;
+        const int ie = mt * 16 + l16e;
+        const u32 b = (c < ncols ? c : 0u) * os;
+        ok_hi[rp] = valid & (c < ncols) & (ie < H);
+        fold[rp] = ok_hi[rp] & (ie + 1 >= H);
+        ok_lo[rp] = ok_hi[rp] & !fold[rp];
+        a_hi[rp] = b + (u32)ie;
+        a_lo[rp] = b + (u32)(nn - ie - 1);
+      }
+    }
+  };
+  auto acc_issue = [&](u32 tl, bool valid, int sub, d2 (&ah)[2], d2 (&al)[2]) {
+    if (!ACC) return;
+    u32 a_hi[2], a_lo[2]; bool ok_hi[2], ok_lo[2], fold[2];
+    geom(tl, valid, sub, p.acc_os, p.acc_rs, a_hi, a_lo, ok_hi, ok_lo, fold);
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) {
+      ah[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
+      al[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
+    }
+  };
+
+  u32 tile = t_lo + blockIdx.x / nxcd;
+  if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
+  issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
+  park_chunk(0, 0, rjA, rmA); park_chunk(0, 1, rjB, rmB);
+
+  // one MFMA chain over sub-tile `sub` of the LDS buffer at sE/sO; issue_fn / park_fn sit inside it
+  auto chain = [&](const double *sE, const double *sO, int sub, int g_issue, int g_park, v4d &ce, v4d &co, auto &&issue_fn, auto &&park_fn) {
+    const int nb = (ng * NSUB + sub) * 16;
+    ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
+    const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
+    const double *fE = sE + frag, *fO = sO + frag;
+    double fb[2][4];
+    fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
+#pragma unroll
+    for (int g = 0; g < KS / 2; g++) {
+      const int cb = g & 1, nbuf = cb ^ 1;
+      if (g + 1 < KS / 2) {
+        fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
+        fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
+      }
+      __builtin_amdgcn_sched_barrier(0);               // fragment reads stay one group ahead of their MFMAs
+      if (g == g_issue) issue_fn();
+      if (g == g_park) park_fn();
+      if (!JFAST) {
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g), fb[cb][2], co, 0, 0, 0);
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g + 1), fb[cb][3], co, 0, 0, 0);
+      } else {
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], AO(2 * g), co, 0, 0, 0);
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], AO(2 * g + 1), co, 0, 0, 0);
+      }
+    }
+  };
+  // out = (acc +) alpha * (sums) for sub-tile `sub` of tile tl; !valid: every store hits the sink
+  auto epilogue = [&](u32 tl, bool valid, int sub, const v4d &ce, const v4d &co, const d2 (&acc_hi)[2], const d2 (&acc_lo)[2]) {
+    u32 a_hi[2], a_lo[2];
+    bool ok_hi[2], ok_lo[2], fold[2];
+    geom(tl, valid, sub, p.out_os, p.out_rs, a_hi, a_lo, ok_hi, ok_lo, fold);
+    double hi[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) {
+      const double own_hi = odd ? hi[2 * rp + 1] : hi[2 * rp], snd_hi = odd ? hi[2 * rp] : hi[2 * rp + 1];
+      const double own_lo = odd ? lo[2 * rp + 1] : lo[2 * rp], snd_lo = odd ? lo[2 * rp] : lo[2 * rp + 1];
+      const double rcv_hi = swap1(snd_hi), rcv_lo = swap1(snd_lo);
+      d2 vh = odd ? d2{rcv_hi, own_hi} : d2{own_hi, rcv_hi};
+      d2 vl;
+      if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
+      else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};
+      if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};
+      if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha * vl; }
+      else { vh = alpha * vh; vl = alpha * vl; }
+      *(ok_hi[rp] ? (d2 *)(p.out + a_hi[rp]) : sink2) = vh;     // unconditional: masked-off lanes hit the sink
+      *(ok_lo[rp] ? (d2 *)(p.out + a_lo[rp]) : sink2) = vl;
+    }
+  };
+
+  // Waves 0-3 (and waves 4-7 with the stagger switched off): chain, epilogue, chain, epilogue, barrier.
+  auto run_plain = [&](auto GRPB_) {
+    constexpr bool GRPB = decltype(GRPB_)::value;
+    constexpr int G_ISSUE = GRPB ? 0 : KS / 8, G_PARK = GRPB ? KS / 4 : 3 * KS / 8;
+    {
+      // reproduce the in-flight state of the loop's back edge (operand X, chunk A, four stores) so
+      // that the wait counts of the loop hold from iteration 0
+      const u32 nx = tile + t_step;
+      acc_issue(tile, true, 0, accX_hi, accX_lo);
+      issue_loads(nx, nx < t_hi, 0, rjA, rmA);
+#pragma unroll
+      for (int q = 0; q < 4; q++) *sink2 = d2{0.0, 0.0};
+    }
+    lds_barrier_v();
+    int cur = 0;
+    for (; tile < t_hi; tile += t_step) {
+      const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
+      const bool v1 = nxt < t_hi, v2 = nxt2 < t_hi;
+      const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
+      v4d ce, co;
+      chain(sE, sO, 0, G_ISSUE, G_PARK, ce, co,
+            [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
+            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
+      epilogue(tile, true, 0, ce, co, accX_hi, accX_lo);
+      chain(sE, sO, 1, G_ISSUE, G_PARK, ce, co,
+            [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
+            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
+      epilogue(tile, true, 1, ce, co, accY_hi, accY_lo);
+      lds_barrier_v();
+      cur ^= 1;
+    }
+  };
+  // Waves 4-7, staggered: the epilogue of sub-tile 1 runs at the top of the next iteration.
+  auto run_stag = [&] {
+    constexpr int G_ISSUE = 0, G_PARK = KS / 4;
+    {
+      const u32 nx = tile + t_step;
+#pragma unroll
+      for (int q = 0; q < 4; q++) *sink2 = d2{0.0, 0.0};
+      acc_issue(tile, true, 0, accX_hi, accX_lo);
+      issue_loads(nx, nx < t_hi, 0, rjA, rmA);
+    }
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) { accY_hi[rp] = d2{0.0, 0.0}; accY_lo[rp] = d2{0.0, 0.0}; }
+    lds_barrier_v();
+    int cur = 0;
+    u32 ptile = tile; bool pvalid = false;
+    v4d ce1 = {0.0, 0.0, 0.0, 0.0}, co1 = {0.0, 0.0, 0.0, 0.0};
+    for (; tile < t_hi; tile += t_step) {
+      const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
+      const bool v1 = nxt < t_hi, v2 = nxt2 < t_hi;
+      const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
+      epilogue(ptile, pvalid, 1, ce1, co1, accY_hi, accY_lo);
+      __builtin_amdgcn_sched_barrier(0);
+      v4d ce0, co0;
+      chain(sE, sO, 0, G_ISSUE, G_PARK, ce0, co0,
+            [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
+            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
+      epilogue(tile, true, 0, ce0, co0, accX_hi, accX_lo);
+      chain(sE, sO, 1, G_ISSUE, G_PARK, ce1, co1,
+            [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
+            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
+      lds_barrier_v();
+      cur ^= 1;
+      ptile = tile; pvalid = true;
+    }
+    epilogue(ptile, pvalid, 1, ce1, co1, accY_hi, accY_lo);
+  };
+  if (w >= 4) {
+    if (!(p.variant & 2)) __builtin_amdgcn_s_setprio(1);   // the younger half loses VALU arbitration otherwise
+    if (p.variant & 1) run_plain(std::true_type{}); else run_stag();
+  } else run_plain(std::false_type{});
+}
+
+template <int KS, bool JFAST>
+static hipError_t launch_v3(const SweepParams &p, unsigned grid, hipStream_t stream) {
+  if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec3_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((cheb_sweep_vec3_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
+  sweep_note_launch();
+  return hipGetLastError();
+}
+
 template <int KS, bool JFAST>
 static hipError_t launch_v2(const SweepParams &p, unsigned grid, hipStream_t stream) {
   if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec2_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
@@ -590,8 +891,20 @@ template <int KS, bool JFAST>
 static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   constexpr int MTP = KS / 4, NG = 8 / MTP, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB;
   SweepParams p = p0;
-  if (JFAST) p.ntiles = (p.ncols + NT - 1) / NT;
-  else p.ntiles = (p.ncols / p.inner) * ((p.inner + NT - 1) / NT);
+  const bool custom = p.qmax != 0 || p.in_os != 0;         // per-array geometry given by the caller (v3 only)
+  if (JFAST) {
+    if (!p.in_os) p.in_os = (unsigned)p.P;
+    if (!p.acc_os) p.acc_os = (unsigned)p.P;
+    if (!p.out_os) p.out_os = (unsigned)p.P;
+    p.in_rs = p.acc_rs = p.out_rs = 1; p.nouter = p.ncols; p.qmax = 1;
+    p.ntiles = (p.ncols + NT - 1) / NT;
+  } else {
+    if (!p.qmax) { p.qmax = p.inner; p.nouter = p.ncols / p.inner; }
+    if (!p.in_os) { p.in_os = (unsigned)p.P * p.inner; p.in_rs = p.inner; }
+    if (!p.acc_os) { p.acc_os = (unsigned)p.P * p.inner; p.acc_rs = p.inner; }
+    if (!p.out_os) { p.out_os = (unsigned)p.P * p.inner; p.out_rs = p.inner; }
+    p.ntiles = p.nouter * ((p.qmax + NT - 1) / NT);
+  }
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -604,8 +917,14 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   if constexpr (KS >= 16) {
     static int v1 = -1;
     if (v1 < 0) { const char *e = getenv("CHEBHIP_VEC_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
-    if (!v1 && !p.ablate && p.sink) return launch_v2<KS, JFAST>(p, grid, stream);
+    static int v2 = -1;
+    if (v2 < 0) { const char *e = getenv("CHEBHIP_VEC_V2"); v2 = (e && e[0] == '1') ? 1 : 0; }
+    if (!v1 && !p.ablate && p.sink) {
+      if (custom || !v2) return launch_v3<KS, JFAST>(p, grid, stream);
+      return launch_v2<KS, JFAST>(p, grid, stream);
+    }
   }
+  if (custom) return hipErrorInvalidValue;                 // per-array geometry exists in the v3 kernel only
   hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
@@ -614,6 +933,11 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p) {
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
   const bool jfast = p.inner < 16;
+  if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: v3 only, every offset must stay 16-B aligned
+    if (m.KS < 16) return false;
+    const unsigned all = p.qmax | p.in_os | p.in_rs | p.acc_os | p.acc_rs | p.out_os | p.out_rs;
+    if (jfast ? ((p.in_os | p.acc_os | p.out_os) & 1) : (all & 1)) return false;
+  }
   if (jfast && (p.inner != 1 || (m.P & 1))) return false;
   if (!jfast && (p.inner & 1)) return false;
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };

@@ -28,6 +28,9 @@ def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_at
             F.neg_()
             ks.solve(op, F, dx, M=M)                    # J dx = -F, state of the last FormFunction
             total += ks.iterations
+            if ks.reason < 0:                           # KSP_DIVERGED_*: SNES stops with SNES_DIVERGED_LINEAR_SOLVE
+                raise RuntimeError("Newton step %d: linear solve diverged (reason %d after %d iterations, residual %.3e)"
+                                   % (it + 1, ks.reason, ks.iterations, ks.residual))
             x.add_(dx)
             op.function(x, b, F, gamma, exponent)
             fn = norm(F)

@@ -219,14 +219,14 @@ def _ell_worker(rank, world, port, dims, q):
         def gnorm(t):
             s = (t * t).sum().cpu(); dist.all_reduce(s); return float(s.sqrt())
         its, kits, fn = solve.newton_krylov(Shim, opshim, b, x, 4.0, 2.0, snes_rtol=1e-11, ksp_rtol=1e-12,
-                                            ksp_restart=min(256, G), ksp_max_it=20000, norm=gnorm)
+                                            ksp_restart=min(256, G), ksp_max_it=20000, snes_max_it=100, norm=gnorm)
         torch.cuda.synchronize()
         q.put((rank, n0, rf.cpu().numpy(), rm.cpu().numpy(), x.cpu().numpy(), its))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims", [(2, (16, 16)), (3, (10, 9, 8)), (3, (4, 6))], ids=str)
+@pytest.mark.parametrize("world,dims", [(2, (16, 16)), (3, (10, 9, 8)), (3, (4, 6)), (3, (12, 7))], ids=str)
 def test_elliptic_slab_ranks_match_oracle_and_solve(world, dims):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -247,15 +247,26 @@ def test_elliptic_slab_ranks_match_oracle_and_solve(world, dims):
     ref_m = orc.elliptic_mult(dims, vs, eta, deta, gradu, mode=orc.DIRECT)
     assert relerr(rf, ref_f) < TOL and relerr(rm, ref_m) < TOL
     # the distributed Newton-Krylov solve lands on the same discrete solution as a dense Newton on the oracle
+    assert len({r[5] for r in res}) == 1
+    # (a) path-independent: the distributed solution is a root of the ORACLE's residual
+    F, eta, deta, gradu = orc.elliptic_function(dims, x, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
+    assert np.linalg.norm(F) <= 1e-9 * np.linalg.norm(u2)
+    # (b) and, where full-step Newton from x = 0 contracts, the very root a dense Newton on the oracle finds.
+    # On an unresolved grid it does not: at 12 x 7 (gamma = 4) the residual wanders between 1e2 and 1e6 for
+    # thirty steps before it settles (tools/fuzz_dist.py found this case), the path is rounding-sensitive and two
+    # correct implementations may settle on different roots -- there only (a) is asserted.
     n = u.size
-    xo = np.zeros(n)
-    for _ in range(15):
+    xo = np.zeros(n); hist = []
+    for _ in range(60):
         F, eta, deta, gradu = orc.elliptic_function(dims, xo, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
-        if np.linalg.norm(F) < 1e-13 * np.linalg.norm(u2):
+        hist.append(np.linalg.norm(F))
+        if hist[-1] < 1e-13 * np.linalg.norm(u2):
             break
         J = np.empty((n, n)); e = np.zeros(n)
         for j in range(n):
             e[j] = 1.0; J[:, j] = orc.elliptic_mult(dims, e, eta, deta, gradu, mode=orc.DIRECT); e[j] = 0.0
         xo = xo - np.linalg.solve(J, F)
-    assert len({r[5] for r in res}) == 1
-    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    assert hist[-1] < 1e-13 * np.linalg.norm(u2), "dense Newton on the oracle did not converge"
+    monotone_tail = len(hist) <= 12
+    if monotone_tail:
+        assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)

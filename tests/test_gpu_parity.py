@@ -199,7 +199,9 @@ def test_elliptic_golden(ell_golden):
 
 
 @pytest.mark.parametrize("dims", [(32, 32), (5, 4), (3, 3), (40,), (64, 64, 64), (20, 18, 16), (6, 5, 4, 3), (33, 70, 9),
-                                  (12, 12, 12, 12, 12), (300, 20), (12, 260, 6), (514,)],
+                                  (12, 12, 12, 12, 12), (300, 20), (12, 260, 6), (514,),
+                                  # padded-accumulator layout of the constant-coefficient path (interior lines > 64, even)
+                                  (72, 68, 70), (100, 90), (200, 68, 98), (68, 132, 76), (71, 68, 70), (256, 130)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_elliptic_mult_vs_oracle(dims):
     """MatMult_Elliptic, linear Poisson state (config 1 is -dim 32,32)."""
@@ -215,6 +217,18 @@ def test_elliptic_mult_vs_oracle(dims):
 def test_elliptic_mult_128_vs_oracle():
     """BASELINE config 2: 3-D Poisson -dim 128,128,128."""
     dims = (128, 128, 128)
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED)
+    U = rng.standard_normal(op.global_size)
+    V = op.mult_host(U)
+    ref = orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=16)
+    assert relerr(V, ref) < TOL
+    op.destroy()
+
+
+def test_elliptic_mult_256_vs_oracle():
+    """BASELINE config 3 on one GPU: 3-D Poisson -dim 256,256,256, the bench workload, against the oracle."""
+    dims = (256, 256, 256)
     op = sp.EllipticOp(dims)
     rng = np.random.default_rng(SEED)
     U = rng.standard_normal(op.global_size)
