@@ -14,6 +14,22 @@
 #include "chebyshev.h"
 #include "chebhip.h"
 
+/* Device Vecs (-vec_type hip, build with -DCHEBHIP_USE_DEVICE_VECS): the arrays PETSc hands out belong to work
+ * queued on PETSc's own stream, so the chebhip launches go on THAT stream (PetscDeviceContextGetStreamHandle,
+ * PETSc >= 3.18); nothing is synchronised with the host and Vec{HIP}RestoreArray* keeps PETSc's ordering. */
+#if defined(PETSC_HAVE_HIP) && defined(CHEBHIP_USE_DEVICE_VECS)
+#include <petscdevice_hip.h>
+static PetscErrorCode cheb_petsc_stream(void **stream) {
+  PetscDeviceContext dctx;
+  void              *handle;
+  PetscFunctionBegin;
+  PetscCall(PetscDeviceContextGetCurrentContext(&dctx));
+  PetscCall(PetscDeviceContextGetStreamHandle(dctx, &handle));   /* hipStream_t* */
+  *stream = (void *)(*(hipStream_t *)handle);
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+#endif
+
 static PetscErrorCode cheb_err(int rc) {
   /* chebhip.h error codes -> PETSc classes (chebyshev.c:18,98,106,122 use PETSC_ERR_USER) */
   if (!rc) return PETSC_SUCCESS;
@@ -38,9 +54,12 @@ PetscErrorCode MatCreateCheb(MPI_Comm comm, int rank, int tr, int *dims, unsigne
   PetscFunctionBegin;
   PetscCall(VecGetSize(vx, &n));
   PetscCall(cheb_err(cheb_plan_create(rank, tr, dims, &plan)));
-  if (cheb_plan_size(plan) != (long)n) {      /* chebyshev.c:122 */
-    cheb_plan_destroy(plan);
-    SETERRQ(comm, PETSC_ERR_USER, "dimensions do not agree: n = %" PetscInt_FMT " but stride = %ld", n, cheb_plan_size(plan));
+  {
+    const long psize = cheb_plan_size(plan);   /* read before the plan is destroyed */
+    if (psize != (long)n) {                    /* chebyshev.c:122 */
+      cheb_plan_destroy(plan);
+      SETERRQ(comm, PETSC_ERR_USER, "dimensions do not agree: n = %" PetscInt_FMT " but stride = %ld", n, psize);
+    }
   }
   PetscCall(MatCreateShell(comm, n, n, n, n, plan, A));
   PetscCall(MatShellSetOperation(*A, MATOP_MULT, (void (*)(void))ChebMult));
@@ -56,11 +75,15 @@ PetscErrorCode ChebMult(Mat A, Vec vx, Vec vy) {
   PetscCall(MatShellGetContext(A, &plan));
 #if defined(PETSC_HAVE_HIP) && defined(CHEBHIP_USE_DEVICE_VECS)
   /* VECHIP vectors: no staging, asynchronous on PETSc's stream */
-  PetscCall(VecHIPGetArrayRead(vx, &x));
-  PetscCall(VecHIPGetArrayWrite(vy, &y));
-  PetscCall(cheb_err(cheb_apply(plan, x, y, NULL)));
-  PetscCall(VecHIPRestoreArrayWrite(vy, &y));
-  PetscCall(VecHIPRestoreArrayRead(vx, &x));
+  {
+    void *stream;
+    PetscCall(cheb_petsc_stream(&stream));
+    PetscCall(VecHIPGetArrayRead(vx, &x));
+    PetscCall(VecHIPGetArrayWrite(vy, &y));
+    PetscCall(cheb_err(cheb_apply(plan, x, y, stream)));
+    PetscCall(VecHIPRestoreArrayWrite(vy, &y));
+    PetscCall(VecHIPRestoreArrayRead(vx, &x));
+  }
 #else
   /* host Vecs, as the reference's VecGetArray (chebyshev.c:151-152): staged through HBM */
   PetscCall(VecGetArrayRead(vx, &x));
@@ -107,11 +130,23 @@ PetscErrorCode MatMult_Elliptic_hip(Mat A, Vec U, Vec V) {
   PetscScalar       *v;
   PetscFunctionBegin;
   PetscCall(MatShellGetContext(A, &op));
+#if defined(PETSC_HAVE_HIP) && defined(CHEBHIP_USE_DEVICE_VECS)
+  {
+    void *stream;
+    PetscCall(cheb_petsc_stream(&stream));
+    PetscCall(VecHIPGetArrayRead(U, &u));
+    PetscCall(VecHIPGetArrayWrite(V, &v));
+    PetscCall(cheb_err(ell_op_mult(op, u, v, stream)));   /* the Krylov hot loop: nothing crosses PCIe */
+    PetscCall(VecHIPRestoreArrayWrite(V, &v));
+    PetscCall(VecHIPRestoreArrayRead(U, &u));
+  }
+#else
   PetscCall(VecGetArrayRead(U, &u));
   PetscCall(VecGetArray(V, &v));
-  PetscCall(cheb_err(ell_op_mult_host(op, u, v)));      /* or ell_op_mult() on VECHIP arrays */
+  PetscCall(cheb_err(ell_op_mult_host(op, u, v)));        /* host Vecs: staged through HBM (plumbing, config 1) */
   PetscCall(VecRestoreArray(V, &v));
   PetscCall(VecRestoreArrayRead(U, &u));
+#endif
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -123,6 +158,19 @@ PetscErrorCode FormFunction_hip(SNES snes, Vec U, Vec rhs, void *void_ac) {
   PetscScalar       *r;
   (void)snes;
   PetscFunctionBegin;
+#if defined(PETSC_HAVE_HIP) && defined(CHEBHIP_USE_DEVICE_VECS)
+  {
+    void *stream;
+    PetscCall(cheb_petsc_stream(&stream));
+    PetscCall(VecHIPGetArrayRead(U, &u));
+    PetscCall(VecHIPGetArrayRead(ac->b, &b));
+    PetscCall(VecHIPGetArrayWrite(rhs, &r));
+    PetscCall(cheb_err(ell_op_function(ac->op, ac->gamma, ac->exponent, u, b, r, stream)));
+    PetscCall(VecHIPRestoreArrayWrite(rhs, &r));
+    PetscCall(VecHIPRestoreArrayRead(ac->b, &b));
+    PetscCall(VecHIPRestoreArrayRead(U, &u));
+  }
+#else
   PetscCall(VecGetArrayRead(U, &u));
   PetscCall(VecGetArrayRead(ac->b, &b));
   PetscCall(VecGetArray(rhs, &r));
@@ -130,6 +178,7 @@ PetscErrorCode FormFunction_hip(SNES snes, Vec U, Vec rhs, void *void_ac) {
   PetscCall(VecRestoreArray(rhs, &r));
   PetscCall(VecRestoreArrayRead(ac->b, &b));
   PetscCall(VecRestoreArrayRead(U, &u));
+#endif
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -147,22 +196,24 @@ PetscErrorCode MatDestroy_Elliptic_hip(Mat A) {
  * stokes_op handle.  The callbacks below take HIP vectors (-vec_type hip): nothing crosses PCIe inside the Krylov
  * loops.  StokesCreate (:257-344) -> stokes_op_create(d, dim, &c->op); stokes_op_set_rheology / _set_dirichlet /
  * _set_force at the places where stokes.C fills options->rheology (:470-480), c->dirichlet (:2003) and c->force. */
+#if defined(PETSC_HAVE_HIP) && defined(CHEBHIP_USE_DEVICE_VECS)
 typedef struct { stokes_op *op; KSP KSPSchurVelocity; Vec vG0, vG1; } StokesCtxHip;
 
 #define STOKES_SHELL(NAME, CALL)                                                            \
   PetscErrorCode NAME(Mat A, Vec xG, Vec yG) {                                              \
-    StokesCtxHip *c; const PetscScalar *x; PetscScalar *y;                                  \
+    StokesCtxHip *c; const PetscScalar *x; PetscScalar *y; void *stream;                    \
     PetscFunctionBegin;                                                                     \
     PetscCall(MatShellGetContext(A, &c));                                                   \
+    PetscCall(cheb_petsc_stream(&stream));                                                  \
     PetscCall(VecHIPGetArrayRead(xG, &x)); PetscCall(VecHIPGetArrayWrite(yG, &y));          \
     PetscCall(cheb_err(CALL));                                                              \
     PetscCall(VecHIPRestoreArrayWrite(yG, &y)); PetscCall(VecHIPRestoreArrayRead(xG, &x));  \
     PetscFunctionReturn(PETSC_SUCCESS);                                                     \
   }
-STOKES_SHELL(StokesMatMult_hip, stokes_op_mult(c->op, x, y, NULL))        /* stokes.C:499-519 */
-STOKES_SHELL(StokesMatMultVV_hip, stokes_op_mult_vv(c->op, x, y, NULL))   /* stokes.C:623-676 */
-STOKES_SHELL(StokesMatMultPV_hip, stokes_op_mult_pv(c->op, x, y, NULL))   /* stokes.C:557-566 */
-STOKES_SHELL(StokesMatMultVP_hip, stokes_op_mult_vp(c->op, x, y, NULL))   /* stokes.C:599-619 */
+STOKES_SHELL(StokesMatMult_hip, stokes_op_mult(c->op, x, y, stream))        /* stokes.C:499-519 */
+STOKES_SHELL(StokesMatMultVV_hip, stokes_op_mult_vv(c->op, x, y, stream))   /* stokes.C:623-676 */
+STOKES_SHELL(StokesMatMultPV_hip, stokes_op_mult_pv(c->op, x, y, stream))   /* stokes.C:557-566 */
+STOKES_SHELL(StokesMatMultVP_hip, stokes_op_mult_vp(c->op, x, y, stream))   /* stokes.C:599-619 */
 
 /* the inner solve of the Schur complement stays the user's KSP (options prefix svel_, stokes.C:338-341) */
 static int stokes_svel_solve(void *ctx, const double *rhs_dev, double *sol_dev, void *stream) {
@@ -175,14 +226,16 @@ static int stokes_svel_solve(void *ctx, const double *rhs_dev, double *sol_dev, 
   VecHIPResetArray(c->vG0); VecHIPResetArray(c->vG1);
   return (int)ierr;
 }
-STOKES_SHELL(StokesMatMultSchur_hip, stokes_op_mult_schur(c->op, x, y, stokes_svel_solve, c, NULL))   /* stokes.C:523-535 */
+STOKES_SHELL(StokesMatMultSchur_hip, stokes_op_mult_schur(c->op, x, y, stokes_svel_solve, c, stream))   /* stokes.C:523-535 */
 
 PetscErrorCode StokesFunction_hip(SNES snes, Vec xG, Vec yG, void *void_ctx) {               /* stokes.C:680-758 */
-  StokesCtxHip *c = (StokesCtxHip *)void_ctx; const PetscScalar *x; PetscScalar *y;
+  StokesCtxHip *c = (StokesCtxHip *)void_ctx; const PetscScalar *x; PetscScalar *y; void *stream;
   (void)snes;
   PetscFunctionBegin;
+  PetscCall(cheb_petsc_stream(&stream));
   PetscCall(VecHIPGetArrayRead(xG, &x)); PetscCall(VecHIPGetArrayWrite(yG, &y));
-  PetscCall(cheb_err(stokes_op_function(c->op, x, y, NULL)));
+  PetscCall(cheb_err(stokes_op_function(c->op, x, y, stream)));
   PetscCall(VecHIPRestoreArrayWrite(yG, &y)); PetscCall(VecHIPRestoreArrayRead(xG, &x));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
+#endif /* device Vecs: the Stokes callbacks exist only for VECHIP vectors */

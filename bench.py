@@ -9,11 +9,17 @@ Poisson state (gamma = 0: eta == 1, deta == 0), global in/out vectors resident i
                                                            (N > 1: the same 256^3 grid slab-split
                                                             over N ranks, RCCL all-to-all transposes;
                                                             strong scaling)
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (cheb_sweep_kernel) with the
-algorithmic bytes of SURVEY 8(d): 112 B/point per matvec (the six-ChebMult model), spread over the
-3 fused launches that now carry it; `cpu_baseline`
-times the CPU oracle (a port of the reference's pass structure; FFTW/PETSc are not installed)
-on this box's host cores, rank 0, N = 1 only.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (cheb_sweep_vec3_kernel,
+csrc/sweep_vec.hip) with the algorithmic bytes of SURVEY 8(d): 112 B/point per matvec (the six-ChebMult
+model), spread over the 3 launches that carry it.  That figure is a MODEL figure of merit: the
+constant-coefficient path moves fewer bytes than the model (one launch per direction instead of two sweeps),
+so `roofline.frac` is not HBM utilisation.  `roofline.traffic` holds the bytes a launch really moved (PMC
+counters, profiles/) when the committed measurement belongs to the sources being timed, and
+`roofline.hbm_real_frac` = traffic / launch time / 8 TB/s; `roofline.mfma_f64_frac` is the fraction of the
+FP64 matrix peak that actually bounds the kernel at P = 256.  `cpu_baseline` times the CPU oracle (a port of
+the reference's pass structure; FFTW/PETSc are not installed) on this box's host cores, rank 0, N = 1 only.
+`spinup` untimed matvecs run before the W warm-up steps (setup: an idle MI355X needs a few ms of load before
+its clocks settle) and are reported in the line.
 """
 import argparse
 import json
@@ -36,12 +42,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--spinup", type=int, default=200, help="untimed setup matvecs before the W warm-up steps")
+    ap.add_argument("--spinup", type=int, default=100, help="untimed setup matvecs before the W warm-up steps (reported as `spinup`)")
     ap.add_argument("--size", type=int, default=256, help="points per dimension P (BASELINE: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings of the other BASELINE configs")
     ap.add_argument("--cpu-threads", type=int, default=1)
     return ap.parse_args()
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (spectral-petsc_amd/csrc/*.hip, *.h, *.cpp, Makefile): ties a committed
+    counter measurement (profiles/traffic.json) to the code it was taken on."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "spectral-petsc_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def cpu_baseline(P, threads, U, V=None):
@@ -188,10 +205,13 @@ def main():
         alg_bytes_launch = BYTES_PER_POINT * npts / launches_per_step / world
         achieved = alg_bytes_launch / launch_s
         two_stage = os.environ.get("CHEBHIP_TWO_STAGE") == "1"
-        traffic = None      # HBM bytes per launch from the committed PMC profile of this kernel/config, if any
+        # HBM bytes per launch from the committed PMC profile -- only if it was taken on the very kernel sources
+        # being timed (hash of csrc/), otherwise null
+        traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step and not two_stage:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if (tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step and not two_stage
+                    and tj.get("csrc_sha256") == csrc_hash()):
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
@@ -200,14 +220,16 @@ def main():
         flops_launch = ((2.0 * P) if two_stage else float(P - 2)) * (float(P - 2) ** 3) / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
         out = {
             "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
-            "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D Poisson MatMult_Elliptic -dim %d,%d,%d (gamma=0), global N(0,1) input seed %d" % (P, P, P, SEED),
                        "P": P, "parallelism": parallelism, "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec2_kernel", "avg_launch_us": launch_s * 1e6,
+                         "frac_is": "model figure of merit: SURVEY 8(d) algorithmic bytes (112 B/point), not bytes moved",
+                         "hbm_real_frac": (traffic / launch_s / HBM_PEAK) if traffic else None,
+                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec3_kernel", "avg_launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "mfma_f64_tflops": flops_launch / launch_s / 1e12,
                          "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},

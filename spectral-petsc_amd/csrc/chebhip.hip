@@ -43,12 +43,14 @@ extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 // Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
 extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
-// Undocumented profiling hook: schedule switches of the 16-byte kernels (sweep_vec.hip v3: 1 = no stagger, 2 = no setprio, 4 = dense W)
+// Undocumented profiling hook: schedule switches of the 16-byte kernels (4 = dense accumulator W, 8 = flat-address kernel v3 instead of v4)
 extern "C" void chebhip_debug_variant(int bits) { sweep_set_variant(bits); }
 // Diagnostic builds (-DCHEB_STAMPS) only: device buffer of 256*8*4 uint64 receiving per-wave phase cycle sums.
 static const double *g_stamp_buf = nullptr;
-extern "C" void chebhip_debug_stamp_buffer(const void *dev) { g_stamp_buf = (const double *)dev; }
+static int g_stamp_cnt = 0;
+extern "C" void chebhip_debug_stamp_buffer(const void *dev) { g_stamp_buf = (const double *)dev; g_stamp_cnt = 0; }
 const double *chebhip_stamp_buf() { return g_stamp_buf; }
+int chebhip_stamp_next() { return g_stamp_cnt++; }
 
 static bool use_two_stage();
 
@@ -686,6 +688,7 @@ static int ell_mult_slab(ell_op *op, const double *U, double *V, hipStream_t st)
 extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
   // empty vectors (a slab that owns only boundary planes) may be NULL
   if (!op || ((!U || !V) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (U && U == V) return fail(CHEBHIP_ERR_ARG, "U and V must be distinct (MatMult never aliases its vectors)");
   if (op->slab) return ell_mult_slab(op, U, V, (hipStream_t)stream);
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -765,6 +768,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
 extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const double *U,
                                const double *b, double *rhs, void *stream) {
   if (!op || ((!U || !rhs) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (U && (U == rhs || b == rhs)) return fail(CHEBHIP_ERR_ARG, "rhs must not alias U or b");
   hipStream_t st = (hipStream_t)stream;
   int rc = ell_alloc_state(op);
   if (rc) return rc;

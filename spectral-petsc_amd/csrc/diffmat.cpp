@@ -47,6 +47,16 @@ void diffmat_dense_host(int P, double *D) {
     for (int j = 0; j < P; j++) D[(size_t)i * P + j] = (double)dentry(i, j, n);
 }
 
+// [m-tile][k-step][lane] -> [m-tile][k-step pair][lane][2]: a lane fetches two fragments with one 16-byte load
+static hipError_t upload_paired(const std::vector<double> &f, int MTP, int KS, double *dev) {
+  std::vector<double> g(f.size());
+  for (int mt = 0; mt < MTP; mt++)
+    for (int s = 0; s < KS; s++)
+      for (int l = 0; l < 64; l++)
+        g[(((size_t)mt * (KS / 2) + s / 2) * 64 + l) * 2 + (s & 1)] = f[((size_t)mt * KS + s) * 64 + l];
+  return hipMemcpy(dev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice);
+}
+
 // P > 256: the matrix does not fit the register file of a workgroup; cheb_sweep_long_kernel streams the dense
 // transpose from L2 instead (a correctness path for any extent the reference accepts, not a tuned one).
 static hipError_t diffmat_create_long(int P, DiffMat *out) {
@@ -99,13 +109,16 @@ hipError_t diffmat_create(int P, DiffMat *out) {
   m.P = P; m.H = H; m.KS = KS; m.MTP = MTP;
   hipError_t e = hipMalloc((void **)&m.fragE, (cnt + 8 + 1024) * sizeof(double));
   if (e != hipSuccess) return e;
-  e = hipMalloc((void **)&m.fragO, cnt * sizeof(double));
+  e = hipMalloc((void **)&m.fragO, 3 * cnt * sizeof(double));
   if (e != hipSuccess) { (void)hipFree(m.fragE); return e; }
+  m.fragE2 = m.fragO + cnt; m.fragO2 = m.fragO + 2 * cnt;
   m.zero = m.fragE + cnt;
   m.sink = m.zero + 8;
   e = hipMemset(m.zero, 0, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = upload_paired(fe, MTP, KS, m.fragE2);
+  if (e == hipSuccess) e = upload_paired(fo, MTP, KS, m.fragO2);
   if (e != hipSuccess) { (void)hipFree(m.fragE); (void)hipFree(m.fragO); return e; }
   *out = m;
   return hipSuccess;
@@ -152,13 +165,16 @@ hipError_t diffmat_create_lap(int P, DiffMat *out) {
   r.P = M; r.H = H; r.KS = KS; r.MTP = MTP; r.sym = 1;
   hipError_t e = hipMalloc((void **)&r.fragE, (cnt + 8 + 1024) * sizeof(double));
   if (e != hipSuccess) return e;
-  e = hipMalloc((void **)&r.fragO, cnt * sizeof(double));
+  e = hipMalloc((void **)&r.fragO, 3 * cnt * sizeof(double));
   if (e != hipSuccess) { (void)hipFree(r.fragE); return e; }
+  r.fragE2 = r.fragO + cnt; r.fragO2 = r.fragO + 2 * cnt;
   r.zero = r.fragE + cnt;
   r.sink = r.zero + 8;
   e = hipMemset(r.zero, 0, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(r.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(r.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = upload_paired(fe, MTP, KS, r.fragE2);
+  if (e == hipSuccess) e = upload_paired(fo, MTP, KS, r.fragO2);
   if (e != hipSuccess) { (void)hipFree(r.fragE); (void)hipFree(r.fragO); return e; }
   *out = r;
   return hipSuccess;
@@ -169,7 +185,7 @@ void diffmat_destroy(DiffMat *m) {
   if (m->fragO) (void)hipFree(m->fragO);
   if (m->longDT) (void)hipFree(m->longDT);
   if (m->longD) (void)hipFree(m->longD);
-  m->fragE = m->fragO = m->longDT = m->longD = nullptr;
+  m->fragE = m->fragO = m->fragE2 = m->fragO2 = m->longDT = m->longD = nullptr;
 }
 
 }  // namespace chebhip

@@ -346,13 +346,8 @@ static hipError_t launch_f(const SweepParams &p0, hipStream_t stream) {
   SweepParams p = p0;
   if (JFAST) p.ntiles = (p.ncols + NT - 1) / NT;
   else p.ntiles = (p.ncols / p.inner) * ((p.inner + NT - 1) / NT);
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    e = hipGetDeviceProperties(&prop, dev); if (e != hipSuccess) return e;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (cu_err != hipSuccess) return cu_err;
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
   if (grid == 0) return hipSuccess;
   switch (p.coef_mode) {

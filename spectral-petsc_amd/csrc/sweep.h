@@ -39,6 +39,7 @@ struct SweepParams {
   double alpha;
   int in_mode, out_mode;
   const double *fragE, *fragO;  // differentiation matrix halves in MFMA fragment order
+  const double *fragE2, *fragO2; // the same with the fragments of k-steps 2g, 2g+1 side by side ([m-tile][KS/2][64 lanes][2]): 16-byte loads
   const double *longDT;         // lines of more than 256 points: dense D^T ([j][i], P x P) instead of fragments
   const double *longD;          // ... and dense D (row-major) for the library-GEMM route
   const double *zero;           // a few zero doubles in HBM: the source of every masked-off load
@@ -48,7 +49,7 @@ struct SweepParams {
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
   int coef_mode;      // fused launches only: CoefMode; COEF_ETA: eta = in1; COEF_FULL: in2 = pairs {eta, c = deta * du0} (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
-  // Per-array geometry of the 16-byte kernels (sweep_vec.hip, v3); 0 = derive from P / inner / ncols.
+  // Per-array geometry of the 16-byte kernels (sweep_vec.hip, v3 / v4); 0 = derive from P / inner / ncols.
   //   COLFAST: a tile is (outer block o, NT neighbouring columns q < qmax); element (o, q, point j) of
   //            array X sits at o * X_os + q + j * X_rs.  The default is the dense tensor: nouter =
   //            ncols / inner, qmax = inner, X_os = P * inner, X_rs = inner.
@@ -57,6 +58,7 @@ struct SweepParams {
   // MatShell vectors stay in the reference's dense interior layout.
   unsigned nouter, qmax;
   unsigned in_os, in_rs, acc_os, acc_rs, out_os, out_rs;
+  unsigned in_bytes, acc_bytes, out_bytes;   // set by the launcher: exact sizes for the buffer descriptors of v4
   int variant;        // profiling only: experimental schedule switches (CHEBHIP_VARIANT)
   int ablate;         // profiling only (see sweep_set_ablate); 0 in production
 };
@@ -67,6 +69,7 @@ struct DiffMat {
   int KS = 0;          // k-steps of 4 (power of two >= 4 for the register-resident kernel); 0 = long lines (longDT)
   int MTP = 0;         // padded m-tiles of 16 rows = KS/4
   double *fragE = nullptr, *fragO = nullptr;  // device, [MTP][KS][64]
+  double *fragE2 = nullptr, *fragO2 = nullptr; // device, [MTP][KS/2][64][2] (same allocation as fragO)
   double *longDT = nullptr;                   // device, dense D^T for P > 256 (then fragE holds only zero/sink)
   double *longD = nullptr;                    // device, dense D (row-major) for the library-GEMM route of long lines
   double *zero = nullptr;                     // device, 8 zero doubles (tail of the fragE allocation)
@@ -97,6 +100,8 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 
 long sweep_launch_count();
+// compute units of the CURRENT device (cached per device id); 0 on error with *err set
+int sweep_num_cus(hipError_t *err);
 void sweep_set_ablate(int bits);
 void sweep_set_variant(int bits);
 int sweep_get_variant();

@@ -36,6 +36,20 @@ typedef unsigned u32;
 static std::atomic<long> g_launches{0};
 static int g_ablate = 0;   // profiling only: bit0 no global loads, bit1 no stores, bit2 no MFMA, bit3 no LDS park
 long sweep_launch_count() { return g_launches.load(); }
+int sweep_num_cus(hipError_t *err) {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { *err = e; return 0; }
+  if (dev >= 0 && dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) { *err = hipSuccess; return c; } }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) { *err = e; return 0; }
+  const int n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+  *err = hipSuccess;
+  return n;
+}
 void sweep_set_ablate(int bits) { g_ablate = bits; }
 int sweep_get_ablate() { return g_ablate; }
 static int g_variant = -1;  // profiling only: schedule switches of the 16-byte kernels (CHEBHIP_VARIANT / chebhip_debug_variant)
@@ -325,13 +339,8 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
   SweepParams p = p0;
   if (JFAST) p.ntiles = (p.ncols + NT - 1) / NT;
   else p.ntiles = (p.ncols / p.inner) * ((p.inner + NT - 1) / NT);
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    e = hipGetDeviceProperties(&prop, dev); if (e != hipSuccess) return e;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (cu_err != hipSuccess) return cu_err;
   // persistent: one 512-thread workgroup per CU (the register-resident matrix allows no more)
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
   if (grid == 0) return hipSuccess;
@@ -342,6 +351,7 @@ static hipError_t launch_t(const SweepParams &p0, hipStream_t stream) {
 
 }  // namespace chebhip
 const double *chebhip_stamp_buf();
+int chebhip_stamp_next();
 namespace chebhip {
 
 // ---------------------------------------------------------------------------------------------
@@ -476,13 +486,17 @@ static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate; p.variant = sweep_get_variant();
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate; p.variant = sweep_get_variant();
   p.longDT = m.longDT; p.longD = m.longD;
   if (m.KS == 0) return m.longDT ? launch_long(p, stream) : hipErrorInvalidValue;
   {
     static int novec = -1;
     if (novec < 0) { const char *e = getenv("CHEBHIP_NOVEC"); novec = (e && e[0] == '1') ? 1 : 0; }
-    if (!novec && sweep_vec_eligible(m, p)) { if (chebhip_stamp_buf()) p.in4 = chebhip_stamp_buf(); return sweep_vec_launch(m, p, stream); }
+    if (!novec && sweep_vec_eligible(m, p)) {
+      // diagnostic builds: three stamp areas of 256 x 8 x 8 words, used round-robin (one per launch of a 3-D matvec)
+      if (chebhip_stamp_buf()) p.in4 = chebhip_stamp_buf() + (size_t)(chebhip_stamp_next() % 3) * (256 * 8 * 8);
+      return sweep_vec_launch(m, p, stream);
+    }
   }
   const bool jfast = p.inner < 16;
   switch (m.KS) {

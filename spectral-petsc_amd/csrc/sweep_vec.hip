@@ -22,6 +22,7 @@ namespace chebhip {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void lds_barrier_v() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -326,8 +327,21 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #endif
 }
 
+// Diagnostic builds only (make diag, tools/stamp_probe3.py): in-kernel cycle stamps kept in SGPRs
+#ifdef CHEB_STAMPS
+#define STAMP3(k_) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    st_seg[k_] += t_ - st_prev; st_prev = t_; } while (0)
+#define STAMP3_MARK(v_) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); v_ = t_; st_prev = t_; } while (0)
+#else
+#define STAMP3(k_) do { } while (0)
+#define STAMP3_MARK(v_) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
-// v2: the same kernel with a STRAIGHT-LINE tile loop (KS >= 16, i.e. P > 64).
+// v3: the kernel with a STRAIGHT-LINE tile loop (KS >= 16, i.e. lines of more than 64 points), flat addressing.
+// Since round 2 it is the fallback of v4 for arrays of 1 GiB and more (v4's 32-bit buffer offsets do not reach).
 //
 // gfx950 retires loads and stores through one in-order counter (vmcnt).  hipcc places the waits,
 // and it can only count exactly through straight-line code: a branch around a load or store (a
@@ -335,262 +349,16 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 // it fall back to vmcnt(0), which waits for EVERYTHING in flight -- including the prefetch issued a
 // few hundred cycles earlier.  Here the loop body has no branch around any memory instruction:
 //   * the loop is instantiated once per wave group (GRPB), so the in-chain placement is static;
-//   * past the last tile the loads simply re-read the current tile (clamped index) and the
-//     parity split rewrites a buffer nobody reads;
-//   * masked-off loads read a zero word, masked-off stores go to a per-lane sink word;
+//   * masked-off loads (tiles past the workgroup's last, lanes outside the tile) read a zero word,
+//     masked-off stores go to a per-lane sink word;
 //   * STORE and ACC are separate instantiations.
 // With exact counts the operand pipeline can be deep: line chunks ride under two MFMA chains, the
 // VecAXPY operand is requested one sub-tile ahead into its own register set (X / Y), and the wait
-// for it does not cover the stores issued in between.
-template <int KS, bool JFAST, bool ACC>
-__global__ __launch_bounds__(512) void cheb_sweep_vec2_kernel(const SweepParams p) {
-  constexpr int MTP = KS / 4;
-  constexpr int NG = 8 / MTP;
-  constexpr int HP = 4 * KS;
-  constexpr int NSUB = 2;
-  constexpr int NT = 16 * NG * NSUB;
-  constexpr int LDJ = HP + 2;
-  constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
-  constexpr int ITEMS = HP * NT / 2 / 512;
-  constexpr int CH = ITEMS / NSUB;
-  constexpr int QSTEP = JFAST ? 512 / (HP / 2) : 512 / (NT / 2);
-  constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
-  constexpr int KSTR = JFAST ? 4 : 4 * NT;
-  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
-  constexpr int KR = KS - NFL;
-  static_assert(KS >= 16 && CH >= 1, "v2 needs two sub-tiles per tile");
-  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int mt = w % MTP, ng = w / MTP;
-  const int kq = lane >> 4, l16 = lane & 15;
-  const int odd = l16 & 1, l16e = l16 & ~1;
-  const int nn = p.P - 1, H = p.H;
-  const u32 inner = p.inner, ncols = p.ncols;
-  const u32 lineLen = (u32)p.P * inner;
-
-  double ae[KS], ao[KR > 0 ? KR : 1];
-  double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
-    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
-    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-
-  const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
-  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
-  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
-  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
-  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
-  const u32 t_step = gridDim.x / nxcd;
-
-  const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
-  const int ld_b = JFAST ? tid / (HP / 2) : tid / (NT / 2);
-  const int ld_lds0 = JFAST ? ld_b * LDJ + 2 * ld_a : ld_b * NT + ((2 * ld_a) ^ ((ld_b & 1) << 4));
-  const d2 *zero2 = (const d2 *)p.zero;
-  d2 *sink2 = (d2 *)p.sink + tid;                      // where masked-off stores go
-  const int i0 = mt * 16 + (JFAST ? l16 : kq);
-  const double alpha = p.alpha;
-
-  d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];               // line chunks in flight
-  d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];   // VecAXPY operands in flight (ACC only)
-
-  auto issue_loads = [&](u32 tl, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
-    if (!JFAST) {
-      const u32 o = tl / tpo, q0 = (tl - o * tpo) * NT;
-      const u32 q = q0 + 2 * ld_a;
-      const bool cv = q < inner;
-      const u32 base = o * lineLen + q;
-      int jp = ld_b + chunk * CH * QSTEP;
-      u32 rel = (u32)jp * inner;
-      const u32 top = base + (u32)nn * inner;
-      asm volatile("" : "+v"(rel), "+v"(jp));
-#pragma unroll
-      for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * inner) {
-        const bool ok = cv && jp < H;
-        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
-        rm[s] = *((ok && nn - jp != jp) ? (const d2 *)(p.in0 + (top - rel)) : zero2);
-      }
-    } else {
-      const int j = 2 * ld_a;
-#pragma unroll
-      for (int s = 0; s < CH; s++) {
-        const u32 c = tl * NT + ld_b + (chunk * CH + s) * QSTEP;
-        const bool ok = c < ncols && j < H;
-        const u32 base = (ok ? c : 0u) * lineLen;
-        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
-        rm[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
-      }
-    }
-  };
-  auto park_chunk = [&](int buf, int chunk, const d2 (&rj)[CH], const d2 (&rm)[CH]) {
-    double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
-#pragma unroll
-    for (int s = 0; s < CH; s++) {
-      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
-      d2 e, o;
-      if (!JFAST) {
-        const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn;
-        e = rj[s] + rm[s];
-        o = rj[s] - rm[s];
-        if (mid) o = d2{0.0, 0.0};
-      } else {
-        const bool v1 = 2 * ld_a + 1 < H;
-        e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
-        o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
-      }
-      *(d2 *)(dE + idx) = e;
-      *(d2 *)(dO + idx) = o;
-    }
-  };
-  // offsets of the two 16-B pieces (row i / mirror row n-i) of pair rp; see v1
-  auto geom = [&](u32 tl, int sub, u32 (&a_hi)[2], u32 (&a_lo)[2], bool (&ok_hi)[2], bool (&ok_lo)[2], bool (&fold)[2]) {
-    const int nb = (ng * NSUB + sub) * 16;
-    const u32 g_o = tl / tpo, g_q0 = (tl - g_o * tpo) * NT;
-    int i0o = i0;
-    asm volatile("" : "+v"(i0o));
-#pragma unroll
-    for (int rp = 0; rp < 2; rp++) {
-      const int r = 2 * rp + odd;
-      if (!JFAST) {
-        const u32 q = g_q0 + nb + l16e;
-        const int i = i0o + 4 * r;
-        const u32 b = g_o * lineLen + q;
-        ok_hi[rp] = q < inner && i < H;
-        ok_lo[rp] = ok_hi[rp] && (nn - i != i);
-        fold[rp] = false;
-        a_hi[rp] = b + (u32)i * inner;
-        a_lo[rp] = b + (u32)(nn - i) * inner;
-      } else {
-        const u32 c = tl * NT + nb + 4 * r + kq;
-        const int ie = mt * 16 + l16e;
-        const u32 b = (c < ncols ? c : 0u) * lineLen;
-        ok_hi[rp] = c < ncols && ie < H;
-        fold[rp] = ok_hi[rp] && (ie + 1 >= H);
-        ok_lo[rp] = ok_hi[rp] && !fold[rp];
-        a_hi[rp] = b + (u32)ie;
-        a_lo[rp] = b + (u32)(nn - ie - 1);
-      }
-    }
-  };
-  auto acc_issue = [&](u32 tl, int sub, d2 (&ah)[2], d2 (&al)[2]) {
-    if (!ACC) return;
-    u32 a_hi[2], a_lo[2]; bool ok_hi[2], ok_lo[2], fold[2];
-    geom(tl, sub, a_hi, a_lo, ok_hi, ok_lo, fold);
-#pragma unroll
-    for (int rp = 0; rp < 2; rp++) {
-      ah[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
-      al[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
-    }
-  };
-
-  u32 tile = t_lo + blockIdx.x / nxcd;
-  if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
-  {
-    // start-up: tile 0 -> LDS; then reproduce the in-flight state of the loop's back edge
-    // (operand X, chunk A, four stores) so that the wait counts of the loop hold from iteration 0
-    issue_loads(tile, 0, rjA, rmA); issue_loads(tile, 1, rjB, rmB);
-    park_chunk(0, 0, rjA, rmA); park_chunk(0, 1, rjB, rmB);
-    const u32 nx = (tile + t_step < t_hi) ? tile + t_step : tile;
-    acc_issue(tile, 0, accX_hi, accX_lo);
-    issue_loads(nx, 0, rjA, rmA);
-#pragma unroll
-    for (int q = 0; q < 4; q++) *sink2 = d2{0.0, 0.0};
-  }
-  lds_barrier_v();
-
-  auto run = [&](auto GRPB_) {
-    constexpr bool GRPB = decltype(GRPB_)::value;
-    constexpr int G_ISSUE = GRPB ? 0 : KS / 8, G_PARK = GRPB ? KS / 4 : 3 * KS / 8;
-    int cur = 0;
-    for (; tile < t_hi; tile += t_step) {
-      const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
-      const u32 nxc = (nxt < t_hi) ? nxt : tile, nx2c = (nxt2 < t_hi) ? nxt2 : tile;   // clamped: no branch around loads
-      const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
-
-      auto do_sub = [&](auto SUB_, d2 (&acc_hi)[2], d2 (&acc_lo)[2], auto &&issue_fn, auto &&park_fn) {
-        constexpr int sub = decltype(SUB_)::value;
-        const int nb = (ng * NSUB + sub) * 16;
-        u32 a_hi[2], a_lo[2];
-        bool ok_hi[2], ok_lo[2], fold[2];
-        geom(tile, sub, a_hi, a_lo, ok_hi, ok_lo, fold);
-
-        v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
-        const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
-        const double *fE = sE + frag, *fO = sO + frag;
-        double fb[2][4];
-        fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
-#pragma unroll
-        for (int g = 0; g < KS / 2; g++) {
-          const int cb = g & 1, nbuf = cb ^ 1;
-          if (g + 1 < KS / 2) {
-            fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
-            fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
-          }
-          __builtin_amdgcn_sched_barrier(0);             // fragment reads stay one group ahead of their MFMAs
-          if (g == G_ISSUE) issue_fn();
-          if (g == G_PARK) park_fn();
-          if (!JFAST) {
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g), fb[cb][2], co, 0, 0, 0);
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g + 1), fb[cb][3], co, 0, 0, 0);
-          } else {
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], AO(2 * g), co, 0, 0, 0);
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], AO(2 * g + 1), co, 0, 0, 0);
-          }
-        }
-
-        double hi[4], lo[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
-#pragma unroll
-        for (int rp = 0; rp < 2; rp++) {
-          const double own_hi = odd ? hi[2 * rp + 1] : hi[2 * rp], snd_hi = odd ? hi[2 * rp] : hi[2 * rp + 1];
-          const double own_lo = odd ? lo[2 * rp + 1] : lo[2 * rp], snd_lo = odd ? lo[2 * rp] : lo[2 * rp + 1];
-          const double rcv_hi = swap1(snd_hi), rcv_lo = swap1(snd_lo);
-          d2 vh = odd ? d2{rcv_hi, own_hi} : d2{own_hi, rcv_hi};
-          d2 vl;
-          if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
-          else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};
-          if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};
-          if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha * vl; }
-          else { vh = alpha * vh; vl = alpha * vl; }
-          *(ok_hi[rp] ? (d2 *)(p.out + a_hi[rp]) : sink2) = vh;     // unconditional: masked-off lanes hit the sink
-          *(ok_lo[rp] ? (d2 *)(p.out + a_lo[rp]) : sink2) = vl;
-        }
-      };
-
-      do_sub(std::integral_constant<int, 0>{}, accX_hi, accX_lo,
-             [&] { acc_issue(tile, 1, accY_hi, accY_lo); issue_loads(nxc, 1, rjB, rmB); },
-             [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
-      do_sub(std::integral_constant<int, 1>{}, accY_hi, accY_lo,
-             [&] { acc_issue(nxc, 0, accX_hi, accX_lo); issue_loads(nx2c, 0, rjA, rmA); },
-             [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
-      lds_barrier_v();
-      cur ^= 1;
-    }
-  };
-  if (w >= 4) run(std::true_type{}); else run(std::false_type{});
-}
-
-// ---------------------------------------------------------------------------------------------
-// v3: v2 plus
-//   * per-array geometry (sweep.h): input, VecAXPY operand and output may have different row pitches,
-//     so the accumulator of the constant-coefficient operator can keep its rows 128-B aligned while
-//     the MatShell vectors stay dense;
-//   * prefetches past the last tile of a workgroup read the zero word instead of re-reading the
-//     current tile (v2 clamped the tile index: 1.5 extra tile loads per workgroup of 8 tiles, +19 %
-//     input traffic);
-//   * STAGGER: the two waves of a SIMD run the same program between the same barriers, so they reach
-//     their matrix chains and their epilogues together and the matrix pipe idles during both
-//     epilogues.  Waves 4-7 defer the epilogue of a tile's second sub-tile to the start of the next
-//     tile (sums and operand stay in registers across the barrier): from then on one wave of a SIMD
-//     is in its chain while the other stores (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+// for it does not cover the stores issued in between.  Per-array geometry (sweep.h): input, VecAXPY
+// operand and output may have different row pitches.
+// Tried and dropped here (measured, round 2): deferring the second epilogue of waves 4-7 by one tile so that
+// one wave of a SIMD stores while the other is in its chain (MI355X_MICROARCH.md "Two waves per SIMD", item 9):
+// 257 us per 256^3 matvec against 255 without, 264 with s_setprio 1 on those waves.
 template <int KS, bool JFAST, bool ACC>
 __global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams p) {
   constexpr int MTP = KS / 4;
@@ -620,13 +388,6 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams 
 
   double ae[KS], ao[KR > 0 ? KR : 1];
   double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
-    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
-    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   const u32 tpo = JFAST ? 1u : (qmax + NT - 1) / NT;
   const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
@@ -738,7 +499,15 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams 
 
   u32 tile = t_lo + blockIdx.x / nxcd;
   if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
+  // the first tile's lines are requested BEFORE the matrix fragments: one memory round trip instead of two
   issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
+    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
+    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see sweep.hip
   park_chunk(0, 0, rjA, rmA); park_chunk(0, 1, rjB, rmB);
 
   // one MFMA chain over sub-tile `sub` of the LDS buffer at sE/sO; issue_fn / park_fn sit inside it
@@ -797,7 +566,6 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams 
     }
   };
 
-  // Waves 0-3 (and waves 4-7 with the stagger switched off): chain, epilogue, chain, epilogue, barrier.
   auto run_plain = [&](auto GRPB_) {
     constexpr bool GRPB = decltype(GRPB_)::value;
     constexpr int G_ISSUE = GRPB ? 0 : KS / 8, G_PARK = GRPB ? KS / 4 : 3 * KS / 8;
@@ -829,46 +597,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams 
       cur ^= 1;
     }
   };
-  // Waves 4-7, staggered: the epilogue of sub-tile 1 runs at the top of the next iteration.
-  auto run_stag = [&] {
-    constexpr int G_ISSUE = 0, G_PARK = KS / 4;
-    {
-      const u32 nx = tile + t_step;
-#pragma unroll
-      for (int q = 0; q < 4; q++) *sink2 = d2{0.0, 0.0};
-      acc_issue(tile, true, 0, accX_hi, accX_lo);
-      issue_loads(nx, nx < t_hi, 0, rjA, rmA);
-    }
-#pragma unroll
-    for (int rp = 0; rp < 2; rp++) { accY_hi[rp] = d2{0.0, 0.0}; accY_lo[rp] = d2{0.0, 0.0}; }
-    lds_barrier_v();
-    int cur = 0;
-    u32 ptile = tile; bool pvalid = false;
-    v4d ce1 = {0.0, 0.0, 0.0, 0.0}, co1 = {0.0, 0.0, 0.0, 0.0};
-    for (; tile < t_hi; tile += t_step) {
-      const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
-      const bool v1 = nxt < t_hi, v2 = nxt2 < t_hi;
-      const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
-      epilogue(ptile, pvalid, 1, ce1, co1, accY_hi, accY_lo);
-      __builtin_amdgcn_sched_barrier(0);
-      v4d ce0, co0;
-      chain(sE, sO, 0, G_ISSUE, G_PARK, ce0, co0,
-            [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
-            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
-      epilogue(tile, true, 0, ce0, co0, accX_hi, accX_lo);
-      chain(sE, sO, 1, G_ISSUE, G_PARK, ce1, co1,
-            [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
-            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
-      lds_barrier_v();
-      cur ^= 1;
-      ptile = tile; pvalid = true;
-    }
-    epilogue(ptile, pvalid, 1, ce1, co1, accY_hi, accY_lo);
-  };
-  if (w >= 4) {
-    if (!(p.variant & 2)) __builtin_amdgcn_s_setprio(1);   // the younger half loses VALU arbitration otherwise
-    if (p.variant & 1) run_plain(std::true_type{}); else run_stag();
-  } else run_plain(std::false_type{});
+  if (w >= 4) run_plain(std::true_type{}); else run_plain(std::false_type{});
 }
 
 template <int KS, bool JFAST>
@@ -879,10 +608,303 @@ static hipError_t launch_v3(const SweepParams &p, unsigned grid, hipStream_t str
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// v4: the straight-line kernel with as few VALU instructions as the algorithm allows.
+//
+// On gfx950 the FP64 MFMA and the VALU do not co-execute (SQ_VALU_MFMA_COEXEC_CYCLES reads 0 for every launch
+// of this kernel, profiles/r02_*; the FP64 matrix rate equals the FP64 vector rate): every vector instruction
+// of a wave is paid in matrix-pipe time, ~6 cycles each, and v3 issued 300-450 of them per tile and wave next
+// to 128 MFMAs (in-kernel stamps: an epilogue beside the partner wave's chain took 4,400 cycles).  Here
+//   * every global access is a raw BUFFER access: 32-bit byte offset = per-lane constant + one scalar per
+//     tile (one v_add), the hardware range check replaces every `ok ? address : dummy` select (out-of-range
+//     loads return 0, out-of-range stores are dropped; a masked lane gets offset 0x80000000);
+//   * loads are not masked at all: lanes outside the tile read other points of the SAME line (or zeros past
+//     the end of the array), which only meet zero entries of the matrix or feed columns that are never stored;
+//   * the lane exchange that makes 16-byte pieces is one DPP broadcast + one select per dword;
+//   * the centro-symmetry sign rides in the scalar factor of the mirror row.
+template <int KS, bool JFAST, bool ACC>
+__global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams p) {
+  constexpr int MTP = KS / 4;
+  constexpr int NG = 8 / MTP;
+  constexpr int HP = 4 * KS;
+  constexpr int NSUB = 2;
+  constexpr int NT = 16 * NG * NSUB;
+  constexpr int LDJ = HP + 2;
+  constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
+  constexpr int ITEMS = HP * NT / 2 / 512;
+  constexpr int CH = ITEMS / NSUB;
+  constexpr int QSTEP = JFAST ? 512 / (HP / 2) : 512 / (NT / 2);
+  constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
+  constexpr int KSTR = JFAST ? 4 : 4 * NT;
+  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
+  constexpr int KR = KS - NFL;
+  // offsets beyond every buffer (the launcher keeps them < 1 GiB): a per-lane constant may carry INVALID, the scalar
+  // part of an offset T_INVALID, and their sum must not wrap back into range
+  constexpr u32 INVALID = 0x80000000u, T_INVALID = 0x40000000u;
+  static_assert(KS >= 16 && CH >= 1, "v4 needs two sub-tiles per tile");
+  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
+
+#ifdef CHEB_STAMPS
+  unsigned long long st_seg[5] = {0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0, st_loop = 0;   // diagnostic build only: see v3
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  STAMP3_MARK(st_begin);
+  const int mt = w % MTP, ng = w / MTP;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const bool odd = l16 & 1; const int l16e = l16 & ~1;
+  const int nn = p.P - 1, H = p.H;
+  const u32 qmax = p.qmax;
+
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in0, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC ? p.acc : p.in0), 0, ACC ? p.acc_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
+  auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
+  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
+
+  double ae[KS], ao[KR > 0 ? KR : 1];
+  double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
+
+  const u32 tpo = JFAST ? 1u : (qmax + NT - 1) / NT;
+  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
+  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
+  const u32 t_step = gridDim.x / nxcd;
+
+  // loader slots as in v1: COLFAST (line pair 2*ld_a, point pair ld_b + s*QSTEP); JFAST (points 2*ld_a, 2*ld_a+1 of
+  // line ld_b + s*QSTEP).  Per-lane byte offsets of slot 0 (point / mirror); a slot adds a scalar
+  const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
+  const int ld_b = JFAST ? tid / (HP / 2) : tid / (NT / 2);
+  const int ld_lds0 = JFAST ? ld_b * LDJ + 2 * ld_a : ld_b * NT + ((2 * ld_a) ^ ((ld_b & 1) << 4));
+  const u32 in_os8 = p.in_os * 8u, in_rs8 = p.in_rs * 8u;
+  const u32 lj = JFAST ? (u32)ld_b * in_os8 + (u32)(2 * ld_a) * 8u : (u32)(2 * ld_a) * 8u + (u32)ld_b * in_rs8;
+  const u32 lm = JFAST ? (u32)ld_b * in_os8 + (u32)(nn - 2 * ld_a - 1) * 8u : (u32)(2 * ld_a) * 8u + (u32)(nn - ld_b) * in_rs8;
+  const u32 slot8 = JFAST ? (u32)QSTEP * in_os8 : (u32)QSTEP * in_rs8;      // byte step between two slots of a lane
+  // byte offset of a tile's origin in an array of geometry (os8, rs8), or INVALID past the workgroup's last tile
+  auto tile_off = [&](u32 tl, bool valid, u32 os8) -> u32 {
+    if (JFAST) return valid ? tl * NT * os8 : T_INVALID;
+    const u32 o = tl / tpo, q0 = (tl - o * tpo) * NT;
+    return valid ? o * os8 + q0 * 8u : T_INVALID;
+  };
+
+  d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
+  d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];
+
+  auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
+    const u32 t0 = tile_off(tl, true, in_os8);
+#pragma unroll
+    for (int s = 0; s < CH; s++) {
+      const u32 so = (u32)(chunk * CH + s) * slot8;                          // scalar
+      rj[s] = ld16(r_in, lj + (valid ? t0 + so : T_INVALID));
+      rm[s] = ld16(r_in, lm + (valid ? (JFAST ? t0 + so : t0 - so) : T_INVALID));
+    }
+  };
+  const bool oddP = (p.P & 1) != 0;                    // a self-paired middle point exists (COLFAST only; JFAST needs even P)
+  auto park_chunk = [&](int buf, int chunk, const d2 (&rj)[CH], const d2 (&rm)[CH]) {
+    double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
+#pragma unroll
+    for (int s = 0; s < CH; s++) {
+      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
+      d2 e, o;
+      if (!JFAST) {
+        e = rj[s] + rm[s];
+        o = rj[s] - rm[s];                             // the middle point of an odd line is its own mirror: o = 0
+        if (oddP) { const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn; if (mid) e = rj[s]; }
+      } else {
+        e = d2{rj[s].x + rm[s].y, rj[s].y + rm[s].x};
+        o = d2{rj[s].x - rm[s].y, rj[s].y - rm[s].x};
+      }
+      *(d2 *)(dE + idx) = e;
+      *(d2 *)(dO + idx) = o;
+    }
+  };
+
+  // Output side.  After the lane exchange a lane owns, for rp = 0, 1: accumulator row r = 2 rp + odd, and of it the
+  // two adjacent columns (COLFAST) / points (JFAST) starting at the even lane of its pair.  Per-lane byte offsets of
+  // the two 16-B pieces (row i / mirror row n-i) relative to the sub-tile's origin; rows that do not exist are INVALID
+  const int i0 = mt * 16 + (JFAST ? l16 : kq);
+  u32 o_hi[2], o_lo[2], c_hi[2], c_lo[2];              // out / acc geometry
+  bool fold[2] = {false, false};
+#pragma unroll
+  for (int rp = 0; rp < 2; rp++) {
+    const int r = 2 * rp + (odd ? 1 : 0);
+    if (!JFAST) {
+      const int i = i0 + 4 * r;
+      const bool ok = i < H, okl = ok & (nn - i != i);
+      o_hi[rp] = ok ? (u32)l16e * 8u + (u32)i * (p.out_rs * 8u) : INVALID;
+      o_lo[rp] = okl ? (u32)l16e * 8u + (u32)(nn - i) * (p.out_rs * 8u) : INVALID;
+      c_hi[rp] = (u32)l16e * 8u + (u32)(ok ? i : 0) * (p.acc_rs * 8u);
+      c_lo[rp] = (u32)l16e * 8u + (u32)(ok ? nn - i : 0) * (p.acc_rs * 8u);
+    } else {
+      const int ie = mt * 16 + l16e;                   // points ie, ie+1 of line 4 r + kq; mirrors n-ie-1, n-ie
+      const bool ok = ie < H;
+      fold[rp] = ok & (ie + 1 >= H);                   // H odd: point ie+1 IS the mirror of ie
+      const bool okl = ok & !fold[rp];
+      o_hi[rp] = ok ? (u32)(4 * r + kq) * (p.out_os * 8u) + (u32)ie * 8u : INVALID;
+      o_lo[rp] = okl ? (u32)(4 * r + kq) * (p.out_os * 8u) + (u32)(nn - ie - 1) * 8u : INVALID;
+      c_hi[rp] = (u32)(4 * r + kq) * (p.acc_os * 8u) + (u32)(ok ? ie : 0) * 8u;
+      c_lo[rp] = (u32)(4 * r + kq) * (p.acc_os * 8u) + (u32)(ok ? nn - ie - 1 : 0) * 8u;
+    }
+  }
+  const u32 out_os8 = p.out_os * 8u, acc_os8 = p.acc_os * 8u;
+  const u32 sub8_out = JFAST ? 16u * out_os8 : 16u * 8u, sub8_acc = JFAST ? 16u * acc_os8 : 16u * 8u;   // sub-tile 1 vs 0
+  const u32 ng8_out = (u32)ng * NSUB * sub8_out, ng8_acc = (u32)ng * NSUB * sub8_acc;
+  const double alpha = p.alpha, alpha_lo = p.sym ? p.alpha : -p.alpha;      // mirror row: D: b - a; D D: a - b
+
+  auto acc_issue = [&](u32 tl, bool valid, int sub, d2 (&ah)[2], d2 (&al)[2]) {
+    if (!ACC) return;
+    const u32 t0 = tile_off(tl, valid, acc_os8) + ng8_acc + (u32)sub * sub8_acc;
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) { ah[rp] = ld16(r_acc, c_hi[rp] + t0); al[rp] = ld16(r_acc, c_lo[rp] + t0); }
+  };
+
+  u32 tile = t_lo + blockIdx.x / nxcd;
+  if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
+  // the first tile's lines are requested BEFORE the matrix fragments: one memory round trip instead of two
+  issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
+#pragma unroll
+  for (int g = 0; g < KS / 2; g++) {                   // two fragments per 16-byte load
+    const d2 ve = ((const d2 *)p.fragE2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+    const d2 vo = ((const d2 *)p.fragO2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+    ae[2 * g] = ve.x; ae[2 * g + 1] = ve.y;
+    if (2 * g < KR) ao[2 * g] = vo.x; else aoL[(2 * g - KR) * 64] = vo.x;
+    if (2 * g + 1 < KR) ao[2 * g + 1] = vo.y; else aoL[(2 * g + 1 - KR) * 64] = vo.y;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see sweep.hip
+#ifdef CHEB_STAMPS
+  unsigned long long st_wait = 0, st_park = 0;
+  STAMP3_MARK(st_wait);
+#endif
+  park_chunk(0, 0, rjA, rmA); park_chunk(0, 1, rjB, rmB);
+#ifdef CHEB_STAMPS
+  STAMP3_MARK(st_park);
+#endif
+
+  auto chain = [&](const double *sE, const double *sO, int sub, int g_issue, int g_park, v4d &ce, v4d &co, auto &&issue_fn, auto &&park_fn) {
+    const int nb = (ng * NSUB + sub) * 16;
+    ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
+    const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
+    const double *fE = sE + frag, *fO = sO + frag;
+    double fb[2][4];
+    fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
+#pragma unroll
+    for (int g = 0; g < KS / 2; g++) {
+      const int cb = g & 1, nbuf = cb ^ 1;
+      if (g + 1 < KS / 2) {
+        fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
+        fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
+      }
+      __builtin_amdgcn_sched_barrier(0);               // fragment reads stay one group ahead of their MFMAs
+      if (g == g_issue) issue_fn();
+      if (g == g_park) park_fn();
+      if (!JFAST) {
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g), fb[cb][2], co, 0, 0, 0);
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g + 1), fb[cb][3], co, 0, 0, 0);
+      } else {
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], AO(2 * g), co, 0, 0, 0);
+        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], AO(2 * g + 1), co, 0, 0, 0);
+      }
+    }
+  };
+  // value of the even lane of each pair / of the odd lane, in both lanes (DPP quad_perm [0,0,2,2] / [1,1,3,3])
+  auto bc_even = [](double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xA0, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xA0, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  };
+  auto bc_odd = [](double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  };
+  // out = (acc +) alpha * (sums) for sub-tile `sub` of tile tl
+  auto epilogue = [&](u32 tl, int sub, const v4d &ce, const v4d &co, const d2 (&acc_hi)[2], const d2 (&acc_lo)[2]) {
+    u32 t0 = tile_off(tl, true, out_os8) + ng8_out + (u32)sub * sub8_out;
+    u32 t0v = t0;                                      // per-lane: INVALID where the tile's last column block ends early
+    if (!JFAST) {
+      const u32 o = tl / tpo, q = (tl - o * tpo) * NT + (ng * NSUB + sub) * 16 + l16e;
+      t0v = (q < qmax) ? t0 : T_INVALID;
+    }
+    double hi[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = ce[r] - co[r]; }
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) {
+      // even lane: row 2rp of its own column and of the odd neighbour's; odd lane: row 2rp+1 of the even neighbour's and its own
+      const double ha = hi[2 * rp], hb = hi[2 * rp + 1], la = lo[2 * rp], lb = lo[2 * rp + 1];
+      // the broadcasts run with EVERY lane active (a DPP read of a lane that EXEC has switched off returns 0), the
+      // selects come after
+      const double hbe = bc_even(hb), hao = bc_odd(ha), lbe = bc_even(lb), lao = bc_odd(la);
+      d2 vh = d2{odd ? hbe : ha, odd ? hb : hao};                         // ascending columns / points
+      d2 vl;
+      if (!JFAST) vl = d2{odd ? lbe : la, odd ? lb : lao};
+      else vl = d2{odd ? lb : lao, odd ? lbe : la};                       // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
+      if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha_lo * vl; }
+      else { vh = alpha * vh; vl = alpha_lo * vl; }
+      if (JFAST && (H & 1)) { if (fold[rp]) vh = d2{vh.x, vl.y}; }       // (y_ie, y_{n-ie}): adjacent when H is odd
+      st16(r_out, o_hi[rp] + t0v, vh);
+      st16(r_out, o_lo[rp] + t0v, vl);
+    }
+  };
+
+  auto run = [&](auto GRPB_) {
+    constexpr bool GRPB = decltype(GRPB_)::value;
+    constexpr int G_ISSUE = GRPB ? 0 : KS / 8, G_PARK = GRPB ? KS / 4 : 3 * KS / 8;
+    {
+      // reproduce the in-flight state of the loop's back edge (operand X, chunk A, four stores) so
+      // that the wait counts of the loop hold from iteration 0
+      const u32 nx = tile + t_step;
+      acc_issue(tile, true, 0, accX_hi, accX_lo);
+      issue_loads(nx, nx < t_hi, 0, rjA, rmA);
+#pragma unroll
+      for (int q = 0; q < 4; q++) st16(r_out, INVALID, d2{0.0, 0.0});
+    }
+    lds_barrier_v();
+    STAMP3_MARK(st_loop);
+    int cur = 0;
+    for (; tile < t_hi; tile += t_step) {
+      const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
+      const bool v1 = nxt < t_hi, v2 = nxt2 < t_hi;
+      const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
+      v4d ce, co;
+      chain(sE, sO, 0, G_ISSUE, G_PARK, ce, co,
+            [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
+            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
+      STAMP3(0);
+      epilogue(tile, 0, ce, co, accX_hi, accX_lo);
+      STAMP3(1);
+      chain(sE, sO, 1, G_ISSUE, G_PARK, ce, co,
+            [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
+            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
+      STAMP3(2);
+      epilogue(tile, 1, ce, co, accY_hi, accY_lo);
+      STAMP3(3);
+      lds_barrier_v();
+      STAMP3(4);
+      cur ^= 1;
+    }
+  };
+  if (w >= 4) run(std::true_type{}); else run(std::false_type{});
+#ifdef CHEB_STAMPS
+  {
+    unsigned long long st_end; STAMP3_MARK(st_end);
+    if (lane == 0 && p.in4) {
+      unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)blockIdx.x * 8 + w) * 8;
+      dbg[0] = st_seg[0]; dbg[1] = st_seg[1]; dbg[2] = st_seg[2]; dbg[3] = st_seg[3]; dbg[4] = st_seg[4];
+      dbg[5] = st_loop - st_begin; dbg[6] = st_wait - st_begin; dbg[7] = st_park - st_begin; (void)st_end;
+    }
+  }
+#endif
+}
+
 template <int KS, bool JFAST>
-static hipError_t launch_v2(const SweepParams &p, unsigned grid, hipStream_t stream) {
-  if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec2_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((cheb_sweep_vec2_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
+static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t stream) {
+  if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
 }
@@ -891,7 +913,7 @@ template <int KS, bool JFAST>
 static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   constexpr int MTP = KS / 4, NG = 8 / MTP, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB;
   SweepParams p = p0;
-  const bool custom = p.qmax != 0 || p.in_os != 0;         // per-array geometry given by the caller (v3 only)
+  const bool custom = p.qmax != 0 || p.in_os != 0;         // per-array geometry given by the caller (v3 / v4 only)
   if (JFAST) {
     if (!p.in_os) p.in_os = (unsigned)p.P;
     if (!p.acc_os) p.acc_os = (unsigned)p.P;
@@ -905,26 +927,30 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
     if (!p.out_os) { p.out_os = (unsigned)p.P * p.inner; p.out_rs = p.inner; }
     p.ntiles = p.nouter * ((p.qmax + NT - 1) / NT);
   }
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    e = hipGetDeviceProperties(&prop, dev); if (e != hipSuccess) return e;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (cu_err != hipSuccess) return cu_err;
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
   if (grid == 0) return hipSuccess;
   if constexpr (KS >= 16) {
     static int v1 = -1;
     if (v1 < 0) { const char *e = getenv("CHEBHIP_VEC_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
-    static int v2 = -1;
-    if (v2 < 0) { const char *e = getenv("CHEBHIP_VEC_V2"); v2 = (e && e[0] == '1') ? 1 : 0; }
     if (!v1 && !p.ablate && p.sink) {
-      if (custom || !v2) return launch_v3<KS, JFAST>(p, grid, stream);
-      return launch_v2<KS, JFAST>(p, grid, stream);
+      // byte sizes of the three arrays for the buffer descriptors of v4 (exact: the range check is the mask)
+      const unsigned long long P_ = (unsigned long long)p.P;
+      auto span = [&](unsigned os, unsigned rs) -> unsigned long long {
+        if (JFAST) return ((unsigned long long)(p.ncols - 1) * os + P_) * 8ull;
+        return ((unsigned long long)(p.nouter - 1) * os + (p.qmax - 1) + (P_ - 1) * rs + 1) * 8ull;
+      };
+      const unsigned long long bi = span(p.in_os, p.in_rs), ba = span(p.acc_os, p.acc_rs), bo = span(p.out_os, p.out_rs);
+      const bool fits = bi < 0x38000000ull && ba < 0x38000000ull && bo < 0x38000000ull;   // < 1 GiB minus slack: see T_INVALID
+      if (fits && !(p.variant & 8)) {
+        p.in_bytes = (unsigned)bi; p.acc_bytes = (unsigned)ba; p.out_bytes = (unsigned)bo;
+        return launch_v4<KS, JFAST>(p, grid, stream);
+      }
+      return launch_v3<KS, JFAST>(p, grid, stream);
     }
   }
-  if (custom) return hipErrorInvalidValue;                 // per-array geometry exists in the v3 kernel only
+  if (custom) return hipErrorInvalidValue;                 // per-array geometry exists in the v3 / v4 kernels only
   hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
@@ -933,7 +959,7 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p) {
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
   const bool jfast = p.inner < 16;
-  if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: v3 only, every offset must stay 16-B aligned
+  if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: v3 / v4 only, every offset must stay 16-B aligned
     if (m.KS < 16) return false;
     const unsigned all = p.qmax | p.in_os | p.in_rs | p.acc_os | p.acc_rs | p.out_os | p.out_rs;
     if (jfast ? ((p.in_os | p.acc_os | p.out_os) & 1) : (all & 1)) return false;

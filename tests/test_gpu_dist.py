@@ -251,22 +251,26 @@ def test_elliptic_slab_ranks_match_oracle_and_solve(world, dims):
     # (a) path-independent: the distributed solution is a root of the ORACLE's residual
     F, eta, deta, gradu = orc.elliptic_function(dims, x, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
     assert np.linalg.norm(F) <= 1e-9 * np.linalg.norm(u2)
-    # (b) and, where full-step Newton from x = 0 contracts, the very root a dense Newton on the oracle finds.
-    # On an unresolved grid it does not: at 12 x 7 (gamma = 4) the residual wanders between 1e2 and 1e6 for
-    # thirty steps before it settles (tools/fuzz_dist.py found this case), the path is rounding-sensitive and two
-    # correct implementations may settle on different roots -- there only (a) is asserted.
+    # (b) and the very root a dense Newton iteration on the oracle finds, with the same backtracking line search
+    # as solve.newton_krylov.  Full steps alone do not contract on an unresolved grid: at 12 x 7 (gamma = 4) the
+    # residual wanders between 1e2 and 1e6 for thirty steps (tools/fuzz_dist.py found this case in round 1), the
+    # path is rounding-sensitive; with the line search both iterations converge in 6-7 steps to the same root.
     n = u.size
-    xo = np.zeros(n); hist = []
-    for _ in range(60):
-        F, eta, deta, gradu = orc.elliptic_function(dims, xo, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
-        hist.append(np.linalg.norm(F))
-        if hist[-1] < 1e-13 * np.linalg.norm(u2):
+    xo = np.zeros(n); hist = []; halved = 0
+    F, eta, deta, gradu = orc.elliptic_function(dims, xo, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
+    for _ in range(100):
+        fn = np.linalg.norm(F); hist.append(fn)
+        if fn < 1e-13 * np.linalg.norm(u2):
             break
         J = np.empty((n, n)); e = np.zeros(n)
         for j in range(n):
             e[j] = 1.0; J[:, j] = orc.elliptic_mult(dims, e, eta, deta, gradu, mode=orc.DIRECT); e[j] = 0.0
-        xo = xo - np.linalg.solve(J, F)
+        dx = -np.linalg.solve(J, F); lam = 1.0
+        while True:
+            F, eta, deta, gradu = orc.elliptic_function(dims, xo + lam * dx, u2, dv, 4.0, 2.0, mode=orc.DIRECT)
+            if np.linalg.norm(F) <= (1.0 - 1e-4 * lam) * fn or lam <= 1e-6:
+                break
+            lam *= 0.5; halved += 1
+        xo = xo + lam * dx
     assert hist[-1] < 1e-13 * np.linalg.norm(u2), "dense Newton on the oracle did not converge"
-    monotone_tail = len(hist) <= 12
-    if monotone_tail:
-        assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)

@@ -30,19 +30,27 @@ def gpu_solve(dims):
     return xs, u, its, kits, fn
 
 
-def oracle_newton(dims, steps=12):
-    """Dense Newton on the oracle's FormFunction / MatMult_Elliptic (small sizes only)."""
+def oracle_newton(dims, steps=40):
+    """Dense Newton with the backtracking line search of solve.newton_krylov on the oracle's FormFunction /
+    MatMult_Elliptic (small sizes only)."""
     u, u2, dv = orc.elliptic_exact(dims, 0, gamma=GAMMA, exponent=EXPO, cos_scale=COS)
     n = u.size
     x = np.zeros(n)
+    F, eta, deta, gradu = orc.elliptic_function(dims, x, u2, dv, GAMMA, EXPO, mode=orc.DIRECT)
     for _ in range(steps):
-        F, eta, deta, gradu = orc.elliptic_function(dims, x, u2, dv, GAMMA, EXPO, mode=orc.DIRECT)
-        if np.linalg.norm(F) < 1e-13 * np.linalg.norm(u2):
+        fn = np.linalg.norm(F)
+        if fn < 1e-13 * np.linalg.norm(u2):
             break
         J = np.empty((n, n)); e = np.zeros(n)
         for j in range(n):
             e[j] = 1.0; J[:, j] = orc.elliptic_mult(dims, e, eta, deta, gradu, mode=orc.DIRECT); e[j] = 0.0
-        x = x - np.linalg.solve(J, F)
+        dx = -np.linalg.solve(J, F); lam = 1.0
+        while True:
+            F, eta, deta, gradu = orc.elliptic_function(dims, x + lam * dx, u2, dv, GAMMA, EXPO, mode=orc.DIRECT)
+            if np.linalg.norm(F) <= (1.0 - 1e-4 * lam) * fn or lam <= 1e-6:
+                break
+            lam *= 0.5
+        x = x + lam * dx
     return x
 
 

@@ -141,3 +141,42 @@ def test_stokes_linearity_config5_size():
     assert torch.isfinite(y3).all()
     assert (torch.linalg.norm(1.5 * y1 - 0.5 * y2 - y3) / torch.linalg.norm(y3)).item() < 1e-11
     op.destroy()
+
+
+def _power_state_test(dims, nthreads):
+    """StokesFunction with the power law of README:52, then StokesMatMult linearised about it (Newton), vs the oracle."""
+    N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
+    rng = np.random.default_rng(SEED)
+    x, dv, force, v = rng.standard_normal(g), rng.standard_normal(ndv), rng.standard_normal(g), rng.standard_normal(g)
+    op = sp.StokesOp(dims)
+    op.set_rheology(*POWER); op.set_dirichlet(dv); op.set_force(force)
+    yf = run(op.function, x, g)
+    ym = run(op.mult, v, g)
+    op.destroy()
+    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=orc.FAST, nthreads=nthreads)
+    ref_m = orc.stokes_mult(dims, v, eta, deta, strain, mode=orc.FAST, nthreads=nthreads)
+    assert relerr(yf, ref_f) < 1e-9 and relerr(ym, ref_m) < 1e-9
+
+
+def test_stokes_power_law_config5_size_vs_oracle():
+    """BASELINE config 5 at its size and rheology: -dim 128,128,128 -rheology 1 (KS = 16 sweeps, power-law node kernel)."""
+    _power_state_test((128, 128, 128), 16)
+
+
+def test_stokes_power_law_96_vs_oracle():
+    _power_state_test((96, 80, 72), 16)
+
+
+@pytest.mark.parametrize("dims", [(96, 96, 96), (128, 128, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_stokes_blocks_large_vs_oracle(dims):
+    """Linear VV / PV / VP / MatMult on lines of 65..128 points (the KS = 16 kernels) vs the oracle."""
+    N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
+    rng = np.random.default_rng(SEED)
+    v, p, x = rng.standard_normal(gv), rng.standard_normal(gp), rng.standard_normal(g)
+    op = sp.StokesOp(dims)
+    op.set_dirichlet(np.zeros(ndv)); op.set_force(np.zeros(g))
+    assert relerr(run(op.mult_vv, v, gv), orc.stokes_mult_vv(dims, v, mode=orc.FAST, nthreads=16)) < 1e-10
+    assert relerr(run(op.mult_pv, v, gp), orc.stokes_divergence(dims, v, mode=orc.FAST, nthreads=16)) < 1e-10
+    assert relerr(run(op.mult_vp, p, gv), orc.stokes_mult_vp(dims, p, mode=orc.FAST, nthreads=16)) < 1e-9
+    assert relerr(run(op.mult, x, g), orc.stokes_mult(dims, x, mode=orc.FAST, nthreads=16)) < 1e-9
+    op.destroy()
