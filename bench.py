@@ -9,7 +9,7 @@ Poisson state (gamma = 0: eta == 1, deta == 0), global in/out vectors resident i
                                                            (N > 1: the same 256^3 grid slab-split
                                                             over N ranks, RCCL all-to-all transposes;
                                                             strong scaling)
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (cheb_sweep_vec3_kernel,
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (cheb_sweep_vec4_kernel,
 csrc/sweep_vec.hip) with the algorithmic bytes of SURVEY 8(d): 112 B/point per matvec (the six-ChebMult
 model), spread over the 3 launches that carry it.  That figure is a MODEL figure of merit: the
 constant-coefficient path moves fewer bytes than the model (one launch per direction instead of two sweeps),
@@ -229,7 +229,7 @@ def main():
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "frac_is": "model figure of merit: SURVEY 8(d) algorithmic bytes (112 B/point), not bytes moved",
                          "hbm_real_frac": (traffic / launch_s / HBM_PEAK) if traffic else None,
-                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec3_kernel", "avg_launch_us": launch_s * 1e6,
+                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec4_kernel", "avg_launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "mfma_f64_tflops": flops_launch / launch_s / 1e12,
                          "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},

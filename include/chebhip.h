@@ -228,6 +228,53 @@ double chebhip_fgmres_residual(const chebhip_fgmres *k);  /* last (recurrence) r
 int chebhip_fgmres_reason(const chebhip_fgmres *k);
 
 /* ------------------------------------------------------------------------- */
+/* The finite-difference preconditioner of the reference:  */
+/* FormJacobian's 2d+1-point matrix P on the collocation nodes                  */
+/* (elliptic.C:537-590; handed to PCILU, elliptic.C:184-185) and its per-       */
+/* component twin MatVVPC of StokesPCSetUp0 (stokes.C:1160-1241).  The matrix   */
+/* lives on the device as coefficient arrays; the approximate solve is a fast   */
+/* diagonalisation of its constant-coefficient part (dense line transforms on   */
+/* the sweep kernel), used alone or inside `sweeps` inner GMRES steps on P.      */
+/* Vectors: the operator's global vectors (scalar: g; Stokes: velocity gv).     */
+/* ------------------------------------------------------------------------- */
+typedef struct chebhip_fdpc chebhip_fdpc;
+int ell_pc_create(ell_op *op, chebhip_fdpc **out);          /* MatCreateSeqAIJ(.., 1+2d, ..) + PCILU, elliptic.C:163,184 */
+int stokes_pc_create(stokes_op *op, chebhip_fdpc **out);    /* MatVVPC, stokes.C:1160-1241 (-pcvel 0)                    */
+int chebhip_fdpc_destroy(chebhip_fdpc *pc);
+/* FormJacobian / StokesPCSetUp0: (re)assemble P from the operator's current eta, deta (and gradu): call after
+ * ell_op_function / stokes_op_function or set_state.  Done implicitly on first use. */
+int chebhip_fdpc_update(chebhip_fdpc *pc, void *stream);
+int chebhip_fdpc_set_sweeps(chebhip_fdpc *pc, int sweeps);  /* inner GMRES steps on P per apply (default 1; 0: P_1^-1 (r/eta) alone) */
+/* y = P x: MatMult on the assembled matrix (tests; the defect correction). */
+int chebhip_fdpc_mult(chebhip_fdpc *pc, const double *x_dev, double *y_dev, void *stream);
+/* z ~= P^-1 r.  Shape of chebhip_apply_fn with ctx = the handle: pass as the M of chebhip_fgmres_solve. */
+int chebhip_fdpc_apply(void *pc, const double *r_dev, double *z_dev, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* The block preconditioners of the Stokes saddle-point system:  */
+/* StokesPCApply0..3 (stokes.C:1714-1817) with the inner solves KSPVelocity,    */
+/* KSPSchur and KSPSchurVelocity (stokes.C:328-341) on device vectors.          */
+/* ------------------------------------------------------------------------- */
+typedef struct stokes_saddle stokes_saddle;
+int stokes_saddle_create(stokes_op *op, stokes_saddle **out);
+int stokes_saddle_destroy(stokes_saddle *s);
+/* -pc_saddle_type (stokes.C:177-187): 0 block LU, 1 upper triangular, 2 block diagonal, 3 lower triangular. */
+int stokes_saddle_set_type(stokes_saddle *s, int type);
+/* Inner solves: which = 0 KSPVelocity (-vel_), 1 KSPSchur (-schur_), 2 KSPSchurVelocity (-svel_); max_it GMRES
+ * iterations at most (<= 30) to relative tolerance rtol.  For the two velocity solves max_it = 0 means
+ * -ksp_type preonly: one application of the MatVVPC solve.  Defaults (README:43): 4 / 3 / preonly, rtol 1e-5. */
+int stokes_saddle_set_inner(stokes_saddle *s, int which, int max_it, double rtol);
+/* Inner GMRES steps on MatVVPC inside its approximate solve (see chebhip_fdpc_set_sweeps); default 0. */
+int stokes_saddle_set_pc_sweeps(stokes_saddle *s, int sweeps);
+/* StokesPCSetUp0 (stokes.C:1160-1241): re-assemble MatVVPC from the operator's current eta. */
+int stokes_saddle_setup(stokes_saddle *s, void *stream);
+/* y = M^-1 x on full global vectors (the pressure part of y has zero mean: KSPSetNullSpace, stokes.C:1017-1019).
+ * Shape of chebhip_apply_fn with ctx = the handle. */
+int stokes_saddle_apply(void *s, const double *x_dev, double *y_dev, void *stream);
+/* MatVV applies (which = 0) / MatSchur applies (1) spent by the inner solves of the last apply. */
+int stokes_saddle_iterations(const stokes_saddle *s, int which);
+
+/* ------------------------------------------------------------------------- */
 /* Instrumentation (the reference has none: SURVEY 5.1).                      */
 /* ------------------------------------------------------------------------- */
 /* Number of sweep-kernel launches issued by this process so far. */

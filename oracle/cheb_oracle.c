@@ -737,3 +737,46 @@ int orc_stokes_exact(int d, const int *dims, int exact, double *U, double *U2, d
   free(ixL);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * FormJacobian's preconditioning matrix P (elliptic.C:537-590) and, with gradu == NULL, one velocity
+ * component of MatVVPC (StokesPCSetUp0, stokes.C:1181-1226): rows in global (interior) order, 2d+1 entries
+ * each -- cols[r*(2d+1)+0] = r (diagonal), then the (-1, +1) neighbours per dimension; a neighbour on the
+ * boundary has column -1, which MatSetValues ignores (value kept for inspection).
+ * eta, deta: N local values; gradu: d*N (gradu[j][i]) or NULL.
+ * ------------------------------------------------------------------------------------------- */
+int orc_fd_matrix(int d, const int *dims, const double *eta, const double *deta, const double *gradu,
+                  int *cols, double *vals) {
+  if (d < 1 || d > 10) return 6;
+  long N = 1; for (int j = 0; j < d; j++) N *= dims[j];
+  int *ixL = build_ixL(d, dims, N);
+  long ls[10]; { long s = 1; for (int j = d - 1; j >= 0; j--) { ls[j] = s; s *= dims[j]; } }
+  int ind[10] = {0};
+  const int W = 2 * d + 1;
+  for (long i = 0; i < N; i++) {                               /* BlockIt order, elliptic.C:561 */
+    if (ixL[i] >= 0) {                                         /* :563 */
+      const long r = ixL[i];
+      int *J = cols + r * W; double *v = vals + r * W;
+      J[0] = (int)r; v[0] = 0.0; int k = 1;                    /* :564 */
+      for (int j = 0; j < d; j++) {
+        const long iM = i - ls[j], iP = i + ls[j];             /* it.shift(j, -1 / +1), :566-567 */
+        const double x0 = cos(ind[j] * ORC_PI / (dims[j] - 1)), xMM = cos((ind[j] - 1) * ORC_PI / (dims[j] - 1)),
+                     xPP = cos((ind[j] + 1) * ORC_PI / (dims[j] - 1));                                 /* :569 */
+        const double xM = 0.5 * (xMM + x0), idxM = 1.0 / (x0 - xMM), xP = 0.5 * (x0 + xPP), idxP = 1.0 / (xPP - x0), idx = 1.0 / (xP - xM);   /* :570 */
+        const double eM = 0.5 * (eta[iM] + eta[i]), eP = 0.5 * (eta[iP] + eta[i]);
+        double deM = 0, du0M = 0, deP = 0, du0P = 0;
+        if (gradu) {                                           /* :571-572 */
+          deM = 0.5 * (deta[iM] + deta[i]); du0M = 0.5 * (gradu[(long)j * N + iM] + gradu[(long)j * N + i]);
+          deP = 0.5 * (deta[iP] + deta[i]); du0P = 0.5 * (gradu[(long)j * N + iP] + gradu[(long)j * N + i]);
+        }
+        J[k] = ixL[iM]; v[k] = -idx * (idxM * eM - 0.5 * deM * du0M); k++;                            /* :573 */
+        J[k] = ixL[iP]; v[k] = -idx * (idxP * eP + 0.5 * deP * du0P); k++;                            /* :574 */
+        v[0] += idx * (idxP * eP + idxM * eM - 0.5 * (deP * du0P - deM * du0M));                       /* :575 */
+      }
+    }
+    for (int j = d - 1; j >= 0; j--) { if (++ind[j] < dims[j]) break; ind[j] = 0; }
+  }
+  free(ixL);
+  return 0;
+}
+

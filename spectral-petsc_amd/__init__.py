@@ -40,6 +40,10 @@ ABI_SYMBOLS = [
     "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations", "stokes_op_set_inner_reduce",
     "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
     "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason", "chebhip_fgmres_set_reduce",
+    "ell_pc_create", "stokes_pc_create", "chebhip_fdpc_destroy", "chebhip_fdpc_update", "chebhip_fdpc_set_sweeps",
+    "chebhip_fdpc_mult", "chebhip_fdpc_apply",
+    "stokes_saddle_create", "stokes_saddle_destroy", "stokes_saddle_set_type", "stokes_saddle_set_inner",
+    "stokes_saddle_setup", "stokes_saddle_apply", "stokes_saddle_iterations", "stokes_saddle_set_pc_sweeps",
 ]
 
 
@@ -124,6 +128,21 @@ def lib():
         L.chebhip_fgmres_residual.restype = C.c_double
         L.chebhip_fgmres_reason.argtypes = [vp]
         L.chebhip_fgmres_set_reduce.argtypes = [vp, vp, vp]
+        L.ell_pc_create.argtypes = [vp, C.POINTER(vp)]
+        L.stokes_pc_create.argtypes = [vp, C.POINTER(vp)]
+        L.chebhip_fdpc_destroy.argtypes = [vp]
+        L.chebhip_fdpc_update.argtypes = [vp, vp]
+        L.chebhip_fdpc_set_sweeps.argtypes = [vp, C.c_int]
+        L.chebhip_fdpc_mult.argtypes = [vp, vp, vp, vp]
+        L.chebhip_fdpc_apply.argtypes = [vp, vp, vp, vp]
+        L.stokes_saddle_create.argtypes = [vp, C.POINTER(vp)]
+        L.stokes_saddle_destroy.argtypes = [vp]
+        L.stokes_saddle_set_type.argtypes = [vp, C.c_int]
+        L.stokes_saddle_set_inner.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+        L.stokes_saddle_setup.argtypes = [vp, vp]
+        L.stokes_saddle_apply.argtypes = [vp, vp, vp, vp]
+        L.stokes_saddle_iterations.argtypes = [vp, C.c_int]
+        L.stokes_saddle_set_pc_sweeps.argtypes = [vp, C.c_int]
         _lib = L
     return _lib
 
@@ -474,6 +493,83 @@ class StokesOp:
             pass
 
 
+class FdPc:
+    """The finite-difference preconditioner of the reference on the device: FormJacobian's matrix P
+    (elliptic.C:537-590) for an EllipticOp, MatVVPC (stokes.C:1160-1241) on velocity vectors for a StokesOp.
+    `apply` is an approximate solve with P (fast diagonalisation + `sweeps` defect corrections); pass the object as
+    the `M` of Fgmres.solve."""
+
+    def __init__(self, op, sweeps=1):
+        h = C.c_void_p()
+        kind = type(op).__name__
+        _chk((lib().ell_pc_create if kind == "EllipticOp" else lib().stokes_pc_create)(op._h, C.byref(h)))
+        self._h = h
+        self._op = op                     # the handle reads the operator's state: keep it alive
+        self.n = op.global_size if kind == "EllipticOp" else op.velocity_size
+        _chk(lib().chebhip_fdpc_set_sweeps(h, sweeps))
+
+    def update(self):
+        """FormJacobian / StokesPCSetUp0: re-assemble from the operator's current eta, deta (gradu)."""
+        _chk(lib().chebhip_fdpc_update(self._h, _stream()))
+
+    def mult(self, x, y):
+        _chk(lib().chebhip_fdpc_mult(self._h, _dev_ptr(x, self.n), _dev_ptr(y, self.n), _stream()))
+        return y
+
+    def apply(self, r, z):
+        _chk(lib().chebhip_fdpc_apply(self._h, _dev_ptr(r, self.n), _dev_ptr(z, self.n), _stream()))
+        return z
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            lib().chebhip_fdpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class StokesSaddlePc:
+    """StokesPCApply0..3 (stokes.C:1714-1817) on the device: block LU / upper / diagonal / lower preconditioners of the
+    saddle-point system, with the inner solves KSPVelocity, KSPSchur, KSPSchurVelocity (stokes.C:328-341).
+    Pass the object as the `M` of Fgmres.solve around StokesOp.mult."""
+
+    def __init__(self, op, saddle_type=0, vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0):
+        h = C.c_void_p()
+        _chk(lib().stokes_saddle_create(op._h, C.byref(h)))
+        self._h = h
+        self._op = op
+        self.n = op.global_size
+        _chk(lib().stokes_saddle_set_type(h, saddle_type))
+        _chk(lib().stokes_saddle_set_pc_sweeps(h, pc_sweeps))
+        for which, (m, rtol) in enumerate((vel, schur, svel)):
+            _chk(lib().stokes_saddle_set_inner(h, which, m, rtol))
+
+    def setup(self):
+        """StokesPCSetUp0: call after StokesOp.function has changed the viscosity."""
+        _chk(lib().stokes_saddle_setup(self._h, _stream()))
+
+    def apply(self, x, y):
+        _chk(lib().stokes_saddle_apply(self._h, _dev_ptr(x, self.n), _dev_ptr(y, self.n), _stream()))
+        return y
+
+    inner_iterations = property(lambda self: (lib().stokes_saddle_iterations(self._h, 0), lib().stokes_saddle_iterations(self._h, 1)))
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            lib().stokes_saddle_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class Fgmres:
     """Restarted flexible GMRES on device vectors (KSPFGMRES's role, elliptic.C:181-185).
 
@@ -497,6 +593,10 @@ class Fgmres:
         if op is None:
             return None, None
         kind = type(op).__name__
+        if kind == "FdPc":
+            return C.cast(lib().chebhip_fdpc_apply, C.c_void_p), op._h
+        if kind == "StokesSaddlePc":
+            return C.cast(lib().stokes_saddle_apply, C.c_void_p), op._h
         if kind in ("EllipticOp", "StokesOp"):
             name = {"EllipticOp": "ell_op_", "StokesOp": "stokes_op_"}[kind] + entry
             return C.cast(getattr(lib(), name), C.c_void_p), op._h

@@ -2,6 +2,7 @@
 // that sit between sweeps.  All heavy arithmetic is in sweep.hip.
 #include "../../include/chebhip.h"
 #include "sweep.h"
+#include "ops.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -383,6 +384,17 @@ static int ell_alloc_state(ell_op *op) {
     }
     op->cdirty = true;
   }
+  return 0;
+}
+
+int ell_op_fd_view(ell_op *op, chebhip::FdView *v) {
+  if (!op || !v) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (op->slab) return fail(CHEBHIP_ERR_ARG, "the finite-difference preconditioner is not available in slab mode");
+  if (op->d > 10) return fail(CHEBHIP_ERR_DIMS, "d > 10");
+  int rc = ell_alloc_state(op); if (rc) return rc;
+  v->d = op->d; v->dims = op->dims.data(); v->N = op->N; v->G = op->G; v->ixL = op->ixL;
+  v->eta = op->eta; v->deta = op->deta;
+  for (int k = 0; k < op->d; k++) v->gradu[k] = op->gradu[k];
   return 0;
 }
 

@@ -124,27 +124,15 @@ hipError_t diffmat_create(int P, DiffMat *out) {
   return hipSuccess;
 }
 
-// Second-derivative operator of a zero-Dirichlet line, restricted to its interior:
-//   L = (D D)[1..n-1, 1..n-1],  M = P-2 points.
-// For constant coefficients the two sweeps of a direction, D_k (1 * D_k w0) with w0 = 0 at both ends
-// (elliptic.C:305-334 with eta = 1, deta = 0), collapse into y = L x on the interior values.  L is
-// centro-SYMMETRIC (L[m-i][m-j] = L[i][j], m = M-1), so with e, o as above
-//     y_i = (ME e)_i + (MO o)_i,   y_{m-i} = (ME e)_i - (MO o)_i      (note the sign vs. D).
-// The product is formed in long double and rounded once.
-hipError_t diffmat_create_lap(int P, DiffMat *out) {
-  const int n = P - 1, M = P - 2, m = M - 1;
-  const int H = (M + 1) / 2;
+// Fragments of a dense M x M matrix A (row-major, long double) that is centro-symmetric (sym = 1:
+// A[m-i][m-j] = A[i][j], m = M-1) or centro-antisymmetric (sym = 0).  With e, o as above
+//     y_i = (ME e)_i + (MO o)_i,   y_{m-i} = (ME e)_i - (MO o)_i   (sym = 1; sym = 0: (MO o)_i - (ME e)_i).
+hipError_t diffmat_from_dense(int M, const long double *A, int sym, DiffMat *out) {
+  if (M < 1 || M > 256) return hipErrorInvalidValue;
+  const int m = M - 1, H = (M + 1) / 2;
   int KS = 4;
   while (4 * KS < H) KS *= 2;
   const int MTP = KS / 4;
-  std::vector<long double> D((size_t)P * P), L((size_t)M * M);
-  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) D[(size_t)i * P + j] = dentry(i, j, n);
-  for (int i = 0; i < M; i++)
-    for (int j = 0; j < M; j++) {
-      long double s = 0.0L;
-      for (int q = 0; q < P; q++) s += D[(size_t)(i + 1) * P + q] * D[(size_t)q * P + (j + 1)];
-      L[(size_t)i * M + j] = s;
-    }
   const size_t cnt = (size_t)MTP * KS * 64;
   std::vector<double> fe(cnt, 0.0), fo(cnt, 0.0);
   for (int mt = 0; mt < MTP; mt++)
@@ -153,16 +141,16 @@ hipError_t diffmat_create_lap(int P, DiffMat *out) {
         const int i = mt * 16 + (l & 15), j = 4 * s + (l >> 4);
         if (i >= H || j >= H) continue;
         long double me, mo;
-        if (2 * j == m) { me = L[(size_t)i * M + j]; mo = 0.0L; }
+        if (2 * j == m) { me = A[(size_t)i * M + j]; mo = 0.0L; }
         else {
-          const long double a = L[(size_t)i * M + j], b = L[(size_t)i * M + (m - j)];
+          const long double a = A[(size_t)i * M + j], b = A[(size_t)i * M + (m - j)];
           me = 0.5L * (a + b); mo = 0.5L * (a - b);
         }
         fe[((size_t)mt * KS + s) * 64 + l] = (double)me;
         fo[((size_t)mt * KS + s) * 64 + l] = (double)mo;
       }
   DiffMat r;
-  r.P = M; r.H = H; r.KS = KS; r.MTP = MTP; r.sym = 1;
+  r.P = M; r.H = H; r.KS = KS; r.MTP = MTP; r.sym = sym;
   hipError_t e = hipMalloc((void **)&r.fragE, (cnt + 8 + 1024) * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMalloc((void **)&r.fragO, 3 * cnt * sizeof(double));
@@ -178,6 +166,121 @@ hipError_t diffmat_create_lap(int P, DiffMat *out) {
   if (e != hipSuccess) { (void)hipFree(r.fragE); (void)hipFree(r.fragO); return e; }
   *out = r;
   return hipSuccess;
+}
+
+// Second-derivative operator of a zero-Dirichlet line, restricted to its interior:
+//   L = (D D)[1..n-1, 1..n-1],  M = P-2 points.
+// For constant coefficients the two sweeps of a direction, D_k (1 * D_k w0) with w0 = 0 at both ends
+// (elliptic.C:305-334 with eta = 1, deta = 0), collapse into y = L x on the interior values.  L is
+// centro-SYMMETRIC.  The product is formed in long double and rounded once.
+hipError_t diffmat_create_lap(int P, DiffMat *out) {
+  const int n = P - 1, M = P - 2;
+  std::vector<long double> D((size_t)P * P), L((size_t)M * M);
+  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) D[(size_t)i * P + j] = dentry(i, j, n);
+  for (int i = 0; i < M; i++)
+    for (int j = 0; j < M; j++) {
+      long double s = 0.0L;
+      for (int q = 0; q < P; q++) s += D[(size_t)(i + 1) * P + q] * D[(size_t)q * P + (j + 1)];
+      L[(size_t)i * M + j] = s;
+    }
+  return diffmat_from_dense(M, L.data(), 1, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast diagonalisation of the finite-difference preconditioner (elliptic.C:556-579 with eta = 1, deta = 0;
+// stokes.C:1181-1226 per velocity component): on the tensor grid that matrix is  sum_k I x .. x T_k x .. x I  with
+// the 1-D three-point operator T on the interior Gauss-Lobatto nodes,
+//     (T u)_i = -idx (idxM u_{i-1} + idxP u_{i+1}) + idx (idxP + idxM) u_i,
+//     idxM = 1/(x_i - x_{i-1}), idxP = 1/(x_{i+1} - x_i), idx = 1/(xP - xM), xM, xP the midpoints.
+// T = H^-1 K with H = diag(-(xP - xM)) > 0 and K symmetric positive definite, so T = S Lambda S^-1 with
+// S = H^-1/2 W, S^-1 = W^T H^1/2, W the orthonormal eigenvectors of H^-1/2 K H^-1/2 (implicit QL, long double).
+// ---------------------------------------------------------------------------------------------
+// EISPACK tql2: eigenvalues d[] and eigenvectors z (row-major n x n, identity on entry) of the symmetric
+// tridiagonal matrix with diagonal d[] and sub-diagonal e[1..n-1] (e[0] unused)
+static bool tql2(int n, std::vector<long double> &d, std::vector<long double> &e, std::vector<long double> &z) {
+  for (int i = 1; i < n; i++) e[i - 1] = e[i];
+  e[n - 1] = 0.0L;
+  long double f = 0.0L, tst1 = 0.0L;
+  for (int l = 0; l < n; l++) {
+    const long double h0 = fabsl(d[l]) + fabsl(e[l]);
+    if (tst1 < h0) tst1 = h0;
+    int m = l;
+    while (m < n - 1) { if (tst1 + fabsl(e[m]) == tst1) break; m++; }
+    if (m != l) {
+      int iter = 0;
+      do {
+        if (++iter > 200) return false;
+        const long double g0 = d[l];
+        long double p = (d[l + 1] - g0) / (2.0L * e[l]);
+        long double r = hypotl(p, 1.0L);
+        d[l] = e[l] / (p + (p < 0 ? -r : r));
+        d[l + 1] = e[l] * (p + (p < 0 ? -r : r));
+        const long double dl1 = d[l + 1];
+        long double h = g0 - d[l];
+        for (int i = l + 2; i < n; i++) d[i] -= h;
+        f += h;
+        p = d[m];
+        long double c = 1.0L, c2 = c, c3 = c, s = 0.0L, s2 = 0.0L;
+        const long double el1 = e[l + 1];
+        for (int i = m - 1; i >= l; i--) {
+          c3 = c2; c2 = c; s2 = s;
+          const long double g = c * e[i];
+          h = c * p;
+          r = hypotl(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r; c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          for (int k = 0; k < n; k++) {
+            h = z[(size_t)k * n + i + 1];
+            z[(size_t)k * n + i + 1] = s * z[(size_t)k * n + i] + c * h;
+            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (tst1 + fabsl(e[l]) > tst1);
+    }
+    d[l] += f;
+  }
+  return true;
+}
+
+// S (nodal <- modal), S^-1 and the eigenvalues of the 1-D operator T on the M = P-2 interior nodes of a line
+bool fdm_line(int P, std::vector<long double> &S, std::vector<long double> &Sinv, std::vector<long double> &lam) {
+  const int n = P - 1, M = P - 2;
+  if (M < 1) return false;
+  std::vector<long double> x(P), h(M), kd(M), ke(M, 0.0L);
+  for (int i = 0; i < P; i++) x[i] = cosl(PI_L * i / n);
+  for (int q = 0; q < M; q++) {
+    const int i = q + 1;
+    const long double idxM = 1.0L / (x[i] - x[i - 1]), idxP = 1.0L / (x[i + 1] - x[i]);
+    h[q] = -0.5L * (x[i + 1] - x[i - 1]);              // -(xP - xM) > 0
+    kd[q] = -(idxP + idxM);                            // K = -(reference's bracket): positive diagonal
+    if (q > 0) ke[q] = idxM;                           // K[q][q-1] = idxM < 0
+  }
+  std::vector<long double> d(M), e(M, 0.0L), W((size_t)M * M, 0.0L);
+  for (int q = 0; q < M; q++) { d[q] = kd[q] / h[q]; if (q > 0) e[q] = ke[q] / sqrtl(h[q] * h[q - 1]); W[(size_t)q * M + q] = 1.0L; }
+  if (!tql2(M, d, e, W)) return false;
+  S.assign((size_t)M * M, 0.0L); Sinv.assign((size_t)M * M, 0.0L); lam = d;
+  for (int i = 0; i < M; i++)
+    for (int j = 0; j < M; j++) {
+      S[(size_t)i * M + j] = W[(size_t)i * M + j] / sqrtl(h[i]);
+      Sinv[(size_t)j * M + i] = W[(size_t)i * M + j] * sqrtl(h[i]);
+    }
+  return true;
+}
+
+// centro-symmetric (part = 1) or centro-antisymmetric (part = 0) part of a dense M x M matrix
+void centro_part(int M, const std::vector<long double> &A, int part, std::vector<long double> &out) {
+  out.resize((size_t)M * M);
+  const int m = M - 1;
+  for (int i = 0; i < M; i++)
+    for (int j = 0; j < M; j++) {
+      const long double a = A[(size_t)i * M + j], b = A[(size_t)(m - i) * M + (m - j)];
+      out[(size_t)i * M + j] = part ? 0.5L * (a + b) : 0.5L * (a - b);
+    }
 }
 
 void diffmat_destroy(DiffMat *m) {

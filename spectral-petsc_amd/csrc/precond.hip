@@ -1,0 +1,327 @@
+// precond.hip -- the finite-difference preconditioner of the reference on the device.
+//
+// The reference preconditions its Krylov solves with a low-order matrix on the collocation nodes:
+//   * FormJacobian (elliptic.C:537-590): the 2d+1-point finite-difference matrix P of
+//     -div(eta grad u) - div(deta u grad u0) on the Gauss-Lobatto grid, Dirichlet rows eliminated, handed to
+//     PCILU with 2 levels of fill (elliptic.C:184-185);
+//   * StokesPCSetUp0 (stokes.C:1160-1241): the same stencil with eta only, per velocity component (MatVVPC),
+//     inside KSPVelocity / KSPSchurVelocity (stokes.C:328-341).
+// Here P is kept as 2d+1 coefficient arrays in the interior (global-vector) layout and applied by a stencil
+// kernel (fd_mult: what MatMult on the AIJ matrix would give, used by the tests and by the defect correction
+// below).  The approximate solve that ILU provides in the reference is replaced by something that suits the
+// chip: on the tensor grid the constant-coefficient part of P is  sum_k I x .. x T_k x .. x I  with a 1-D
+// three-point operator T_k, which is diagonalised ONCE (diffmat.cpp: fdm_line), so that
+//     P_1^-1 = (S_0 x S_1 x S_2) diag(1 / (l_i + l_j + l_k)) (S_0^-1 x S_1^-1 x S_2^-1)
+// is 2d batched dense line transforms -- the very sweep kernel the operator itself runs on (each transform
+// is applied as its centro-symmetric plus its centro-antisymmetric part, two launches) -- and one pointwise
+// scaling.  For eta == 1 that is the exact inverse of P; for variable coefficients the approximate solve is
+// `sweeps` iterations of GMRES on P z = r with P_1^-1 (1/eta) as its right preconditioner (sweeps = 0: that
+// preconditioner alone) -- a varying, hence flexible, preconditioner for the outer FGMRES, as ILU(2) is not.
+#include "../../include/chebhip.h"
+#include "ops.h"
+#include "sweep.h"
+#include <cmath>
+#include <map>
+#include <new>
+#include <vector>
+
+using namespace chebhip;
+
+#define PHIPCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+constexpr int MAXD = 10;
+struct Geo { int d; int dims[MAXD]; long gs[MAXD]; };      // local extents, interior strides
+
+static inline unsigned pgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+#define GS_LOOP(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// One row of P per interior node, exactly the arithmetic of elliptic.C:556-579 (gradu[j] null: the deta * du0
+// terms are absent, stokes.C:1217-1222).  cf[0] diagonal, cf[1+2j] / cf[2+2j] the neighbours at -1 / +1 along
+// dimension j; a neighbour on the boundary has no column (MatSetValues drops negative indices): coefficient 0.
+struct GradPtrs { const double *p[MAXD]; };
+struct CoordPtrs { const double *p[MAXD]; };
+__global__ void k_fd_assemble(Geo geo, long N, long G, const int *__restrict__ ixL, const double *__restrict__ eta,
+                              const double *__restrict__ deta, GradPtrs gu, CoordPtrs xs, double *__restrict__ cf,
+                              double *__restrict__ eta_g) {
+  GS_LOOP(l, N) {
+    const int g = ixL[l];
+    if (g < 0) continue;
+    long rem = l, ls[MAXD]; int ind[MAXD];
+    { long s = 1; for (int j = geo.d - 1; j >= 0; j--) { ls[j] = s; s *= geo.dims[j]; } }
+    for (int j = 0; j < geo.d; j++) { ind[j] = (int)(rem / ls[j]); rem -= (long)ind[j] * ls[j]; }
+    double v0 = 0.0;
+    for (int j = 0; j < geo.d; j++) {
+      const long iM = l - ls[j], iP = l + ls[j];
+      const double x0 = xs.p[j][ind[j]], xMM = xs.p[j][ind[j] - 1], xPP = xs.p[j][ind[j] + 1];
+      const double xM = 0.5 * (xMM + x0), idxM = 1.0 / (x0 - xMM), xP = 0.5 * (x0 + xPP), idxP = 1.0 / (xPP - x0), idx = 1.0 / (xP - xM);
+      const double eM = 0.5 * (eta[iM] + eta[l]), eP = 0.5 * (eta[iP] + eta[l]);
+      double tM = 0.0, tP = 0.0;
+      if (gu.p[j]) {
+        const double deM = 0.5 * (deta[iM] + deta[l]), du0M = 0.5 * (gu.p[j][iM] + gu.p[j][l]);
+        const double deP = 0.5 * (deta[iP] + deta[l]), du0P = 0.5 * (gu.p[j][iP] + gu.p[j][l]);
+        tM = 0.5 * deM * du0M; tP = 0.5 * deP * du0P;
+      }
+      const double vM = -idx * (idxM * eM - tM), vP = -idx * (idxP * eP + tP);
+      v0 += idx * (idxP * eP + idxM * eM - (tP - tM));
+      cf[(long)(1 + 2 * j) * G + g] = ixL[iM] >= 0 ? vM : 0.0;
+      cf[(long)(2 + 2 * j) * G + g] = ixL[iP] >= 0 ? vP : 0.0;
+    }
+    cf[g] = v0;
+    eta_g[g] = eta[l];
+  }
+}
+
+// y = P x on nf stacked fields of G interior values each
+__global__ void k_fd_mult(Geo geo, long G, int nf, const double *__restrict__ cf, const double *__restrict__ x, double *__restrict__ y) {
+  GS_LOOP(t, G * nf) {
+    const long f = t / G, g = t - f * G;
+    const double *xf = x + f * G;
+    double s = cf[g] * xf[g];
+    for (int j = 0; j < geo.d; j++) {
+      const double cM = cf[(long)(1 + 2 * j) * G + g], cP = cf[(long)(2 + 2 * j) * G + g];
+      if (cM != 0.0) s += cM * xf[g - geo.gs[j]];
+      if (cP != 0.0) s += cP * xf[g + geo.gs[j]];
+    }
+    y[t] = s;
+  }
+}
+
+// modal scaling: t /= (l_0[i_0] + ... + l_{d-1}[i_{d-1}])
+struct LamPtrs { const double *p[MAXD]; };
+__global__ void k_modal_scale(Geo geo, long G, int nf, LamPtrs lam, double *__restrict__ t) {
+  GS_LOOP(q, G * nf) {
+    long g = q % G; double s = 0.0;
+    for (int j = 0; j < geo.d; j++) { const long i = g / geo.gs[j]; g -= i * geo.gs[j]; s += lam.p[j][i]; }
+    t[q] = t[q] / s;
+  }
+}
+
+// out = (a - (y ? y : 0)) / eta_g  on nf stacked fields
+__global__ void k_resid_over_eta(long G, int nf, const double *__restrict__ a, const double *__restrict__ y,
+                                 const double *__restrict__ eta_g, double *__restrict__ out) {
+  GS_LOOP(q, G * nf) { const double r = y ? a[q] - y[q] : a[q]; out[q] = r / eta_g[q % G]; }
+}
+
+// node-major interleaved (I nodes x d components, the reference's velocity vectors) <-> component-major
+__global__ void k_deinterleave(long G, int nf, const double *__restrict__ a, double *__restrict__ b) { GS_LOOP(q, G * nf) { const long f = q / G, g = q - f * G; b[q] = a[g * nf + f]; } }
+__global__ void k_interleave(long G, int nf, const double *__restrict__ b, double *__restrict__ a) { GS_LOOP(q, G * nf) { const long f = q / G, g = q - f * G; a[g * nf + f] = b[q]; } }
+
+struct LineMats { DiffMat Fcs, Fca, Bcs, Bca; double *lam = nullptr; bool ok = false; };
+
+}  // namespace
+
+struct chebhip_fdpc {
+  Geo geo;
+  long N = 0, G = 0;
+  int nf = 1;                                  // 1: scalar operator; d: Stokes velocity (component-major inside)
+  bool interleaved = false;                    // vectors at the ABI are node-major (Stokes)
+  std::map<int, LineMats> lines;               // per distinct extent
+  std::vector<unsigned> inner_g, ncols_g;
+  double *xs[MAXD] = {nullptr};
+  double *cf = nullptr, *eta_g = nullptr;
+  double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr, *t5 = nullptr;   // nf * G each
+  int sweeps = 1;
+  chebhip_fgmres *inner = nullptr; int inner_m = 0;   // the approximate solve with variable coefficients
+  bool assembled = false;
+  ell_op *eop = nullptr; stokes_op *sop = nullptr;
+};
+
+static void fdpc_free(chebhip_fdpc *pc) {
+  if (!pc) return;
+  if (pc->inner) chebhip_fgmres_destroy(pc->inner);
+  for (auto &kv : pc->lines) {
+    if (!kv.second.ok) continue;
+    diffmat_destroy(&kv.second.Fcs); diffmat_destroy(&kv.second.Fca); diffmat_destroy(&kv.second.Bcs); diffmat_destroy(&kv.second.Bca);
+    if (kv.second.lam) (void)hipFree(kv.second.lam);
+  }
+  for (int k = 0; k < MAXD; k++) if (pc->xs[k]) (void)hipFree(pc->xs[k]);
+  double *all[] = {pc->cf, pc->eta_g, pc->t0, pc->t1, pc->t2, pc->t3, pc->t4, pc->t5};
+  for (double *p : all) if (p) (void)hipFree(p);
+  delete pc;
+}
+
+static int fdpc_create(const FdView &v, int nf, bool interleaved, chebhip_fdpc **out) {
+  *out = nullptr;
+  if (v.d < 1 || v.d > MAXD) return chebhip_fail(CHEBHIP_ERR_DIMS, "d = %d out of range", v.d);
+  for (int k = 0; k < v.d; k++) {
+    if (v.dims[k] < 3) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d: the preconditioner needs interior nodes", k, v.dims[k]);
+    if (v.dims[k] > 258) return chebhip_fail(CHEBHIP_ERR_ARG, "dims[%d] = %d: fast diagonalisation supports at most 258 points per line", k, v.dims[k]);
+  }
+  chebhip_fdpc *pc = new (std::nothrow) chebhip_fdpc;
+  if (!pc) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  pc->geo.d = v.d; pc->N = v.N; pc->G = v.G; pc->nf = nf; pc->interleaved = interleaved;
+  for (int k = 0; k < v.d; k++) pc->geo.dims[k] = v.dims[k];
+  { long s = 1; for (int k = v.d - 1; k >= 0; k--) { pc->geo.gs[k] = s; s *= (v.dims[k] - 2); } }
+#define PCCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fdpc_free(pc); \
+    return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+  pc->inner_g.resize(v.d); pc->ncols_g.resize(v.d);
+  for (int k = 0; k < v.d; k++) {
+    const int P = v.dims[k], M = P - 2;
+    pc->inner_g[k] = (unsigned)pc->geo.gs[k];
+    pc->ncols_g[k] = (unsigned)(v.G / M);
+    std::vector<double> x(P);
+    for (int i = 0; i < P; i++) x[i] = cos(i * 3.14159265358979323846 / (P - 1));          // elliptic.C:279, stokes.C:296
+    PCCHK(hipMalloc((void **)&pc->xs[k], P * sizeof(double)));
+    PCCHK(hipMemcpy(pc->xs[k], x.data(), P * sizeof(double), hipMemcpyHostToDevice));
+    if (pc->lines.count(P)) continue;
+    LineMats lm;
+    std::vector<long double> S, Si, lam, part;
+    if (!fdm_line(P, S, Si, lam)) { fdpc_free(pc); return chebhip_fail(CHEBHIP_ERR_ARG, "eigen-decomposition of the %d-point line operator failed", P); }
+    centro_part(M, Si, 1, part); PCCHK(diffmat_from_dense(M, part.data(), 1, &lm.Fcs));
+    centro_part(M, Si, 0, part); PCCHK(diffmat_from_dense(M, part.data(), 0, &lm.Fca));
+    centro_part(M, S, 1, part);  PCCHK(diffmat_from_dense(M, part.data(), 1, &lm.Bcs));
+    centro_part(M, S, 0, part);  PCCHK(diffmat_from_dense(M, part.data(), 0, &lm.Bca));
+    std::vector<double> ld(M); for (int i = 0; i < M; i++) ld[i] = (double)lam[i];
+    PCCHK(hipMalloc((void **)&lm.lam, M * sizeof(double)));
+    PCCHK(hipMemcpy(lm.lam, ld.data(), M * sizeof(double), hipMemcpyHostToDevice));
+    lm.ok = true;
+    pc->lines[P] = lm;
+  }
+  const size_t gb = (size_t)(v.G > 0 ? v.G : 1) * sizeof(double);
+  PCCHK(hipMalloc((void **)&pc->cf, (2 * v.d + 1) * gb));
+  PCCHK(hipMalloc((void **)&pc->eta_g, gb));
+  PCCHK(hipMalloc((void **)&pc->t0, nf * gb)); PCCHK(hipMalloc((void **)&pc->t1, nf * gb));
+  PCCHK(hipMalloc((void **)&pc->t2, nf * gb)); PCCHK(hipMalloc((void **)&pc->t3, nf * gb));
+  PCCHK(hipMalloc((void **)&pc->t4, nf * gb)); PCCHK(hipMalloc((void **)&pc->t5, nf * gb));
+#undef PCCHK
+  *out = pc;
+  return 0;
+}
+
+static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
+  FdView v;
+  int rc = pc->eop ? ell_op_fd_view(pc->eop, &v) : stokes_op_fd_view(pc->sop, &v);
+  if (rc) return rc;
+  if (pc->G == 0) { pc->assembled = true; return 0; }
+  GradPtrs gu; CoordPtrs xs;
+  for (int k = 0; k < MAXD; k++) { gu.p[k] = k < v.d ? v.gradu[k] : nullptr; xs.p[k] = pc->xs[k]; }
+  hipLaunchKernelGGL(k_fd_assemble, dim3(pgrid(pc->N)), dim3(256), 0, st, pc->geo, pc->N, pc->G, v.ixL, v.eta, v.deta, gu, xs, pc->cf, pc->eta_g);
+  PHIPCHK(hipGetLastError());
+  pc->assembled = true;
+  return 0;
+}
+
+// y = (Xcs + Xca) x along dimension k of nf stacked interior fields (x != y)
+static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st) {
+  LineMats &lm = pc->lines[pc->geo.dims[k]];
+  SweepParams sp = {};
+  sp.ncols = pc->ncols_g[k] * (unsigned)pc->nf; sp.inner = pc->inner_g[k];
+  sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.alpha = 1.0;
+  sp.out_mode = OUT_STORE;
+  PHIPCHK(sweep_launch(backward ? lm.Bcs : lm.Fcs, sp, st));
+  sp.out_mode = OUT_ACC; sp.acc = y;
+  PHIPCHK(sweep_launch(backward ? lm.Bca : lm.Fca, sp, st));
+  return 0;
+}
+
+// z = P_1^-1 r (the constant-coefficient part, exactly); r is not modified; t0 / t1 are scratch (r, z must be neither)
+static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t st) {
+  const int d = pc->geo.d;
+  const double *src = r;
+  double *a = pc->t0, *b = pc->t1;
+  for (int k = 0; k < d; k++) { int rc = line_transform(pc, k, false, src, a, st); if (rc) return rc; src = a; std::swap(a, b); }
+  LamPtrs lam; for (int k = 0; k < MAXD; k++) lam.p[k] = k < d ? pc->lines[pc->geo.dims[k]].lam : nullptr;
+  hipLaunchKernelGGL(k_modal_scale, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, lam, (double *)src);
+  for (int k = d - 1; k >= 0; k--) {
+    double *dst = (k == 0) ? z : a;
+    int rc = line_transform(pc, k, true, src, dst, st); if (rc) return rc;
+    src = dst; std::swap(a, b);
+  }
+  PHIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int fdpc_mult(chebhip_fdpc *pc, const double *x, double *y, hipStream_t st) {
+  if (!pc->assembled) { int rc = fdpc_update(pc, st); if (rc) return rc; }
+  if (pc->G == 0) return 0;
+  const long n = pc->G * pc->nf;
+  const double *xin = x; double *yout = y;
+  if (pc->interleaved) { hipLaunchKernelGGL(k_deinterleave, dim3(pgrid(n)), dim3(256), 0, st, pc->G, pc->nf, x, pc->t2); xin = pc->t2; yout = pc->t3; }
+  hipLaunchKernelGGL(k_fd_mult, dim3(pgrid(n)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, (const double *)pc->cf, xin, yout);
+  if (pc->interleaved) hipLaunchKernelGGL(k_interleave, dim3(pgrid(n)), dim3(256), 0, st, pc->G, pc->nf, (const double *)pc->t3, y);
+  PHIPCHK(hipGetLastError());
+  return 0;
+}
+
+// component-major callbacks of the inner solve: y = P x and z = P_1^-1 (r / eta)
+static int cb_fd_mult(void *ctx, const double *x, double *y, void *stream) {
+  chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
+  hipLaunchKernelGGL(k_fd_mult, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, (hipStream_t)stream, pc->geo, pc->G, pc->nf, (const double *)pc->cf, x, y);
+  PHIPCHK(hipGetLastError());
+  return 0;
+}
+static int cb_fdm(void *ctx, const double *r, double *z, void *stream) {
+  chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
+  hipLaunchKernelGGL(k_resid_over_eta, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, (hipStream_t)stream, pc->G, pc->nf, r, (const double *)nullptr,
+                     (const double *)pc->eta_g, pc->t3);
+  return fdm_solve(pc, pc->t3, z, (hipStream_t)stream);
+}
+
+static int fdpc_apply(chebhip_fdpc *pc, const double *r, double *z, hipStream_t st) {
+  if (!pc->assembled) { int rc = fdpc_update(pc, st); if (rc) return rc; }
+  if (pc->G == 0) return 0;
+  const long n = pc->G * pc->nf;
+  const unsigned grid = pgrid(n);
+  // component-major copies of r and of the iterate where the ABI vectors are node-major (Stokes velocity)
+  const double *rin = r; double *zc = z;
+  if (pc->interleaved) { hipLaunchKernelGGL(k_deinterleave, dim3(grid), dim3(256), 0, st, pc->G, pc->nf, r, pc->t2); rin = pc->t2; zc = pc->t4; }
+  if (pc->sweeps == 0) {                       // z = P_1^-1 (r / eta)
+    int rc = cb_fdm(pc, rin, zc, st); if (rc) return rc;
+  } else {
+    // `sweeps` iterations of GMRES on P z = r, right-preconditioned by P_1^-1 (1/eta): monotone in the residual for
+    // any coefficient state (a stationary defect correction diverges once eta varies by more than a factor ~2)
+    if (!pc->inner || pc->inner_m != pc->sweeps) {
+      if (pc->inner) chebhip_fgmres_destroy(pc->inner);
+      pc->inner = nullptr;
+      int rc = chebhip_fgmres_create(n, pc->sweeps, &pc->inner); if (rc) return rc;
+      pc->inner_m = pc->sweeps;
+    }
+    int rc = chebhip_fgmres_set_tolerances(pc->inner, 1e-12, 1e-300, pc->sweeps); if (rc) return rc;
+    if ((rc = chebhip_fgmres_solve(pc->inner, cb_fd_mult, pc, cb_fdm, pc, rin, zc, 0, st))) return rc;
+  }
+  if (pc->interleaved) hipLaunchKernelGGL(k_interleave, dim3(grid), dim3(256), 0, st, pc->G, pc->nf, (const double *)zc, z);
+  PHIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- C ABI: scalar elliptic operator -------------------------------------------------------------
+extern "C" int ell_pc_create(ell_op *op, chebhip_fdpc **out) {
+  if (!op || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  FdView v; int rc = ell_op_fd_view(op, &v); if (rc) return rc;
+  rc = fdpc_create(v, 1, false, out); if (rc) return rc;
+  (*out)->eop = op;
+  return 0;
+}
+
+// ---- C ABI: Stokes velocity block (MatVVPC) ------------------------------------------------------
+extern "C" int stokes_pc_create(stokes_op *op, chebhip_fdpc **out) {
+  if (!op || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  FdView v; int rc = stokes_op_fd_view(op, &v); if (rc) return rc;
+  rc = fdpc_create(v, v.d, true, out); if (rc) return rc;
+  (*out)->sop = op;
+  return 0;
+}
+
+extern "C" int chebhip_fdpc_destroy(chebhip_fdpc *pc) { fdpc_free(pc); return 0; }
+extern "C" int chebhip_fdpc_update(chebhip_fdpc *pc, void *stream) { if (!pc) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle"); return fdpc_update(pc, (hipStream_t)stream); }
+extern "C" int chebhip_fdpc_set_sweeps(chebhip_fdpc *pc, int sweeps) {
+  if (!pc || sweeps < 0 || sweeps > 64) return chebhip_fail(CHEBHIP_ERR_ARG, "sweeps must be in 0..64");
+  pc->sweeps = sweeps; return 0;
+}
+extern "C" int chebhip_fdpc_mult(chebhip_fdpc *pc, const double *x, double *y, void *stream) {
+  if (!pc || ((!x || !y) && pc->G)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (x && x == y) return chebhip_fail(CHEBHIP_ERR_ARG, "x and y must be distinct");
+  return fdpc_mult(pc, x, y, (hipStream_t)stream);
+}
+extern "C" int chebhip_fdpc_apply(void *ctx, const double *r, double *z, void *stream) {
+  chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
+  if (!pc || ((!r || !z) && pc->G)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (r && r == z) return chebhip_fail(CHEBHIP_ERR_ARG, "r and z must be distinct");
+  return fdpc_apply(pc, r, z, (hipStream_t)stream);
+}

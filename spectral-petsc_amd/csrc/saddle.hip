@@ -1,0 +1,222 @@
+// saddle.hip -- the block preconditioners of the Stokes saddle-point system on the device:
+// StokesPCApply0..3 (stokes.C:1714-1817) composed from the operator's own blocks (stokes_op_mult_vv / _pv / _vp /
+// _schur), the finite-difference velocity matrix MatVVPC (precond.hip) and three inner Krylov solves with the
+// roles the reference gives its KSPs (StokesCreate, stokes.C:328-341):
+//   KSPVelocity       operators (MatVV, MatVVPC), prefix vel_    -> flexible GMRES on MatVV, M = MatVVPC solve
+//   KSPSchur          operator MatSchur, no preconditioner, constant null space removed from every Krylov vector
+//                     (stokes.C:1020-1021), prefix schur_
+//   KSPSchurVelocity  operators (MatVV, MatVVPC), prefix svel_   -> inside StokesMatMultSchur (stokes.C:531)
+// Defaults follow the options the reference's README recommends (README:43): -vel_ksp_max_it 4,
+// -schur_ksp_max_it 3, -svel_ksp_type preonly (one application of the MatVVPC solve).
+// Everything here goes through the public C ABI of the operator: vectors never leave HBM.
+#include "../../include/chebhip.h"
+#include <hip/hip_runtime.h>
+#include <new>
+
+int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+
+#define SHIPCHK2(expr)                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+static inline unsigned sgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+#define GS_LOOP(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// full global vector (I nodes x [v_0 .. v_{d-1}, p]) <-> velocity (I x d) and pressure (I) parts: scatterGV / GP / VG / PG
+__global__ void k_split(long I, int d, const double *__restrict__ x, double *__restrict__ v, double *__restrict__ p) {
+  GS_LOOP(q, I * (d + 1)) { const long n = q / (d + 1); const int c = (int)(q - n * (d + 1)); if (c < d) { if (v) v[n * d + c] = x[q]; } else if (p) p[n] = x[q]; }
+}
+// y_v = (addv ? y_v : 0) + v,  y_p = p   (either part may be null: left untouched)
+__global__ void k_merge(long I, int d, const double *__restrict__ v, int addv, const double *__restrict__ p, double *__restrict__ y) {
+  GS_LOOP(q, I * (d + 1)) {
+    const long n = q / (d + 1); const int c = (int)(q - n * (d + 1));
+    if (c < d) { if (v) y[q] = addv ? y[q] + v[n * d + c] : v[n * d + c]; }
+    else if (p) y[q] = p[n];
+  }
+}
+// a = s * a + (b ? b : 0)
+__global__ void k_scale_add(long n, double s, double *__restrict__ a, const double *__restrict__ b) { GS_LOOP(q, n) a[q] = s * a[q] + (b ? b[q] : 0.0); }
+// out = in - mean(in): MatNullSpaceRemove with the constant vector; one block, fixed summation order
+__global__ __launch_bounds__(1024) void k_remove_mean(long n, const double *__restrict__ in, double *__restrict__ out) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (long q = threadIdx.x; q < n; q += 1024) s += in[q];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  const double mean = sh[0] / (double)n;
+  for (long q = threadIdx.x; q < n; q += 1024) out[q] = in[q] - mean;
+}
+}  // namespace
+
+struct stokes_saddle {
+  stokes_op *op = nullptr;
+  chebhip_fdpc *vvpc = nullptr;
+  int d = 0; long I = 0, gv = 0, gp = 0, g = 0;
+  int type = 0;                                    // -pc_saddle_type (stokes.C:177-187)
+  double *v0 = nullptr, *v1 = nullptr, *p0 = nullptr, *p1 = nullptr;      // vG0, vG1, pG0, pG1 (stokes.C:56-57)
+  chebhip_fgmres *kvel = nullptr, *kschur = nullptr, *ksvel = nullptr;
+  // restart / max_it / rtol per inner solve; max_it 0 = "preonly": one application of the preconditioner
+  int m_vel = 4, m_schur = 3, m_svel = 0;
+  double rtol_vel = 1e-5, rtol_schur = 1e-5, rtol_svel = 1e-5;
+  int its_vel = 0, its_schur = 0;                  // operator applies of the last apply, for monitoring
+};
+
+static int vv_apply(void *ctx, const double *x, double *y, void *stream) { return stokes_op_mult_vv(((stokes_saddle *)ctx)->op, x, y, stream); }
+// KSPSolve(KSPSchurVelocity) (stokes.C:531): preonly -> one MatVVPC solve; otherwise GMRES on MatVV with it
+static int svel_solve(void *ctx, const double *rhs, double *sol, void *stream) {
+  stokes_saddle *s = (stokes_saddle *)ctx;
+  if (s->m_svel == 0) return chebhip_fdpc_apply(s->vvpc, rhs, sol, stream);
+  int rc = chebhip_fgmres_set_tolerances(s->ksvel, s->rtol_svel, 1e-50, s->m_svel); if (rc) return rc;
+  return chebhip_fgmres_solve(s->ksvel, vv_apply, s, chebhip_fdpc_apply, s->vvpc, rhs, sol, 0, stream);
+}
+// MatSchur followed by the removal of the constant: KSPSchur carries the constant null space (stokes.C:1020-1021) and
+// PETSc's (left-preconditioned) GMRES removes it from every vector it builds, i.e. it solves  P S x = P b  on
+// zero-mean vectors, P = I - 1 1^T / n.  (S P z = b would be inconsistent: S is singular and not symmetric.)
+static int schur_apply(void *ctx, const double *x, double *y, void *stream) {
+  stokes_saddle *s = (stokes_saddle *)ctx;
+  int rc = stokes_op_mult_schur(s->op, x, y, svel_solve, s, stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, s->gp, (const double *)y, y);
+  SHIPCHK2(hipGetLastError());
+  return 0;
+}
+// KSPSolve(KSPVelocity, b, x)
+static int vel_solve(stokes_saddle *s, const double *b, double *x, void *stream) {
+  if (s->m_vel == 0) return chebhip_fdpc_apply(s->vvpc, b, x, stream);
+  int rc = chebhip_fgmres_set_tolerances(s->kvel, s->rtol_vel, 1e-50, s->m_vel); if (rc) return rc;
+  rc = chebhip_fgmres_solve(s->kvel, vv_apply, s, chebhip_fdpc_apply, s->vvpc, b, x, 0, stream);
+  s->its_vel += chebhip_fgmres_iterations(s->kvel);
+  return rc;
+}
+// KSPSolve(KSPSchur, b, x); b is overwritten by its zero-mean part
+static int schur_solve(stokes_saddle *s, double *b, double *x, void *stream) {
+  hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, s->gp, (const double *)b, b);
+  int rc = chebhip_fgmres_set_tolerances(s->kschur, s->rtol_schur, 1e-50, s->m_schur > 0 ? s->m_schur : 1); if (rc) return rc;
+  rc = chebhip_fgmres_solve(s->kschur, schur_apply, s, nullptr, nullptr, b, x, 0, stream);
+  s->its_schur += chebhip_fgmres_iterations(s->kschur);
+  return rc;
+}
+
+extern "C" int stokes_saddle_destroy(stokes_saddle *s) {
+  if (!s) return 0;
+  if (s->kvel) chebhip_fgmres_destroy(s->kvel);
+  if (s->kschur) chebhip_fgmres_destroy(s->kschur);
+  if (s->ksvel) chebhip_fgmres_destroy(s->ksvel);
+  if (s->vvpc) chebhip_fdpc_destroy(s->vvpc);
+  double *all[] = {s->v0, s->v1, s->p0, s->p1};
+  for (double *p : all) if (p) (void)hipFree(p);
+  delete s;
+  return 0;
+}
+
+extern "C" int stokes_saddle_create(stokes_op *op, stokes_saddle **out) {
+  if (!op || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  stokes_saddle *s = new (std::nothrow) stokes_saddle;
+  if (!s) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  s->op = op;
+  s->I = stokes_op_size(op, 1); s->gv = stokes_op_size(op, 2); s->gp = stokes_op_size(op, 3); s->g = stokes_op_size(op, 4);
+  s->d = s->I > 0 ? (int)(s->gv / s->I) : 2;
+  int rc = stokes_pc_create(op, &s->vvpc);
+  if (!rc) rc = chebhip_fdpc_set_sweeps(s->vvpc, 0);
+  if (!rc) rc = chebhip_fgmres_create(s->gv, 30, &s->kvel);
+  if (!rc) rc = chebhip_fgmres_create(s->gp, 30, &s->kschur);
+  if (!rc) rc = chebhip_fgmres_create(s->gv, 30, &s->ksvel);
+  if (rc) { stokes_saddle_destroy(s); return rc; }
+  const size_t nv = (size_t)(s->gv > 0 ? s->gv : 1) * sizeof(double), np = (size_t)(s->gp > 0 ? s->gp : 1) * sizeof(double);
+  if (hipMalloc((void **)&s->v0, nv) != hipSuccess || hipMalloc((void **)&s->v1, nv) != hipSuccess ||
+      hipMalloc((void **)&s->p0, np) != hipSuccess || hipMalloc((void **)&s->p1, np) != hipSuccess) {
+    stokes_saddle_destroy(s); return chebhip_fail(CHEBHIP_ERR_MEMORY, "device allocation failed");
+  }
+  *out = s;
+  return 0;
+}
+
+extern "C" int stokes_saddle_set_type(stokes_saddle *s, int type) {
+  if (!s || type < 0 || type > 3) return chebhip_fail(CHEBHIP_ERR_ARG, "pc_saddle_type %d not implemented (stokes.C:186)", type);
+  s->type = type; return 0;
+}
+// which: 0 KSPVelocity (vel_), 1 KSPSchur (schur_), 2 KSPSchurVelocity (svel_).  max_it = 0 for the two velocity
+// solves means -ksp_type preonly: one application of the MatVVPC solve
+extern "C" int stokes_saddle_set_inner(stokes_saddle *s, int which, int max_it, double rtol) {
+  if (!s || which < 0 || which > 2 || max_it < 0 || max_it > 30 || !(rtol >= 0.0)) return chebhip_fail(CHEBHIP_ERR_ARG, "bad inner-solver setting");
+  if (which == 0) { s->m_vel = max_it; s->rtol_vel = rtol; }
+  else if (which == 1) { s->m_schur = max_it; s->rtol_schur = rtol; }
+  else { s->m_svel = max_it; s->rtol_svel = rtol; }
+  return 0;
+}
+// StokesPCSetUp0 (stokes.C:1160-1241): MatVVPC from the current eta -- call after stokes_op_function / set_state
+extern "C" int stokes_saddle_setup(stokes_saddle *s, void *stream) {
+  if (!s) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  return chebhip_fdpc_update(s->vvpc, stream);
+}
+// inner GMRES steps on MatVVPC per application of its approximate solve (chebhip_fdpc_set_sweeps; default 0: the fast
+// diagonalisation alone, exact for constant viscosity -- raise it when the viscosity varies strongly)
+extern "C" int stokes_saddle_set_pc_sweeps(stokes_saddle *s, int sweeps) {
+  if (!s) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  return chebhip_fdpc_set_sweeps(s->vvpc, sweeps);
+}
+extern "C" int stokes_saddle_iterations(const stokes_saddle *s, int which) { return !s ? -1 : (which == 0 ? s->its_vel : s->its_schur); }
+
+// StokesPCApply0..3 (stokes.C:1714-1817): y = M^-1 x on full global vectors; shape of chebhip_apply_fn
+extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *stream) {
+  stokes_saddle *s = (stokes_saddle *)ctx;
+  if (!s || ((!x || !y) && s->g)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (s->g == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const long I = s->I; const int d = s->d;
+  const unsigned gg = sgrid(s->g), gpn = sgrid(s->gp), gvn = sgrid(s->gv);
+  s->its_vel = s->its_schur = 0;
+  int rc;
+#define SPLIT(V, P) hipLaunchKernelGGL(k_split, dim3(gg), dim3(256), 0, st, I, d, x, V, P)
+#define MERGE(V, ADD, P) hipLaunchKernelGGL(k_merge, dim3(gg), dim3(256), 0, st, I, d, (const double *)(V), ADD, (const double *)(P), y)
+  switch (s->type) {
+    case 0:   // block LU (stokes.C:1714-1740)
+      SPLIT(s->v0, (double *)nullptr);                                             // scatterGV: v0 <- x_v
+      if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0          (:1723)
+      MERGE(s->v1, 0, nullptr);                                                    // y_v <- v1              (:1725)
+      if ((rc = stokes_op_mult_pv(s->op, s->v1, s->p0, stream))) return rc;        // p0 <- B v1             (:1726)
+      SPLIT((double *)nullptr, s->p1);                                             // x_p
+      hipLaunchKernelGGL(k_scale_add, dim3(gpn), dim3(256), 0, st, s->gp, -1.0, s->p0, (const double *)s->p1);   // p0 <- -p0 + x_p (:1727-1729)
+      if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0          (:1732)
+      if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1           (:1734)
+      hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)nullptr);   // v0 <- -v0 (:1735)
+      if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0          (:1736)
+      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);      // KSPSetNullSpace (:1019)
+      MERGE(s->v1, 1, s->p1);                                                      // y_v += v1, y_p <- p1   (:1733,1737)
+      break;
+    case 1:   // block upper triangular (stokes.C:1747-1765)
+      SPLIT(s->v1, s->p0);
+      if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0
+      if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1
+      hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)s->v1);   // v0 <- -v0 + x_v
+      if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
+      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);
+      MERGE(s->v1, 0, s->p1);
+      break;
+    case 2:   // block diagonal (stokes.C:1772-1790)
+      SPLIT(s->v0, s->p0);
+      if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
+      if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;
+      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);
+      MERGE(s->v1, 0, s->p1);
+      break;
+    default:  // block lower triangular (stokes.C:1797-1816)
+      SPLIT(s->v0, s->p1);
+      if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0
+      if ((rc = stokes_op_mult_pv(s->op, s->v1, s->p0, stream))) return rc;        // p0 <- B v1
+      hipLaunchKernelGGL(k_scale_add, dim3(gpn), dim3(256), 0, st, s->gp, -1.0, s->p0, (const double *)s->p1);   // p0 <- -p0 + x_p
+      MERGE(s->v1, 0, nullptr);                                                    // y_v <- v1 (before v1 is reused by the Schur solve)
+      if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0
+      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);
+      MERGE((const double *)nullptr, 0, s->p1);
+      break;
+  }
+#undef SPLIT
+#undef MERGE
+  SHIPCHK2(hipGetLastError());
+  return 0;
+}

@@ -6,6 +6,7 @@
 // node-local kernels below.
 #include "../../include/chebhip.h"
 #include "sweep.h"
+#include "ops.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,7 +18,6 @@
 
 using namespace chebhip;
 
-int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
 #define SHIPCHK(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (expr);                                                                             \
@@ -355,6 +355,14 @@ extern "C" int stokes_op_create_slab(int d, const int *dims, int lo, int hi, sto
   return st_create(d, dims, lo, hi, dim0, dim0_ctx, out);
 }
 
+
+int stokes_op_fd_view(stokes_op *op, chebhip::FdView *v) {
+  if (!op || !v) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "the finite-difference preconditioner is not available in slab mode");
+  v->d = op->d; v->dims = op->dims.data(); v->N = op->N; v->G = op->I; v->ixL = op->ixL;
+  v->eta = op->eta; v->deta = op->deta;                   // StokesPCSetUp0 reads eta only (stokes.C:1217-1222)
+  return 0;
+}
 
 extern "C" long stokes_op_size(const stokes_op *op, int which) {
   if (!op) return -1;

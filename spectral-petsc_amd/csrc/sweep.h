@@ -1,6 +1,7 @@
 // sweep.h -- internal interface between the C-ABI layer and the gfx950 sweep kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 
 namespace chebhip {
 
@@ -83,6 +84,8 @@ hipError_t diffmat_create(int P, DiffMat *out);
 // returned DiffMat describes lines of P-2 stored points.
 hipError_t diffmat_create_lap(int P, DiffMat *out);
 void diffmat_destroy(DiffMat *m);
+// Fragments of an arbitrary centro-symmetric (sym = 1) / centro-antisymmetric (sym = 0) dense M x M matrix, M <= 256.
+hipError_t diffmat_from_dense(int M, const long double *A, int sym, DiffMat *out);
 // Host-side dense differentiation matrix (row-major P x P), for tests and the adapter.
 void diffmat_dense_host(int P, double *D);
 
@@ -105,5 +108,9 @@ int sweep_num_cus(hipError_t *err);
 void sweep_set_ablate(int bits);
 void sweep_set_variant(int bits);
 int sweep_get_variant();
+
+// Fast diagonalisation of the 1-D three-point operator of the finite-difference preconditioners (diffmat.cpp)
+bool fdm_line(int P, std::vector<long double> &S, std::vector<long double> &Sinv, std::vector<long double> &lam);
+void centro_part(int M, const std::vector<long double> &A, int part, std::vector<long double> &out);
 
 }  // namespace chebhip

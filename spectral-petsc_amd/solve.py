@@ -48,3 +48,62 @@ def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_at
     finally:
         ks.destroy()
     return it, total, fn
+
+
+def continuation_schedule(exponent, regularization, cont0=0, cont=1):
+    """The (exponent, regularization) pairs of the Newton continuation loop, stokes.C:217-221:
+    exponent_i = 1 + (i/cont)^0.8 (exponent - 1), regularization_i = exp(log(regularization) i/cont)."""
+    import math
+    out = []
+    for i in range(cont0, cont + 1):
+        out.append((1.0 + math.pow(1.0 * i / cont, 0.8) * (exponent - 1.0), math.exp(math.log(regularization) * i / cont)))
+    return out
+
+
+def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, saddle_type=0,
+                 snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50, ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000,
+                 vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, line_search=True, monitor=None, max_linear_fail=1):
+    """The solve phase of stokes.C:213-235 on device vectors: for every continuation stage, SNESSolve = Newton with a
+    backtracking line search around StokesFunction (stokes.C:680-758), each step KSPSolve(KSPFGMRES) on the
+    Newton-linearised StokesMatMult (stokes.C:499-519) right-preconditioned by StokesPCApply<saddle_type>
+    (stokes.C:1714-1817; MatVVPC re-assembled per step as StokesPCSetUp0 does).  Dirichlet values and force must be
+    set on `op`; x (device tensor, global_size) holds the initial guess and the result.
+    `max_linear_fail`: linear solves that may end on their iteration limit before the Newton iteration gives up
+    (-snes_max_linear_solve_fail, PETSc's default 1); the step of such a solve is still tried by the line search.
+    Returns a list of (exponent, regularization, newton_its, ksp_its, |F|) per stage."""
+    kind, hardness, exponent, regularization, gamma0 = rheology
+    n = op.global_size
+    F = torch.empty_like(x); dx = torch.empty_like(x)
+    ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
+    pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps)
+    stages = continuation_schedule(exponent, regularization, cont0, cont) if kind == 1 else [(exponent, regularization)]
+    out = []
+    fails = 0
+    try:
+        for (e_i, r_i) in stages:
+            op.set_rheology(kind, hardness, e_i, r_i, gamma0)                  # stokes.C:219-220
+            op.function(x, F)
+            f0 = fn = float(F.norm()); it = 0; total = 0
+            while it < snes_max_it and fn > max(snes_rtol * f0, snes_atol):
+                pc.setup()                                                      # StokesPCSetUp0 after the new viscosity
+                F.neg_()
+                ks.solve(op, F, dx, M=pc)
+                total += ks.iterations
+                if ks.reason < 0:
+                    fails += 1
+                    if fails >= max_linear_fail or ks.reason != -3:
+                        raise RuntimeError("stage (%g, %g) Newton step %d: linear solve diverged (reason %d, %d its, residual %.3e)"
+                                           % (e_i, r_i, it + 1, ks.reason, ks.iterations, ks.residual))
+                lam, fold = 1.0, fn
+                x.add_(dx)
+                op.function(x, F); fn = float(F.norm())
+                while line_search and not (fn <= (1.0 - 1e-4 * lam) * fold) and lam > 1e-6:
+                    x.add_(dx, alpha=-0.5 * lam); lam *= 0.5
+                    op.function(x, F); fn = float(F.norm())
+                it += 1
+                if monitor:
+                    monitor(e_i, r_i, it, fn, ks.iterations, lam)
+            out.append((e_i, r_i, it, total, fn))
+    finally:
+        ks.destroy(); pc.destroy()
+    return out

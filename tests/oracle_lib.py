@@ -130,6 +130,28 @@ def elliptic_function(dims, U, b=None, dirichlet=None, gamma=0.0, exponent=2.0, 
     return rhs, eta, deta, gradu.reshape(d, N)
 
 
+def fd_matrix(dims, eta=None, deta=None, gradu=None):
+    """FormJacobian's matrix P (elliptic.C:537-590) as a scipy CSR matrix on the global (interior) vector; gradu None
+    and deta ignored: one velocity component of MatVVPC (stokes.C:1181-1226)."""
+    import scipy.sparse as sps
+    d = len(dims)
+    N, G, _ = sizes(dims)
+    eta = np.ones(N) if eta is None else np.ascontiguousarray(eta, dtype=np.float64).ravel()
+    deta = np.zeros(N) if deta is None else np.ascontiguousarray(deta, dtype=np.float64).ravel()
+    gu = None if gradu is None else np.ascontiguousarray(gradu, dtype=np.float64).ravel()
+    W = 2 * d + 1
+    cols = np.empty(G * W, dtype=np.int32); vals = np.empty(G * W)
+    L = lib()
+    L.orc_fd_matrix.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    err = L.orc_fd_matrix(d, _ip(dims), _dp(eta), _dp(deta), _dp(gu), cols.ctypes.data_as(C.POINTER(C.c_int)), _dp(vals))
+    if err:
+        raise ValueError("orc_fd_matrix error %d" % err)
+    rows = np.repeat(np.arange(G), W)
+    keep = cols >= 0                                            # MatSetValues ignores negative indices
+    return sps.csr_matrix((vals[keep], (rows[keep], cols[keep])), shape=(G, G))
+
+
 def elliptic_exact(dims, exact, gamma=0.0, exponent=2.0, cos_scale=1.0):
     """CreateExactSolution (elliptic.C:594-677): u, u2 (global), dirichlet (compact)."""
     d = len(dims)

@@ -1,0 +1,105 @@
+"""The finite-difference preconditioner on the device: FormJacobian's matrix P (elliptic.C:537-590),
+MatVVPC of StokesPCSetUp0 (stokes.C:1160-1241) and the approximate solves with them, against the oracle's
+assembled matrices (oracle_lib.fd_matrix restates the reference loops) and scipy's sparse direct solver."""
+import numpy as np
+import pytest
+import torch
+import scipy.sparse as sps
+import scipy.sparse.linalg as spl
+
+import __graft_entry__ as ge
+import oracle_lib as orc
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+sp = ge.load()
+SEED = 20240229
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def out(n):
+    return torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+
+
+@pytest.mark.parametrize("dims", [(9,), (12, 10), (8, 7, 6), (33, 20), (66, 12, 5), (5, 4, 4, 3)], ids=lambda d: "x".join(map(str, d)))
+def test_fd_matrix_and_exact_solve_linear_state(dims):
+    """eta == 1: P is the separable operator; fd_mult = oracle matrix, apply = its exact inverse."""
+    op = sp.EllipticOp(dims)
+    pc = sp.FdPc(op, sweeps=0)
+    rng = np.random.default_rng(SEED)
+    x = rng.standard_normal(op.global_size)
+    P = orc.fd_matrix(dims)
+    y = pc.mult(dev(x), out(op.global_size)).cpu().numpy()
+    assert relerr(y, P @ x) < 1e-13
+    z = pc.apply(dev(x), out(op.global_size)).cpu().numpy()
+    assert relerr(z, spl.spsolve(P.tocsc(), x)) < 1e-9
+    pc.destroy(); op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(14, 12), (10, 9, 8)], ids=lambda d: "x".join(map(str, d)))
+def test_fd_matrix_nonlinear_state(dims):
+    """After FormFunction with gamma != 0 the stencil carries eta, deta and grad u (elliptic.C:571-575)."""
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED)
+    u, u2, dv = orc.elliptic_exact(dims, 0, gamma=2.0, exponent=2.0, cos_scale=2.0)
+    op.set_dirichlet(dv)
+    U = (u + 1.5) * (1.0 + 0.05 * rng.standard_normal(op.global_size))
+    op.function_host(U, None, 2.0, 2.0)
+    pc = sp.FdPc(op, sweeps=3)
+    _, eta, deta, gradu = orc.elliptic_function(dims, U, None, dv, 2.0, 2.0, mode=orc.DIRECT)
+    P = orc.fd_matrix(dims, eta, deta, gradu)
+    x = rng.standard_normal(op.global_size)
+    assert relerr(pc.mult(dev(x), out(op.global_size)).cpu().numpy(), P @ x) < 1e-12
+    # the inner GMRES on P is monotone in the residual and converges to P^-1 r
+    res = []
+    for s in (0, 3, 12, 40):
+        sp.lib().chebhip_fdpc_set_sweeps(pc._h, s)
+        z = pc.apply(dev(x), out(op.global_size)).cpu().numpy()
+        res.append(np.linalg.norm(x - P @ z) / np.linalg.norm(x))
+    assert res[1] < res[0] and res[2] < res[1] and res[3] < 1e-6, res
+    assert relerr(z, spl.spsolve(P.tocsc(), x)) < 1e-5
+    pc.destroy(); op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(48, 48), (24, 22, 20), (64, 64, 64)], ids=lambda d: "x".join(map(str, d)))
+def test_preconditioned_fgmres_converges_fast(dims):
+    """KSPFGMRES + the finite-difference preconditioner (elliptic.C:181-185): a handful of iterations where the
+    unpreconditioned solve needs hundreds -- the condition number of P^-1 A is bounded independently of the order."""
+    op = sp.EllipticOp(dims)
+    pc = sp.FdPc(op, sweeps=0)
+    rng = np.random.default_rng(SEED)
+    xs = rng.standard_normal(op.global_size)
+    b = op.mult(dev(xs), out(op.global_size))
+    x = torch.zeros_like(b)
+    ks = sp.Fgmres(op.global_size, restart=30, rtol=1e-10, max_it=200)
+    ks.solve(op, b, x, M=pc)
+    torch.cuda.synchronize()
+    assert ks.reason > 0 and ks.iterations <= 40, (ks.reason, ks.iterations)
+    assert relerr(x.cpu().numpy(), xs) < 1e-7
+    ks.destroy(); pc.destroy(); op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(10, 9), (7, 6, 5), (20, 18, 16)], ids=lambda d: "x".join(map(str, d)))
+def test_stokes_velocity_pc(dims):
+    """MatVVPC (stokes.C:1181-1226): per component the eta-only stencil, on node-major velocity vectors."""
+    d = len(dims)
+    st = sp.StokesOp(dims)
+    pc = sp.FdPc(st, sweeps=0)
+    rng = np.random.default_rng(SEED)
+    v = rng.standard_normal(st.velocity_size)
+    P1 = orc.fd_matrix(dims)                                  # linear rheology: eta == 1
+    P = sps.kron(P1, sps.identity(d)).tocsr()                 # row = node * d + component (stokes.C:1211)
+    assert relerr(pc.mult(dev(v), out(st.velocity_size)).cpu().numpy(), P @ v) < 1e-13
+    assert relerr(pc.apply(dev(v), out(st.velocity_size)).cpu().numpy(), spl.spsolve(P.tocsc(), v)) < 1e-9
+    # as the preconditioner of KSPVelocity (operators MatVV, MatVVPC; stokes.C:328-333)
+    b = st.mult_vv(dev(v), out(st.velocity_size))
+    x = torch.zeros_like(b)
+    ks = sp.Fgmres(st.velocity_size, restart=30, rtol=1e-10, max_it=300)
+    ks.solve(st, b, x, M=pc, a_entry="mult_vv")
+    torch.cuda.synchronize()
+    assert ks.reason > 0 and ks.iterations <= 80, (ks.reason, ks.iterations)
+    assert relerr(x.cpu().numpy(), v) < 1e-6
+    ks.destroy(); pc.destroy(); st.destroy()
