@@ -280,6 +280,27 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
 /* Number of sweep-kernel launches issued by this process so far. */
 long chebhip_launch_count(void);
 
+/* Per-stage device timers: when enabled, every entry point listed below brackets its work with a hipEvent pair on
+ * the caller's stream (inclusive times: stokes_saddle_apply contains the stokes_op_mult_vv calls of its inner
+ * solves).  Reading drains the pending events (synchronises with them).  Off by default: no events, no cost. */
+enum {
+  CHEBHIP_STAGE_CHEB_APPLY = 0, CHEBHIP_STAGE_ELL_MULT, CHEBHIP_STAGE_ELL_FUNCTION, CHEBHIP_STAGE_STOKES_MULT,
+  CHEBHIP_STAGE_STOKES_MULT_VV, CHEBHIP_STAGE_STOKES_MULT_PV, CHEBHIP_STAGE_STOKES_MULT_VP, CHEBHIP_STAGE_STOKES_FUNCTION,
+  CHEBHIP_STAGE_STOKES_SCHUR, CHEBHIP_STAGE_FDPC_APPLY, CHEBHIP_STAGE_SADDLE_APPLY, CHEBHIP_STAGE_FGMRES_SOLVE,
+  CHEBHIP_NSTAGES
+};
+int chebhip_timers_enable(int on);
+int chebhip_timers_reset(void);
+int chebhip_timers_read(int stage, double *total_ms, long *calls);
+const char *chebhip_stage_name(int stage);
+
+/* min / max of the viscosity left by the last stokes_op_function: the VecMin / VecMax the reference prints inside
+ * StokesFunction (stokes.C:731-734).  Synchronises with `stream`; never called implicitly. */
+int stokes_op_viscosity_range(stokes_op *op, double *eta_min, double *eta_max, void *stream);
+/* StokesStateView (stokes.C:1821-1894, -output_vtk): legacy ASCII VTK file with velocity, pressure, force, eta, deta and
+ * strain on the full grid, same sections and number format as the reference.  Host I/O; synchronises the device. */
+int stokes_op_write_vtk(stokes_op *op, const double *state_dev, const char *path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,8 @@ ABI_SYMBOLS = [
     "chebhip_fdpc_mult", "chebhip_fdpc_apply",
     "stokes_saddle_create", "stokes_saddle_destroy", "stokes_saddle_set_type", "stokes_saddle_set_inner",
     "stokes_saddle_setup", "stokes_saddle_apply", "stokes_saddle_iterations", "stokes_saddle_set_pc_sweeps",
+    "chebhip_timers_enable", "chebhip_timers_reset", "chebhip_timers_read", "chebhip_stage_name",
+    "stokes_op_viscosity_range", "stokes_op_write_vtk",
 ]
 
 
@@ -143,6 +145,12 @@ def lib():
         L.stokes_saddle_apply.argtypes = [vp, vp, vp, vp]
         L.stokes_saddle_iterations.argtypes = [vp, C.c_int]
         L.stokes_saddle_set_pc_sweeps.argtypes = [vp, C.c_int]
+        L.chebhip_timers_enable.argtypes = [C.c_int]
+        L.chebhip_timers_read.argtypes = [C.c_int, dp, C.POINTER(C.c_long)]
+        L.chebhip_stage_name.argtypes = [C.c_int]
+        L.chebhip_stage_name.restype = C.c_char_p
+        L.stokes_op_viscosity_range.argtypes = [vp, dp, dp, vp]
+        L.stokes_op_write_vtk.argtypes = [vp, vp, C.c_char_p]
         _lib = L
     return _lib
 
@@ -464,6 +472,16 @@ class StokesOp:
     def inner_iterations(self):
         return lib().stokes_op_inner_iterations(self._h)
 
+    def viscosity_range(self):
+        """(min, max) of eta after the last `function`: what StokesFunction prints (stokes.C:731-734)."""
+        lo, hi = C.c_double(), C.c_double()
+        _chk(lib().stokes_op_viscosity_range(self._h, C.byref(lo), C.byref(hi), _stream()))
+        return lo.value, hi.value
+
+    def write_vtk(self, state, path):
+        """StokesStateView (stokes.C:1821-1894): the -output_vtk dump of a state vector (device tensor)."""
+        _chk(lib().stokes_op_write_vtk(self._h, _dev_ptr(state, self.global_size), str(path).encode()))
+
     def function(self, x, y):
         return self._call(lib().stokes_op_function, x, self.global_size, y, self.global_size)
 
@@ -491,6 +509,28 @@ class StokesOp:
             self.destroy()
         except Exception:
             pass
+
+
+def timers(enable=None, reset=False):
+    """Per-stage device timers of the library (chebhip_timers_*): timers(True) switches them on, timers() returns
+    {stage name: (total ms, calls)} for every stage that ran, timers(reset=True) clears the counters."""
+    L = lib()
+    if enable is not None:
+        _chk(L.chebhip_timers_enable(1 if enable else 0))
+    if reset:
+        _chk(L.chebhip_timers_reset())
+    out = {}
+    i = 0
+    while True:
+        name = L.chebhip_stage_name(i).decode()
+        if not name:
+            break
+        ms, calls = C.c_double(), C.c_long()
+        _chk(L.chebhip_timers_read(i, C.byref(ms), C.byref(calls)))
+        if calls.value:
+            out[name] = (ms.value, calls.value)
+        i += 1
+    return out
 
 
 class FdPc:

@@ -3,6 +3,8 @@
 #include "../../include/chebhip.h"
 #include "sweep.h"
 #include "ops.h"
+#include "timers.h"
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -52,6 +54,56 @@ static int g_stamp_cnt = 0;
 extern "C" void chebhip_debug_stamp_buffer(const void *dev) { g_stamp_buf = (const double *)dev; g_stamp_cnt = 0; }
 const double *chebhip_stamp_buf() { return g_stamp_buf; }
 int chebhip_stamp_next() { return g_stamp_cnt++; }
+
+// ---------------------------------------------------------------------------------------------
+// per-stage device timers (include/chebhip.h "Instrumentation")
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Pending { int id; hipEvent_t e0, e1; };
+std::mutex g_tm_mu;
+bool g_tm_on = false;
+std::vector<Pending> g_tm_pending;
+double g_tm_ms[CHEBHIP_NSTAGES] = {0};
+long g_tm_calls[CHEBHIP_NSTAGES] = {0};
+const char *const g_tm_names[CHEBHIP_NSTAGES] = {
+  "cheb_apply", "ell_op_mult", "ell_op_function", "stokes_op_mult", "stokes_op_mult_vv", "stokes_op_mult_pv", "stokes_op_mult_vp",
+  "stokes_op_function", "stokes_op_mult_schur", "chebhip_fdpc_apply", "stokes_saddle_apply", "chebhip_fgmres_solve"};
+void tm_drain_locked() {
+  for (auto &p : g_tm_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { g_tm_ms[p.id] += ms; g_tm_calls[p.id]++; }
+    (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+  }
+  g_tm_pending.clear();
+}
+}  // namespace
+chebhip::StageTimer::StageTimer(int stage, void *stream) : id(stage), st((hipStream_t)stream), on(g_tm_on) {
+  if (!on) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventRecord(e0, st) != hipSuccess) { on = false; if (e0) (void)hipEventDestroy(e0); }
+}
+chebhip::StageTimer::~StageTimer() {
+  if (!on) return;
+  hipEvent_t e1 = nullptr;
+  if (hipEventCreate(&e1) != hipSuccess || hipEventRecord(e1, st) != hipSuccess) { (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return; }
+  std::lock_guard<std::mutex> lk(g_tm_mu);
+  g_tm_pending.push_back({id, e0, e1});
+  if (g_tm_pending.size() > 4096) tm_drain_locked();     // bound the number of live events
+}
+extern "C" int chebhip_timers_enable(int on) { std::lock_guard<std::mutex> lk(g_tm_mu); g_tm_on = on != 0; return 0; }
+extern "C" int chebhip_timers_reset(void) {
+  std::lock_guard<std::mutex> lk(g_tm_mu);
+  tm_drain_locked();
+  for (int i = 0; i < CHEBHIP_NSTAGES; i++) { g_tm_ms[i] = 0.0; g_tm_calls[i] = 0; }
+  return 0;
+}
+extern "C" int chebhip_timers_read(int stage, double *total_ms, long *calls) {
+  if (stage < 0 || stage >= CHEBHIP_NSTAGES || !total_ms || !calls) return fail(CHEBHIP_ERR_ARG, "stage %d out of range", stage);
+  std::lock_guard<std::mutex> lk(g_tm_mu);
+  tm_drain_locked();
+  *total_ms = g_tm_ms[stage]; *calls = g_tm_calls[stage];
+  return 0;
+}
+extern "C" const char *chebhip_stage_name(int stage) { return (stage >= 0 && stage < CHEBHIP_NSTAGES) ? g_tm_names[stage] : ""; }
 
 static bool use_two_stage();
 
@@ -163,6 +215,7 @@ extern "C" int cheb_apply(cheb_plan *p, const double *x, double *y, void *stream
   if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct (as every ChebMult call site)");
   if (p->trimmed) return fail(CHEBHIP_ERR_ARG, "plan is trimmed: use cheb_apply_lap1d");
+  StageTimer tm(CHEBHIP_STAGE_CHEB_APPLY, stream);
   SweepParams sp = {};
   sp.ncols = p->ncols; sp.inner = p->inner;
   sp.in0 = x; sp.out = y; sp.alpha = 1.0;
@@ -701,6 +754,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   // empty vectors (a slab that owns only boundary planes) may be NULL
   if (!op || ((!U || !V) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (U && U == V) return fail(CHEBHIP_ERR_ARG, "U and V must be distinct (MatMult never aliases its vectors)");
+  StageTimer tm(CHEBHIP_STAGE_ELL_MULT, stream);
   if (op->slab) return ell_mult_slab(op, U, V, (hipStream_t)stream);
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -781,6 +835,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
                                const double *b, double *rhs, void *stream) {
   if (!op || ((!U || !rhs) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (U && (U == rhs || b == rhs)) return fail(CHEBHIP_ERR_ARG, "rhs must not alias U or b");
+  StageTimer tm(CHEBHIP_STAGE_ELL_FUNCTION, stream);
   hipStream_t st = (hipStream_t)stream;
   int rc = ell_alloc_state(op);
   if (rc) return rc;

@@ -9,6 +9,7 @@
 //   w -= V h;  h_{j+1,j} = |w|;  Givens rotations and the triangular solve on the host.
 // Reductions are two-stage with a fixed block order: results do not depend on scheduling.
 #include "../../include/chebhip.h"
+#include "timers.h"
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <new>
@@ -254,6 +255,7 @@ static int dev_norm(chebhip_fgmres *k, const double *v, hipStream_t st, double *
 extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void *actx, chebhip_apply_fn M, void *mctx,
                                     const double *b, double *x, int x_nonzero, void *stream) {
   if (!k || !A || ((!b || !x) && k->n > 0)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  chebhip::StageTimer tm(CHEBHIP_STAGE_FGMRES_SOLVE, stream);
   hipStream_t st = (hipStream_t)stream;
   const long n = k->n, ld = k->ld;
   const int m = k->m;

@@ -20,6 +20,7 @@
 #include "../../include/chebhip.h"
 #include "ops.h"
 #include "sweep.h"
+#include "timers.h"
 #include <cmath>
 #include <map>
 #include <new>
@@ -323,5 +324,6 @@ extern "C" int chebhip_fdpc_apply(void *ctx, const double *r, double *z, void *s
   chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
   if (!pc || ((!r || !z) && pc->G)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (r && r == z) return chebhip_fail(CHEBHIP_ERR_ARG, "r and z must be distinct");
+  StageTimer tm(CHEBHIP_STAGE_FDPC_APPLY, stream);
   return fdpc_apply(pc, r, z, (hipStream_t)stream);
 }

@@ -10,6 +10,7 @@
 // -schur_ksp_max_it 3, -svel_ksp_type preonly (one application of the MatVVPC solve).
 // Everything here goes through the public C ABI of the operator: vectors never leave HBM.
 #include "../../include/chebhip.h"
+#include "timers.h"
 #include <hip/hip_runtime.h>
 #include <new>
 
@@ -166,6 +167,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
   stokes_saddle *s = (stokes_saddle *)ctx;
   if (!s || ((!x || !y) && s->g)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (s->g == 0) return 0;
+  chebhip::StageTimer tm(CHEBHIP_STAGE_SADDLE_APPLY, stream);
   hipStream_t st = (hipStream_t)stream;
   const long I = s->I; const int d = s->d;
   const unsigned gg = sgrid(s->g), gpn = sgrid(s->gp), gvn = sgrid(s->gv);

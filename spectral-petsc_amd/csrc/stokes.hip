@@ -7,6 +7,7 @@
 #include "../../include/chebhip.h"
 #include "sweep.h"
 #include "ops.h"
+#include "timers.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -461,29 +462,33 @@ static int st_divergence(stokes_op *op, hipStream_t st) {
   return 0;
 }
 
+// boundary values of pL by extrapolation from the interior (StokesPressureReduceOrder, stokes.C:1029-1080); in slab
+// mode the x lines are left to the driver (see st_pressure_gradient)
+static void st_pressure_extrapolate(stokes_op *op, double *pL, hipStream_t st) {
+  const int d = op->d;
+  const long m = op->dims[0], n = op->dims[1], p = (d == 2) ? 1 : op->dims[2];
+  const long i_lo = (op->lo == 0) ? 1 : 0, ni = m - i_lo;
+  if (p > 1 && ni > 0) {
+    long g = (ni * (n - 1) + 3) / 4; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_st_preduce_contig, dim3((unsigned)g), dim3(256), 0, st, pL, ni, i_lo, n * p, n - 1, 1L, p,
+                       (int)p, (const double *)op->w0[2], (const double *)op->w1[2]);
+  }
+  if (ni > 0)
+    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(ni * p)), dim3(256), 0, st, pL, ni, i_lo, n * p, p, 0L, 1L, p,
+                       (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
+  if (!op->slab)
+    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(n * p)), dim3(256), 0, st, pL, n, 0L, p, p, 0L, 1L, n * p,
+                       (int)m, (const double *)op->w0[0], (const double *)op->w1[0]);
+}
+
 // pL (interior filled, boundary zero) -> boundary extrapolation -> gp[i] = DP[i] pL   (stokes.C:609-614)
 static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   const int d = op->d;
-  const long m = op->dims[0], n = op->dims[1], p = (d == 2) ? 1 : op->dims[2];
-  // planes i = 1..m-1 of the global grid that this handle owns: local planes i_lo .. m-1
-  const long i_lo = (op->lo == 0) ? 1 : 0, ni = m - i_lo;
-  if (p > 1 && ni > 0) {  // z lines of rows i = 1..m-1, j = 1..n-1 (stokes.C:1043-1052): contiguous lines
-    long g = (ni * (n - 1) + 3) / 4; if (g > 8192) g = 8192; if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_st_preduce_contig, dim3((unsigned)g), dim3(256), 0, st, op->pL, ni, i_lo, n * p, n - 1, 1L, p,
-                       (int)p, (const double *)op->w0[2], (const double *)op->w1[2]);
-  }
-  // y lines of planes i = 1..m-1, every k (stokes.C:1054-1062)
-  if (ni > 0)
-    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(ni * p)), dim3(256), 0, st, op->pL, ni, i_lo, n * p, p, 0L, 1L, p,
-                       (int)n, (const double *)op->w0[1], (const double *)op->w1[1]);
+  st_pressure_extrapolate(op, op->pL, st);      // z lines, y lines (and, on one GPU, x lines): stokes.C:1043-1074
   if (op->slab) {
     // x lines cross the slabs: extrapolation (stokes.C:1064-1074) and DP[0] happen on pencils, in the driver.  The end
     // planes of pL it would have filled only feed DP[1], DP[2] on those planes, which the final scatter never reads.
     int rc = op->dim0(op->dim0_ctx, 1, 1, op->pL, nullptr, 1.0, op->gp[0], st); if (rc) return rc;
-  } else {
-    // x lines, every (j, k) (stokes.C:1064-1074)
-    hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(n * p)), dim3(256), 0, st, op->pL, n, 0L, p, p, 0L, 1L, n * p,
-                       (int)m, (const double *)op->w0[0], (const double *)op->w1[0]);
   }
   for (int i = op->slab ? 1 : 0; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
   return 0;
@@ -511,6 +516,7 @@ static int st_join(stokes_op *op, hipStream_t st) {
 
 extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
   ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(out));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VV, stream);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
@@ -522,6 +528,7 @@ extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, v
 
 extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, void *stream) {
   ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(pout));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_PV, stream);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
@@ -533,6 +540,7 @@ extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, 
 
 extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, void *stream) {
   ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(vout));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VP, stream);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
@@ -544,6 +552,7 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
 
 extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void *stream) {
   ARGCHK(op); ARGCHK(VEC_OK(xG) && VEC_OK(yG));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT, stream);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   // scatterGV + scatterVL (zero boundary) and scatterGP (:505-510) in one pass over xG; the same xL serves
@@ -559,6 +568,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
 
 extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, void *stream) {
   ARGCHK(op); ARGCHK(VEC_OK(xG) && VEC_OK(yG));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_FUNCTION, stream);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
@@ -600,6 +610,7 @@ extern "C" int stokes_op_set_inner_reduce(stokes_op *op, chebhip_reduce_fn reduc
 
 extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream) {
   ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(out));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_SCHUR, stream);
   hipStream_t st = (hipStream_t)stream;
   const size_t gv = (size_t)op->I * op->d;
   if (!op->sv0) { int rc = st_alloc(&op->sv0, gv ? gv : 1); if (rc) return rc; if ((rc = st_alloc(&op->sv1, gv ? gv : 1))) return rc; }
@@ -678,3 +689,94 @@ extern "C" int stokes_op_set_state(stokes_op *op, int which, const double *src) 
   SHIPCHK(hipMemcpy(p, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
+
+// ---- min / max viscosity (the VecMin / VecMax of StokesFunction, stokes.C:731-734) ---------------------------
+// Optional: StokesFunction itself does not reduce or print anything (a reduction plus a host read-back inside the
+// residual would stall the stream); call this after it when the numbers are wanted.
+__global__ __launch_bounds__(256) void k_minmax(long n, const double *__restrict__ a, double *__restrict__ part) {
+  __shared__ double smin[256], smax[256];
+  double lo = 1.0 / 0.0, hi = -1.0 / 0.0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const double v = a[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]); smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = smin[0]; part[2 * blockIdx.x + 1] = smax[0]; }
+}
+
+extern "C" int stokes_op_viscosity_range(stokes_op *op, double *eta_min, double *eta_max, void *stream) {
+  ARGCHK(op && eta_min && eta_max);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = sgrid(op->N) > 256 ? 256 : sgrid(op->N);
+  // p2 is free between callbacks: 2 * nb partial results
+  if ((long)(2 * nb) > op->N) return chebhip_fail(CHEBHIP_ERR_SIZE, "grid too small");
+  hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, st, op->N, (const double *)op->eta, op->p2);
+  std::vector<double> h(2 * nb);
+  SHIPCHK(hipMemcpyAsync(h.data(), op->p2, 2 * nb * sizeof(double), hipMemcpyDeviceToHost, st));
+  SHIPCHK(hipStreamSynchronize(st));
+  double lo = h[0], hi = h[1];
+  for (unsigned b = 1; b < nb; b++) { lo = h[2 * b] < lo ? h[2 * b] : lo; hi = h[2 * b + 1] > hi ? h[2 * b + 1] : hi; }
+  *eta_min = lo; *eta_max = hi;
+  return 0;
+}
+
+// ---- StokesStateView (stokes.C:1821-1894): the ASCII legacy-VTK dump behind -output_vtk ----------------------
+// Same sections, order and number format as the reference ("%20e ", three values per point line, tensors as 3x3):
+// POINTS (node coordinates), velocity (with Dirichlet values), pressure (boundary filled by
+// StokesPressureReduceOrder), vel_force / div_force (the force vector treated the same way), eta, deta, strain.
+extern "C" int stokes_op_write_vtk(stokes_op *op, const double *state_dev, const char *path) {
+  ARGCHK(op && path); ARGCHK(VEC_OK(state_dev));
+  if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "stokes_op_write_vtk: serial handles only");
+  const int d = op->d; const long N = op->N;
+  SHIPCHK(hipDeviceSynchronize());
+  std::vector<double> v(N * d), p(N), fv(N * d, 0.0), fp(N, 0.0), eta(N), deta(N), strain((size_t)d * N * d);
+  auto fetch = [&](const double *src, std::vector<double> &vel, std::vector<double> &pre) -> int {
+    st_local(op, d + 1, d, src, op->dirloc, op->xL, op->pL, nullptr);                 // scatters + dirichlet (:1827-1838)
+    st_pressure_extrapolate(op, op->pL, nullptr);                                       // :1837
+    SHIPCHK(hipMemcpy(vel.data(), op->xL, (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost));
+    SHIPCHK(hipMemcpy(pre.data(), op->pL, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+  };
+  int rc = fetch(state_dev, v, p); if (rc) return rc;
+  if (op->force) { rc = fetch(op->force, fv, fp); if (rc) return rc; }                 // :1840-1851
+  SHIPCHK(hipMemcpy(eta.data(), op->eta, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  SHIPCHK(hipMemcpy(deta.data(), op->deta, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  for (int j = 0; j < d; j++) SHIPCHK(hipMemcpy(strain.data() + (size_t)j * N * d, op->strain[j], (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost));
+  FILE *f = fopen(path, "w");
+  if (!f) return chebhip_fail(CHEBHIP_ERR_ARG, "cannot open %s", path);
+  const int m = op->dims[0], n = op->dims[1], pp = d > 2 ? op->dims[2] : 1;
+  fprintf(f, "# vtk DataFile Version 2.0\nStokes Output\nASCII\nDATASET STRUCTURED_GRID\n");
+  fprintf(f, "DIMENSIONS %d %d %d\nPOINTS %ld double\n", m, n, pp, N);
+  {  // c->coord: x = cos(i pi/(dim-1)) per dimension (stokes.C:296), three values per line
+    std::vector<int> ind(d, 0);
+    for (long l = 0; l < N; l++) {
+      for (int j = 0; j < d; j++) fprintf(f, "%20e ", cos(ind[j] * 3.14159265358979323846 / (op->dims[j] - 1)));
+      for (int j = d; j < 3; j++) fprintf(f, "0 ");
+      fprintf(f, "\n");
+      for (int j = d - 1; j >= 0; j--) { if (++ind[j] < op->dims[j]) break; ind[j] = 0; }
+    }
+  }
+  auto vec3 = [&](const std::vector<double> &a) {       // component-major work vector, printed node by node (StokesVecView)
+    for (long l = 0; l < N; l++) { for (int j = 0; j < d; j++) fprintf(f, "%20e ", a[(size_t)j * N + l]); for (int j = d; j < 3; j++) fprintf(f, "0 "); fprintf(f, "\n"); }
+  };
+  auto scal = [&](const std::vector<double> &a) { for (long l = 0; l < N; l++) fprintf(f, "%20e \n", a[l]); };
+  fprintf(f, "\nPOINT_DATA %ld\nVECTORS velocity double\n", N); vec3(v);
+  fprintf(f, "\nSCALARS pressure double 1\nLOOKUP_TABLE default\n"); scal(p);
+  fprintf(f, "\nVECTORS vel_force double\n"); vec3(fv);
+  fprintf(f, "\nSCALARS div_force double 1\nLOOKUP_TABLE default\n"); scal(fp);
+  fprintf(f, "\nSCALARS eta double 1\nLOOKUP_TABLE default\n"); scal(eta);
+  fprintf(f, "\nSCALARS deta double 1\nLOOKUP_TABLE default\n"); scal(deta);
+  fprintf(f, "\nTENSORS strain double\n");
+  for (long l = 0; l < N; l++) {
+    for (int j = 0; j < 3; j++) {
+      for (int k = 0; k < 3; k++) fprintf(f, "%20e ", (j < d && k < d) ? strain[(size_t)j * N * d + (size_t)k * N + l] : 0.0);
+      fprintf(f, "\n");
+    }
+    fprintf(f, "\n");
+  }
+  if (fclose(f) != 0) return chebhip_fail(CHEBHIP_ERR_ARG, "write to %s failed", path);
+  return 0;
+}
+

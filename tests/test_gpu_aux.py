@@ -1,0 +1,110 @@
+"""Auxiliary pieces around the hot path: per-stage device timers, the viscosity range StokesFunction
+prints (stokes.C:731-734) and the -output_vtk dump StokesStateView (stokes.C:1821-1894)."""
+import re
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+import oracle_lib as orc
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+sp = ge.load()
+SEED = 20240229
+POWER = (1, 1.0, 3.0, 1e-4, 1.0)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def test_stage_timers():
+    op = sp.EllipticOp((40, 36, 32))
+    U = torch.randn(op.global_size, dtype=torch.float64, device="cuda"); V = torch.empty_like(U)
+    assert sp.timers(enable=False, reset=True) == {}
+    op.mult(U, V)                                     # timers off: nothing recorded
+    assert sp.timers() == {}
+    sp.timers(enable=True)
+    for _ in range(7):
+        op.mult(U, V)
+    ks = sp.Fgmres(op.global_size, restart=10, rtol=1e-3, max_it=10)
+    ks.solve(op, V, U)
+    t = sp.timers(enable=False)
+    # the 7 direct applies plus the solver's (one more may have been enqueued speculatively)
+    assert 7 + ks.iterations <= t["ell_op_mult"][1] <= 7 + ks.iterations + 2
+    assert t["ell_op_mult"][0] > 0 and t["chebhip_fgmres_solve"][1] == 1 and t["chebhip_fgmres_solve"][0] >= 0
+    sp.timers(reset=True)
+    assert sp.timers() == {}
+    ks.destroy(); op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(14, 12), (10, 9, 8)], ids=lambda d: "x".join(map(str, d)))
+def test_viscosity_range(dims):
+    st = sp.StokesOp(dims)
+    U, U2, dv = orc.stokes_exact(dims, 1)
+    rng = np.random.default_rng(SEED)
+    xs = U + 0.05 * rng.standard_normal(U.shape)
+    st.set_rheology(*POWER); st.set_dirichlet(dv); st.set_force(U2)
+    y = torch.empty(st.global_size, dtype=torch.float64, device="cuda")
+    st.function(dev(xs), y)
+    lo, hi = st.viscosity_range()
+    _, eta, _, _ = orc.stokes_function(dims, xs, dv, U2, POWER)
+    assert abs(lo - eta.min()) <= 1e-10 * eta.min() and abs(hi - eta.max()) <= 1e-10 * eta.max()
+    st.destroy()
+
+
+def _sections(path):
+    """{name: array} of a legacy VTK file as StokesStateView writes it."""
+    txt = open(path).read()
+    assert txt.startswith("# vtk DataFile Version 2.0\nStokes Output\nASCII\nDATASET STRUCTURED_GRID\n")
+    out = {}
+    m = re.search(r"DIMENSIONS (\d+) (\d+) (\d+)\nPOINTS (\d+) double\n", txt)
+    out["dims"] = tuple(int(v) for v in m.groups()[:3]); n = int(m.group(4))
+    heads = [("POINTS", r"POINTS \d+ double\n", 3), ("velocity", r"VECTORS velocity double\n", 3), ("pressure", r"SCALARS pressure double 1\nLOOKUP_TABLE default\n", 1),
+             ("vel_force", r"VECTORS vel_force double\n", 3), ("div_force", r"SCALARS div_force double 1\nLOOKUP_TABLE default\n", 1),
+             ("eta", r"SCALARS eta double 1\nLOOKUP_TABLE default\n", 1), ("deta", r"SCALARS deta double 1\nLOOKUP_TABLE default\n", 1),
+             ("strain", r"TENSORS strain double\n", 9)]
+    for name, pat, per in heads:
+        mm = re.search(pat, txt)
+        vals = txt[mm.end():].split()[:n * per]
+        out[name] = np.array([float(v) for v in vals]).reshape(n, per)
+    return out
+
+
+@pytest.mark.parametrize("dims", [(8, 7), (7, 6, 5)], ids=lambda d: "x".join(map(str, d)))
+def test_vtk_dump(dims, tmp_path):
+    d = len(dims)
+    st = sp.StokesOp(dims)
+    U, U2, dv = orc.stokes_exact(dims, 1)
+    rng = np.random.default_rng(SEED)
+    xs = U + 0.05 * rng.standard_normal(U.shape)
+    st.set_rheology(*POWER); st.set_dirichlet(dv); st.set_force(U2)
+    xd = dev(xs); y = torch.empty_like(xd)
+    st.function(xd, y)
+    path = tmp_path / "stokes.vtk"
+    st.write_vtk(xd, path)
+    s = _sections(path)
+    N = int(np.prod(dims))
+    assert s["dims"] == (dims[0], dims[1], dims[2] if d > 2 else 1) and s["POINTS"].shape[0] == N
+    # coordinates x = cos(i pi/(dim-1)) (stokes.C:296), row-major with the last dimension fastest
+    grids = np.meshgrid(*[np.cos(np.arange(p) * np.pi / (p - 1)) for p in dims], indexing="ij")
+    for j in range(d):
+        assert np.abs(s["POINTS"][:, j] - grids[j].ravel()).max() < 1e-6
+    _, eta, deta, strain = orc.stokes_function(dims, xs, dv, U2, POWER, mode=orc.DIRECT)
+    assert relerr(s["eta"][:, 0], eta) < 1e-6 and relerr(s["deta"][:, 0], deta) < 1e-6      # "%20e": 7 significant digits
+    # velocity = interior values of the state + Dirichlet values; pressure = interior + extrapolated boundary
+    m = np.ones(dims, dtype=bool)
+    for ax, p in enumerate(dims):
+        sl = [slice(None)] * d; sl[ax] = 0; m[tuple(sl)] = False; sl[ax] = p - 1; m[tuple(sl)] = False
+    X = xs.reshape(-1, d + 1)
+    vel = np.zeros((N, d)); vel[m.ravel()] = X[:, :d]; vel[~m.ravel()] = dv.reshape(-1, d)
+    assert relerr(s["velocity"][:, :d], vel) < 1e-6
+    pL = np.zeros(N); pL[m.ravel()] = X[:, d]
+    assert relerr(s["pressure"][:, 0], orc.stokes_pressure_reduce(dims, pL)) < 1e-6
+    T = s["strain"].reshape(N, 3, 3)
+    ref = strain.reshape(d, N, d)                       # strain[j][i*d+k]
+    for j in range(d):
+        for k in range(d):
+            assert np.abs(T[:, j, k] - ref[j][:, k]).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    st.destroy()
