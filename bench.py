@@ -79,6 +79,32 @@ def cpu_baseline(P, threads, U, V=None):
     return out, parity
 
 
+def dist_parity_check(make, dist, torch, rank, world, P=34):
+    """N > 1: the slab-partitioned matvec at a reduced size (P^3) against the oracle's serial matvec, checked on rank 0.
+    Returns {"rel_l2_vs_oracle": .., "P": ..}; a mismatch aborts the bench."""
+    import numpy as np
+    op = make((P, P, P))
+    U = op.random_input(SEED + 1)
+    V = torch.empty_like(U)
+    op.mult(U, V)
+    torch.cuda.synchronize()
+    pieces = [None] * world
+    dist.all_gather_object(pieces, V.cpu().numpy())
+    if hasattr(op, "destroy"):
+        op.destroy()
+    out = None
+    if rank == 0:
+        import oracle_lib as orc
+        g = torch.Generator(device="cpu").manual_seed(SEED + 1)
+        Ufull = torch.randn((P - 2) ** 3, dtype=torch.float64, generator=g).numpy()
+        ref = orc.elliptic_mult((P, P, P), Ufull, mode=orc.FAST, nthreads=4)
+        err = float(np.linalg.norm(np.concatenate(pieces) - ref) / np.linalg.norm(ref))
+        out = {"rel_l2_vs_oracle": err, "tolerance": 1e-10, "P": P, "ranks": world}
+        if not err <= 1e-10:
+            raise SystemExit("parity failure: %d-rank %d^3 matvec differs from the oracle by %.3e" % (world, P, err))
+    return out
+
+
 def extras(sp, torch):
     """Secondary timings (us per call, sustained loops, HIP events) of the other callbacks on the hot path, taken
     AFTER the timed region of the metric: BASELINE configs 2, 4, 5 and the variable-coefficient callbacks at the
@@ -157,12 +183,17 @@ def main():
         parallelism = "single"
     else:
         dsp = ge.load_dist()
-        op = dsp.DistPoissonOp(dims, backend=dsp.HipBackend(sp))
+        # The slab driver behind the C ABI (csrc/dist.hip: chebhip_dist_*, RCCL grouped send/recv on its own
+        # communicator); BENCH_DIST_IMPL=python selects its Python twin (torch.distributed all_to_all_single).
+        impl = os.environ.get("BENCH_DIST_IMPL", "c")
+        make = (lambda dm: dsp.DistPoissonC(dm, sp)) if impl == "c" else (lambda dm: dsp.DistPoissonOp(dm, backend=dsp.HipBackend(sp)))
+        dist_parity = dist_parity_check(make, dist, torch, rank, world)      # reduced size, against the oracle on rank 0
+        op = make(dims)
         U = op.random_input(SEED)
         V = torch.empty_like(U)
         step = lambda: op.mult(U, V)
         launches_per_step = 3
-        parallelism = "slab%d+all2all" % world
+        parallelism = "slab%d+all2all(%s, %s)" % (world, "C host" if impl == "c" else "python host", backend)
 
     def barrier():
         torch.cuda.synchronize()
@@ -235,6 +266,8 @@ def main():
                          "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},
             "device_ms_per_step": dev_ms / args.steps,
         }
+        if world > 1:
+            out["parity"] = dist_parity
         if world == 1 and not args.no_cpu_baseline:
             try:
                 Uh, Vh = U.cpu().numpy(), V.cpu().numpy()

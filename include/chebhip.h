@@ -205,6 +205,37 @@ int stokes_op_pencil_sweep(stokes_op *op, int nfields, long ncol, const double *
 int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil_dev, double *gp0_pencil_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
+/* Multi-GPU host for BASELINE config 3: the linear 3-D Poisson    */
+/* matvec slab-partitioned along dimension 0, one rank per GPU, two            */
+/* all-to-all exchanges per matvec (slab <-> pencil), local sweeps overlapped   */
+/* with them on a second stream, accumulation in the serial order k = 0,1,2.   */
+/* No counterpart in the serial reference (elliptic.C:262, nk.c:63); any G      */
+/* reproduces the G = 1 vector.  Vectors: this rank's contiguous piece of the   */
+/* reference's global vector ([chebhip_dist_slab_offset, + local_size)).        */
+/* ------------------------------------------------------------------------- */
+typedef struct chebhip_dist chebhip_dist;
+/* Moves one exchange: send_dev holds, peer-major and contiguous, send_counts[s] doubles for every rank s; the
+ * counts received from rank s are recv_counts[s], stored peer-major in recv_dev; ordered on `stream`. */
+typedef int (*chebhip_exchange_fn)(void *ctx, const double *send_dev, const long *send_counts, double *recv_dev,
+                                   const long *recv_counts, void *stream);
+int chebhip_dist_create(int d, const int *dims, int nranks, int rank, chebhip_dist **out);
+int chebhip_dist_destroy(chebhip_dist *D);
+long chebhip_dist_local_size(const chebhip_dist *D);
+long chebhip_dist_slab_offset(const chebhip_dist *D);
+/* Transport: grouped ncclSend / ncclRecv on `nccl_comm` (an ncclComm_t of nranks ranks, rank order as at create;
+ * rccl.h:700,722,923) -- RCCL is looked up at run time, never linked -- or any other exchange function. */
+int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm);
+int chebhip_dist_set_exchange(chebhip_dist *D, chebhip_exchange_fn fn, void *ctx);
+/* MatMult_Elliptic (elliptic.C:297-339, eta = 1, deta = 0) on the slab: V = -(L_0 + L_1 + ..) U. */
+int chebhip_dist_mult(chebhip_dist *D, const double *U_slab_dev, double *V_slab_dev, void *stream);
+/* For hosts without a communicator of their own: rank 0 makes the 128-byte id, the host hands it to every rank. */
+int chebhip_rccl_unique_id(void *id128);
+int chebhip_rccl_comm_create(int nranks, int rank, const void *id128, void **nccl_comm_out);
+int chebhip_rccl_comm_destroy(void *nccl_comm);
+/* A chebhip_reduce_fn (ctx = the ncclComm_t): ncclAllReduce of the few doubles a Krylov iteration needs. */
+int chebhip_rccl_reduce(void *nccl_comm, double *vals_dev, int count, void *stream);
+
+/* ------------------------------------------------------------------------- */
 /* Krylov driver on device vectors: the caller of the path.     */
 /* KSPSolve with KSPFGMRES around MatMult_Elliptic (elliptic.C:181-185) and    */
 /* KSPSchurVelocity inside StokesMatMultSchur (stokes.C:531).  Restarted       */

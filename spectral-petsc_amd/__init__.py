@@ -46,6 +46,9 @@ ABI_SYMBOLS = [
     "stokes_saddle_setup", "stokes_saddle_apply", "stokes_saddle_iterations", "stokes_saddle_set_pc_sweeps",
     "chebhip_timers_enable", "chebhip_timers_reset", "chebhip_timers_read", "chebhip_stage_name",
     "stokes_op_viscosity_range", "stokes_op_write_vtk",
+    "chebhip_dist_create", "chebhip_dist_destroy", "chebhip_dist_local_size", "chebhip_dist_slab_offset",
+    "chebhip_dist_use_rccl", "chebhip_dist_set_exchange", "chebhip_dist_mult",
+    "chebhip_rccl_unique_id", "chebhip_rccl_comm_create", "chebhip_rccl_comm_destroy", "chebhip_rccl_reduce",
 ]
 
 
@@ -151,6 +154,18 @@ def lib():
         L.chebhip_stage_name.restype = C.c_char_p
         L.stokes_op_viscosity_range.argtypes = [vp, dp, dp, vp]
         L.stokes_op_write_vtk.argtypes = [vp, vp, C.c_char_p]
+        L.chebhip_dist_create.argtypes = [C.c_int, ip, C.c_int, C.c_int, C.POINTER(vp)]
+        L.chebhip_dist_destroy.argtypes = [vp]
+        for f in (L.chebhip_dist_local_size, L.chebhip_dist_slab_offset):
+            f.argtypes = [vp]
+            f.restype = C.c_long
+        L.chebhip_dist_use_rccl.argtypes = [vp, vp]
+        L.chebhip_dist_set_exchange.argtypes = [vp, vp, vp]
+        L.chebhip_dist_mult.argtypes = [vp, vp, vp, vp]
+        L.chebhip_rccl_unique_id.argtypes = [vp]
+        L.chebhip_rccl_comm_create.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.chebhip_rccl_comm_destroy.argtypes = [vp]
+        L.chebhip_rccl_reduce.argtypes = [vp, vp, C.c_int, vp]
         _lib = L
     return _lib
 

@@ -1,0 +1,283 @@
+// dist.hip -- the slab-partitioned linear Poisson matvec of BASELINE config 3, host side in C++ behind the C ABI
+// (the reference itself is strictly serial: elliptic.C:262 VecCreateSeq, nk.c:63).
+//
+// Everything lives in the interior layout of the reference's global vector (M0, M1, ..) = dims - 2, row-major
+// (SetupBC, elliptic.C:372-434).  Rank r owns the planes [s0[r], s0[r+1]) of dimension 0.  With L_k the interior
+// second-derivative operator of a zero-Dirichlet line (MatMult_Elliptic with eta = 1, deta = 0, elliptic.C:297-339):
+//
+//   main stream                               side stream
+//   A_1 = -L_1 U   (slab, local)              buf  = pack(U)                     blocks U[:, c1[s]:c1[s+1], :]
+//   A_2 = -L_2 U   ...                        UT   = exchange(buf)               slab -> pencil (M0, m1, R)
+//                                             TT   = -L_0 UT                     one launch on the pencil
+//                                             T    = exchange(TT)                pencil rows -> slab blocks
+//   V = ((T + A_1) + A_2) + ...               (waits for the side stream)
+//
+// The sum runs in the serial order k = 0, 1, 2 (elliptic.C:331-334), so every G reproduces the G = 1 vector to the
+// last bits of the per-line products.  Two exchanges per matvec; the pencil side of the forward exchange and the
+// slab-row side of the backward one need no (un)packing.
+//
+// Transport.  chebhip_dist_use_rccl: grouped ncclSend / ncclRecv (one RCCL launch per exchange, G-1 direct xGMI
+// messages per GPU) on a communicator the caller supplies -- or one made by chebhip_rccl_comm_create from a unique
+// id the host distributes.  RCCL is looked up at run time (the copy the process already holds, e.g. PyTorch's,
+// else the system one) and never linked.  chebhip_dist_set_exchange plugs in any other transport with the same
+// contract (the CPU tests run the exchange logic under gloo that way).
+#include "../../include/chebhip.h"
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+
+#define DHIPCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+// ---- RCCL through dlopen (rccl.h:236-923; types restated so that no header of the library is needed) ---------
+struct Id128 { char internal[128]; };     // ncclUniqueId
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *id) = nullptr;                                       // ncclGetUniqueId(ncclUniqueId*): 128 bytes
+  int (*CommInitRank)(void **comm, int nranks, Id128 id, int rank) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*GroupStart)() = nullptr, (*GroupEnd)() = nullptr;
+  int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+  int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+  int (*AllReduce)(const void *s, void *r, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+
+bool rccl_ready() {
+  std::call_once(g_rccl_once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // the process's own copy first
+    for (const char *n : names) if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl.lib) return;
+    void *L = g_rccl.lib;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(L, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(L, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(L, "ncclCommDestroy");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(L, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(L, "ncclGroupEnd");
+    g_rccl.Send = (decltype(g_rccl.Send))dlsym(L, "ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(L, "ncclRecv");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(L, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(L, "ncclGetErrorString");
+    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd &&
+                g_rccl.Send && g_rccl.Recv && g_rccl.AllReduce;
+  });
+  return g_rccl.ok;
+}
+int rccl_fail(const char *what, int rc) {
+  return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+
+// ---- pack / combine -------------------------------------------------------------------------------------------
+struct Split { int G; long c1[65]; };
+// position in the exchange buffer (peer-major: for peer s the block slab[:, c1[s]:c1[s+1], :]) of slab element e
+__device__ __forceinline__ long buf_index(const Split &sp, long m0, long M1, long R, long e) {
+  const long i0 = e / (M1 * R), rem = e - i0 * (M1 * R);
+  const long j = rem / R, r = rem - j * R;
+  int s = 0;
+  while (s + 1 < sp.G && j >= sp.c1[s + 1]) s++;
+  const long w = sp.c1[s + 1] - sp.c1[s];
+  return m0 * sp.c1[s] * R + (i0 * w + (j - sp.c1[s])) * R + r;
+}
+__global__ void k_pack(Split sp, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf) {
+  const long n = m0 * M1 * R;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) buf[buf_index(sp, m0, M1, R, e)] = slab[e];
+}
+struct APtrs { const double *p[9]; int n; };
+// V = ((T + A_1) + A_2) + ...   T in exchange order: the serial accumulation order k = 0, 1, 2 (elliptic.C:331-334)
+__global__ void k_combine(Split sp, long m0, long M1, long R, const double *__restrict__ buf, APtrs A, double *__restrict__ out) {
+  const long n = m0 * M1 * R;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    double v = buf[buf_index(sp, m0, M1, R, e)];
+    for (int k = 0; k < A.n; k++) v = v + A.p[k][e];
+    out[e] = v;
+  }
+}
+static inline unsigned dgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+static void split_sizes(long n, int parts, std::vector<long> &sz) { sz.resize(parts); for (int i = 0; i < parts; i++) sz[i] = n / parts + (i < n % parts ? 1 : 0); }
+
+}  // namespace
+
+struct chebhip_dist {
+  int d = 0, G = 1, rank = 0;
+  std::vector<long> M;                        // interior extents
+  long R = 1;                                 // trailing dimensions flattened
+  std::vector<long> m0, m1, s0, s1;           // plane / column counts and offsets per rank
+  long local = 0, pencil = 0;
+  std::vector<long> fwd_send, fwd_recv;       // doubles per peer (backward: roles swap)
+  std::vector<cheb_plan *> slab_plan;         // directions 1..d-1 on the slab
+  cheb_plan *pencil_plan = nullptr;           // direction 0 on the pencil
+  std::vector<double *> A;                    // d-1 local contributions
+  double *sendbuf = nullptr, *recvbuf = nullptr, *UT = nullptr, *TT = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  chebhip_exchange_fn xfn = nullptr; void *xctx = nullptr;
+  void *comm = nullptr;                       // RCCL communicator (not owned)
+  Split split;
+};
+
+extern "C" int chebhip_dist_destroy(chebhip_dist *D) {
+  if (!D) return 0;
+  for (auto p : D->slab_plan) if (p) cheb_plan_destroy(p);
+  if (D->pencil_plan) cheb_plan_destroy(D->pencil_plan);
+  for (auto p : D->A) if (p) (void)hipFree(p);
+  double *all[] = {D->sendbuf, D->recvbuf, D->UT, D->TT};
+  for (double *p : all) if (p) (void)hipFree(p);
+  if (D->side) (void)hipStreamDestroy(D->side);
+  if (D->ev_in) (void)hipEventDestroy(D->ev_in);
+  if (D->ev_out) (void)hipEventDestroy(D->ev_out);
+  delete D;
+  return 0;
+}
+
+extern "C" int chebhip_dist_create(int d, const int *dims, int nranks, int rank, chebhip_dist **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!dims || d < 2 || d > 10) return chebhip_fail(CHEBHIP_ERR_DIMS, "slab partitioning needs 2 <= d <= 10");
+  if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return chebhip_fail(CHEBHIP_ERR_ARG, "rank %d of %d", rank, nranks);
+  for (int k = 0; k < d; k++) if (dims[k] < 3 || dims[k] > 258) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d must be in 3..258", k, dims[k]);
+  if (dims[0] - 2 < nranks || dims[1] - 2 < nranks)
+    return chebhip_fail(CHEBHIP_ERR_SIZE, "every rank needs at least one interior plane along dimensions 0 and 1");
+  chebhip_dist *D = new (std::nothrow) chebhip_dist;
+  if (!D) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  D->d = d; D->G = nranks; D->rank = rank;
+  D->M.resize(d); for (int k = 0; k < d; k++) D->M[k] = dims[k] - 2;
+  D->R = 1; for (int k = 2; k < d; k++) D->R *= D->M[k];
+  split_sizes(D->M[0], nranks, D->m0); split_sizes(D->M[1], nranks, D->m1);
+  D->s0.assign(nranks + 1, 0); D->s1.assign(nranks + 1, 0);
+  for (int s = 0; s < nranks; s++) { D->s0[s + 1] = D->s0[s] + D->m0[s]; D->s1[s + 1] = D->s1[s] + D->m1[s]; }
+  D->local = D->m0[rank] * D->M[1] * D->R;
+  D->pencil = D->M[0] * D->m1[rank] * D->R;
+  D->fwd_send.resize(nranks); D->fwd_recv.resize(nranks);
+  for (int s = 0; s < nranks; s++) { D->fwd_send[s] = D->m0[rank] * D->m1[s] * D->R; D->fwd_recv[s] = D->m0[s] * D->m1[rank] * D->R; }
+  D->split.G = nranks; for (int s = 0; s <= nranks; s++) D->split.c1[s] = D->s1[s];
+  int rc = 0;
+#define DCHK(expr) do { rc = (expr); if (rc) { chebhip_dist_destroy(D); return rc; } } while (0)
+#define DHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { chebhip_dist_destroy(D); \
+    return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+  {  // plans on the stored (interior) tensors: slab (m0, M1, M2..), pencil (M0, m1, M2..)
+    std::vector<int> sd(d), pd(d);
+    for (int k = 0; k < d; k++) { sd[k] = (int)D->M[k]; pd[k] = (int)D->M[k]; }
+    sd[0] = (int)D->m0[rank]; pd[1] = (int)D->m1[rank];
+    D->slab_plan.assign(d, nullptr);
+    for (int k = 1; k < d; k++) DCHK(cheb_plan_create_trimmed(d, k, sd.data(), &D->slab_plan[k]));
+    DCHK(cheb_plan_create_trimmed(d, 0, pd.data(), &D->pencil_plan));
+  }
+  const size_t lb = (size_t)(D->local > 0 ? D->local : 1) * sizeof(double), pb = (size_t)(D->pencil > 0 ? D->pencil : 1) * sizeof(double);
+  D->A.assign(d - 1, nullptr);
+  for (int k = 0; k < d - 1; k++) DHIP(hipMalloc((void **)&D->A[k], lb));
+  DHIP(hipMalloc((void **)&D->sendbuf, lb)); DHIP(hipMalloc((void **)&D->recvbuf, lb));
+  DHIP(hipMalloc((void **)&D->UT, pb)); DHIP(hipMalloc((void **)&D->TT, pb));
+  DHIP(hipStreamCreateWithFlags(&D->side, hipStreamNonBlocking));
+  DHIP(hipEventCreateWithFlags(&D->ev_in, hipEventDisableTiming));
+  DHIP(hipEventCreateWithFlags(&D->ev_out, hipEventDisableTiming));
+#undef DCHK
+#undef DHIP
+  *out = D;
+  return 0;
+}
+
+extern "C" long chebhip_dist_local_size(const chebhip_dist *D) { return D ? D->local : -1; }
+extern "C" long chebhip_dist_slab_offset(const chebhip_dist *D) { return D ? D->s0[D->rank] * D->M[1] * D->R : -1; }
+
+extern "C" int chebhip_dist_set_exchange(chebhip_dist *D, chebhip_exchange_fn fn, void *ctx) {
+  if (!D) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  D->xfn = fn; D->xctx = ctx; D->comm = nullptr;
+  return 0;
+}
+extern "C" int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm) {
+  if (!D || !nccl_comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  D->comm = nccl_comm; D->xfn = nullptr; D->xctx = nullptr;
+  return 0;
+}
+
+// send[s] (doubles, peer-major, contiguous) -> recv[s]: one grouped RCCL launch, the own block by a device copy
+static int exchange(chebhip_dist *D, const double *send, const long *sc, double *recv, const long *rc_, hipStream_t st) {
+  if (D->xfn) return D->xfn(D->xctx, send, sc, recv, rc_, (void *)st);
+  long so = 0, ro = 0;
+  if (D->G == 1 && !D->comm) { DHIPCHK(hipMemcpyAsync(recv, send, (size_t)sc[0] * sizeof(double), hipMemcpyDeviceToDevice, st)); return 0; }
+  if (!D->comm) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist: no transport set (chebhip_dist_use_rccl / chebhip_dist_set_exchange)");
+  int rc = g_rccl.GroupStart(); if (rc) return rccl_fail("ncclGroupStart", rc);
+  // CHEBHIP_DIST_SELF_RCCL=1 (smoke tests on one GPU): the rank's own block goes through ncclSend / ncclRecv as well
+  static const bool self_rccl = [] { const char *e = getenv("CHEBHIP_DIST_SELF_RCCL"); return e && e[0] == '1'; }();
+  for (int s = 0; s < D->G; s++) {
+    if (s == D->rank && !self_rccl) { if (sc[s]) DHIPCHK(hipMemcpyAsync(recv + ro, send + so, (size_t)sc[s] * sizeof(double), hipMemcpyDeviceToDevice, st)); }
+    else {
+      if (sc[s] && (rc = g_rccl.Send(send + so, (size_t)sc[s], NCCL_DOUBLE, s, D->comm, st))) { g_rccl.GroupEnd(); return rccl_fail("ncclSend", rc); }
+      if (rc_[s] && (rc = g_rccl.Recv(recv + ro, (size_t)rc_[s], NCCL_DOUBLE, s, D->comm, st))) { g_rccl.GroupEnd(); return rccl_fail("ncclRecv", rc); }
+    }
+    so += sc[s]; ro += rc_[s];
+  }
+  rc = g_rccl.GroupEnd(); if (rc) return rccl_fail("ncclGroupEnd", rc);
+  return 0;
+}
+
+extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, void *stream) {
+  if (!D || !U || !V) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (U == V) return chebhip_fail(CHEBHIP_ERR_ARG, "U and V must be distinct");
+  hipStream_t st = (hipStream_t)stream, side = D->side;
+  const int d = D->d, r = D->rank;
+  const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
+  int rc;
+  // side stream: U is ready when the caller's stream gets here
+  DHIPCHK(hipEventRecord(D->ev_in, st));
+  DHIPCHK(hipStreamWaitEvent(side, D->ev_in, 0));
+  hipLaunchKernelGGL(k_pack, dim3(dgrid(D->local)), dim3(256), 0, side, D->split, m0, M1, R, U, D->sendbuf);
+  if ((rc = exchange(D, D->sendbuf, D->fwd_send.data(), D->UT, D->fwd_recv.data(), side))) return rc;          // lands as the pencil
+  if ((rc = cheb_apply_lap1d(D->pencil_plan, D->UT, nullptr, -1.0, D->TT, side))) return rc;                    // TT = -L_0 UT
+  if ((rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), side))) return rc;           // pencil rows -> slab blocks
+  DHIPCHK(hipEventRecord(D->ev_out, side));
+  // main stream: the local directions, each into its own array (they overlap both exchanges)
+  for (int k = 1; k < d; k++) if ((rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[k - 1], st))) return rc;
+  DHIPCHK(hipStreamWaitEvent(st, D->ev_out, 0));
+  APtrs A; A.n = d - 1; for (int k = 0; k < 9; k++) A.p[k] = k < d - 1 ? D->A[k] : nullptr;
+  hipLaunchKernelGGL(k_combine, dim3(dgrid(D->local)), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, A, V);
+  DHIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- communicator helpers for hosts that do not bring their own ncclComm_t ------------------------------------
+extern "C" int chebhip_rccl_unique_id(void *id128) {
+  if (!id128) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  int rc = g_rccl.GetUniqueId(id128); if (rc) return rccl_fail("ncclGetUniqueId", rc);
+  return 0;
+}
+extern "C" int chebhip_rccl_comm_create(int nranks, int rank, const void *id128, void **comm) {
+  if (!id128 || !comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  Id128 id; memcpy(&id, id128, sizeof id);
+  int rc = g_rccl.CommInitRank(comm, nranks, id, rank); if (rc) return rccl_fail("ncclCommInitRank", rc);
+  return 0;
+}
+extern "C" int chebhip_rccl_comm_destroy(void *comm) {
+  if (!comm) return 0;
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  int rc = g_rccl.CommDestroy(comm); if (rc) return rccl_fail("ncclCommDestroy", rc);
+  return 0;
+}
+// chebhip_reduce_fn over an RCCL communicator (ctx = the ncclComm_t): the all-reduce of a few doubles per Krylov
+// iteration (rccl.h:611), for chebhip_fgmres_set_reduce / stokes_op_set_inner_reduce
+extern "C" int chebhip_rccl_reduce(void *comm, double *vals_dev, int count, void *stream) {
+  if (!comm || !vals_dev || count < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  int rc = g_rccl.AllReduce(vals_dev, vals_dev, (size_t)count, NCCL_DOUBLE, NCCL_SUM, comm, (hipStream_t)stream);
+  if (rc) return rccl_fail("ncclAllReduce", rc);
+  return 0;
+}

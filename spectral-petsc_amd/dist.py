@@ -17,9 +17,12 @@ zero-extended lines (MatMult_Elliptic with eta = 1, deta = 0, elliptic.C:297-339
 
 The two exchanges are the only collectives (torch.distributed all_to_all_single = RCCL
 all-to-all; each GPU sends 7 direct xGMI messages).  The forward exchange overlaps the first
-local launch, the backward exchange the last one (separate HIP stream).  The accumulation order
-differs from the serial k = 0,1,2 order (k = 0 arrives last), which changes the result in the
-last bits only.
+local launches (separate HIP stream).  The local terms are kept in arrays of their own and summed
+with the exchanged term in the serial order k = 0, 1, 2 (elliptic.C:331-334).
+
+The product driver is DistPoissonC below: the same algorithm in C++ behind the C ABI (csrc/dist.hip,
+chebhip_dist_*) with RCCL as its transport.  DistPoissonOp is its Python twin: the exchange logic with the
+local arithmetic delegated to a backend, which lets tests/ run it under gloo on CPU with an oracle backend.
 
 The local arithmetic is delegated to a backend: HipBackend (the product: C-ABI calls on device
 tensors).  tests/ supplies an oracle-based CPU backend to exercise the exchange logic under gloo.
@@ -101,6 +104,7 @@ class DistPoissonOp:
         # but no cross-stream dependencies either)
         serial = os.environ.get("CHEBHIP_DIST_SERIAL") == "1"
         self.comm_stream = backend.side_stream() if ((G > 1 or forced) and not serial) else None
+        self.A = []
 
     # ---- helpers -------------------------------------------------------------------------------
     def random_input(self, seed):
@@ -123,33 +127,124 @@ class DistPoissonOp:
 
     # ---- the matvec ----------------------------------------------------------------------------
     def mult(self, U, V):
+        """V = ((T_0 + A_1) + A_2) + ..: the local terms A_k = -L_k U go to arrays of their own (they overlap both
+        exchanges) and are added to the exchanged term T_0 = -L_0 U in the serial order k = 0, 1, 2 (elliptic.C:331-334)."""
         be, M = self.backend, self.M
         d = len(M)
         cs = self.comm_stream
-        if cs is not None:
-            cur = torch.cuda.current_stream()
-            cs.wait_stream(cur)
-            with torch.cuda.stream(cs):
-                be.pack(U, self.sendbuf, self.m0[self.rank], M[1], self.R, self.c1)
-                self._a2a(self.UT, self.sendbuf, self.fwd_recv, self.fwd_send)
-        else:
+        if len(self.A) < d - 1:
+            self.A = [torch.empty(self.local_size, dtype=torch.float64, device=be.device) for _ in range(d - 1)]
+
+        def exchange_chain():
             be.pack(U, self.sendbuf, self.m0[self.rank], M[1], self.R, self.c1)
             self._a2a(self.UT, self.sendbuf, self.fwd_recv, self.fwd_send)
-        # local directions 1..d-1 on the slab (overlap the forward exchange)
-        be.lap1d(U, self.slab_shape, 1, self.W, None, -1.0)
-        if cs is not None:
-            with torch.cuda.stream(cs):
-                be.lap1d(self.UT, self.pencil_shape, 0, self.TT, None, -1.0)
-                self._a2a(self.sendbuf, self.TT, self.fwd_send, self.fwd_recv)   # back: roles of the splits swap
-        else:
             be.lap1d(self.UT, self.pencil_shape, 0, self.TT, None, -1.0)
-            self._a2a(self.sendbuf, self.TT, self.fwd_send, self.fwd_recv)
-        for k in range(2, d):                                                    # overlap the backward exchange
-            be.lap1d(U, self.slab_shape, k, self.W, self.W, -1.0)
+            self._a2a(self.sendbuf, self.TT, self.fwd_send, self.fwd_recv)       # back: roles of the splits swap
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                exchange_chain()
+        else:
+            exchange_chain()
+        for k in range(1, d):                                                    # overlap both exchanges
+            be.lap1d(U, self.slab_shape, k, self.A[k - 1], None, -1.0)
         if cs is not None:
             torch.cuda.current_stream().wait_stream(cs)
-        be.unpack_add(self.sendbuf, self.W, V, self.m0[self.rank], M[1], self.R, self.c1)   # V = W + T
+        be.unpack_add(self.sendbuf, None, self.W, self.m0[self.rank], M[1], self.R, self.c1)   # W = T_0
+        for k in range(1, d):
+            out = V if k == d - 1 else self.W
+            torch.add(self.W, self.A[k - 1], out=out)                           # (T_0 + A_1) + A_2 ...
         return V
+
+
+class DistPoissonC:
+    """The slab driver that lives behind the C ABI (csrc/dist.hip: chebhip_dist_*): partition, pack, the two
+    exchanges, pencil launch, overlap on a side stream and the fixed-order sum are all C++; this class only hands it
+    a transport -- an RCCL communicator made from a unique id that rank 0 broadcasts through the process group
+    (backend "nccl"), or, for rehearsals on one GPU under gloo, a callback that stages the exchange through the host."""
+
+    def __init__(self, dims, sp, group=None):
+        import ctypes as C
+        self.sp, self.group = sp, group
+        self.dims = tuple(int(v) for v in dims)
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        L = sp.lib()
+        h = C.c_void_p()
+        sp._chk(L.chebhip_dist_create(len(self.dims), (C.c_int * len(self.dims))(*self.dims), self.G, self.rank, C.byref(h)))
+        self._h = h
+        self.local_size = L.chebhip_dist_local_size(h)
+        self.slab_offset = L.chebhip_dist_slab_offset(h)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._comm = None
+        self._cb = None
+        forced = dist.is_initialized() and os.environ.get("CHEBHIP_DIST_FORCE_A2A") == "1"
+        if self.G > 1 or forced:
+            if dist.get_backend(group) == "nccl":
+                idbuf = C.create_string_buffer(128)
+                if self.rank == 0:
+                    sp._chk(L.chebhip_rccl_unique_id(idbuf))
+                box = [bytes(idbuf.raw)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                comm = C.c_void_p()
+                sp._chk(L.chebhip_rccl_comm_create(self.G, self.rank, C.create_string_buffer(box[0], 128), C.byref(comm)))
+                self._comm = comm
+                sp._chk(L.chebhip_dist_use_rccl(h, comm))
+            else:
+                self._cb = self._host_exchange()
+                sp._chk(L.chebhip_dist_set_exchange(h, C.cast(self._cb, C.c_void_p), None))
+
+    def _host_exchange(self):
+        """chebhip_exchange_fn under gloo: device -> host, all_to_all_single, host -> device, ordered on `stream`."""
+        import ctypes as C
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.POINTER(C.c_long), C.c_void_p)
+        G, sp, group = self.G, self.sp, self.group
+
+        def xfn(ctx, send, sc, recv, rc, stream):
+            try:
+                scl = [int(sc[i]) for i in range(G)]; rcl = [int(rc[i]) for i in range(G)]
+                ext = torch.cuda.ExternalStream(int(stream or 0))
+                with torch.cuda.stream(ext):
+                    hs = sp.device_view(send, max(sum(scl), 1))[:sum(scl)].cpu()          # synchronises with `stream`
+                    hr = torch.empty(sum(rcl), dtype=torch.float64)
+                    dist.all_to_all_single(hr, hs, rcl, scl, group=group)
+                    if sum(rcl):
+                        sp.device_view(recv, sum(rcl)).copy_(hr)
+                    ext.synchronize()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 5
+        return FN(xfn)
+
+    def random_input(self, seed):
+        """Rank-local slab of the global N(0,1) vector: every G sees the same global field."""
+        M = [v - 2 for v in self.dims]
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        full = torch.randn(int(np.prod(M)), dtype=torch.float64, generator=g)
+        return full[self.slab_offset:self.slab_offset + self.local_size].contiguous().to(self.device)
+
+    def mult(self, U, V):
+        sp = self.sp
+        sp._chk(sp.lib().chebhip_dist_mult(self._h, sp._dev_ptr(U, self.local_size), sp._dev_ptr(V, self.local_size), sp._stream()))
+        return V
+
+    def reduce_fn(self):
+        """(chebhip_reduce_fn, ctx) completing Krylov inner products over the ranks: ncclAllReduce on the C side."""
+        import ctypes as C
+        if self._comm is not None:
+            return C.cast(self.sp.lib().chebhip_rccl_reduce, C.c_void_p), self._comm
+        return None, None
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize()
+            self.sp.lib().chebhip_dist_destroy(self._h)
+            self._h = None
+        if getattr(self, "_comm", None):
+            self.sp.lib().chebhip_rccl_comm_destroy(self._comm)
+            self._comm = None
 
 
 class _SlabPencil:
