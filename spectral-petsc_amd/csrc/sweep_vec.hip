@@ -762,13 +762,27 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
   if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
   // the first tile's lines are requested BEFORE the matrix fragments: one memory round trip instead of two
   issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
+  // Every workgroup of the chip fetches the same 256 KiB at the same moment.  The CUs of an XCD start at four
+  // different places of their fragment sets (a static rotation per code path: the registers are fixed), which
+  // spreads the requests over the L2 channels instead of queueing them on one line at a time.
+  auto load_frags = [&](auto ROT_) {
+    constexpr int ROT = decltype(ROT_)::value;
 #pragma unroll
-  for (int g = 0; g < KS / 2; g++) {                   // two fragments per 16-byte load
-    const d2 ve = ((const d2 *)p.fragE2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
-    const d2 vo = ((const d2 *)p.fragO2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
-    ae[2 * g] = ve.x; ae[2 * g + 1] = ve.y;
-    if (2 * g < KR) ao[2 * g] = vo.x; else aoL[(2 * g - KR) * 64] = vo.x;
-    if (2 * g + 1 < KR) ao[2 * g + 1] = vo.y; else aoL[(2 * g + 1 - KR) * 64] = vo.y;
+    for (int g0 = 0; g0 < KS / 2; g0++) {              // two fragments per 16-byte load
+      constexpr int dummy = 0; (void)dummy;
+      const int g = (g0 + ROT) % (KS / 2);
+      const d2 ve = ((const d2 *)p.fragE2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+      const d2 vo = ((const d2 *)p.fragO2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+      ae[2 * g] = ve.x; ae[2 * g + 1] = ve.y;
+      if (2 * g < KR) ao[2 * g] = vo.x; else aoL[(2 * g - KR) * 64] = vo.x;
+      if (2 * g + 1 < KR) ao[2 * g + 1] = vo.y; else aoL[(2 * g + 1 - KR) * 64] = vo.y;
+    }
+  };
+  switch ((blockIdx.x / nxcd) & 3u) {
+    case 0: load_frags(std::integral_constant<int, 0>{}); break;
+    case 1: load_frags(std::integral_constant<int, KS / 8>{}); break;
+    case 2: load_frags(std::integral_constant<int, KS / 4>{}); break;
+    default: load_frags(std::integral_constant<int, 3 * KS / 8>{}); break;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see sweep.hip
 #ifdef CHEB_STAMPS

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round profile of the headline bench: kernel trace + stats, then the counter passes (separate runs), then the
+# traffic record bench.py reads (profiles/traffic.json, tied to the kernel sources by their hash).
+# usage (on the GPU box): tools/profile_round.sh r02      -> writes gpurun_out/<tag>_*; copy what is to be judged into profiles/
+set -e
+tag=${1:-r02}
+R=$GRAFT_REPO_ROOT; out=gpurun_out
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_trace -o t -- python3 $R/bench.py --no-cpu-baseline > $R/$out/${tag}_bench_under_rocprof.json 2> $R/$out/${tag}_trace.log
+cd $R
+f=$(find $out/${tag}_trace -name '*kernel_trace.csv' | head -1)
+python3 tools/prof_summary.py $f > $out/${tag}_bench_kernel_summary.txt
+tools/pmc_passes.sh $out/${tag}_pmc 256 0 > $out/${tag}_pmc.log 2>&1
+python3 - <<PY
+import json, re, sys
+sys.path.insert(0, "$R")
+import bench
+tot = {}
+for line in open("$R/$out/${tag}_pmc/summary.txt"):
+    m = re.search(r"cheb_sweep_vec4_kernel<32, (\w+), (\w+)>.*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ mean=\s*([\d.]+)", line)
+    if m:
+        k = (m.group(1), m.group(2)); tot.setdefault(k, 0.0)
+        tot[k] += float(m.group(4)) * 1024.0 * (2.0 if m.group(3) == "FETCH_SIZE" else 1.0)   # KiB; FETCH_SIZE x2 on gfx950
+per = [tot.get(("false", "false"), 0), tot.get(("false", "true"), 0), tot.get(("true", "true"), 0)]
+rec = {"P": 256, "kernel": "cheb_sweep_vec4_kernel", "launches_per_matvec": 3, "hbm_bytes_per_matvec": sum(per), "hbm_bytes_per_launch": sum(per) / 3.0,
+       "per_direction_bytes": per, "csrc_sha256": bench.csrc_hash(),
+       "source": "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes (tools/pmc_passes.sh); FETCH_SIZE x2 gfx950 correction; KiB units"}
+json.dump(rec, open("$R/$out/${tag}_traffic.json", "w"), indent=1)
+print(rec)
+PY
+python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+cat $out/${tag}_bench.json
