@@ -238,4 +238,49 @@ PetscErrorCode StokesFunction_hip(SNES snes, Vec xG, Vec yG, void *void_ctx) {  
   PetscCall(VecHIPRestoreArrayWrite(yG, &y)); PetscCall(VecHIPRestoreArrayRead(xG, &x));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
+/* ---- preconditioning: what elliptic.C:181-185 and stokes.C:159-187 register ---------------------------------- */
+/* FormJacobian (elliptic.C:537-590) keeps its signature; instead of filling an AIJ matrix for PCILU it refreshes the
+ * device stencil, and the PC of the SNES's KSP becomes a PCSHELL whose apply is the fast-diagonalisation solve:
+ *   PCSetType(pc, PCSHELL); PCShellSetContext(pc, fdpc); PCShellSetApply(pc, PCApply_Elliptic_hip);      (for :184-185) */
+PetscErrorCode FormJacobian_hip(SNES snes, Vec w, Mat A, Mat P, void *void_pc) {
+  void *stream;
+  (void)snes; (void)w; (void)A; (void)P;
+  PetscFunctionBegin;
+  PetscCall(cheb_petsc_stream(&stream));
+  PetscCall(cheb_err(chebhip_fdpc_update((chebhip_fdpc *)void_pc, stream)));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+PetscErrorCode PCApply_Elliptic_hip(PC pc, Vec r, Vec z) {
+  chebhip_fdpc *fd; const PetscScalar *rr; PetscScalar *zz; void *stream;
+  PetscFunctionBegin;
+  PetscCall(PCShellGetContext(pc, &fd));
+  PetscCall(cheb_petsc_stream(&stream));
+  PetscCall(VecHIPGetArrayRead(r, &rr)); PetscCall(VecHIPGetArrayWrite(z, &zz));
+  PetscCall(cheb_err(chebhip_fdpc_apply(fd, rr, zz, stream)));
+  PetscCall(VecHIPRestoreArrayWrite(z, &zz)); PetscCall(VecHIPRestoreArrayRead(r, &rr));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+/* StokesPCSetUp0 / StokesPCApply0..3 (stokes.C:1160-1241, 1714-1817): PCShellSetSetUp / PCShellSetApply on the outer
+ * KSP's PC (stokes.C:159-187), context = a stokes_saddle made with stokes_saddle_create(c->op, ..) and
+ * stokes_saddle_set_type(-pc_saddle_type).  The inner KSPs of the reference (vel_, schur_, svel_ options) are
+ * replaced by the library's own solves: stokes_saddle_set_inner carries -vel_ksp_max_it / -schur_ksp_max_it. */
+PetscErrorCode StokesPCSetUp_hip(PC pc) {
+  stokes_saddle *s; void *stream;
+  PetscFunctionBegin;
+  PetscCall(PCShellGetContext(pc, &s));
+  PetscCall(cheb_petsc_stream(&stream));
+  PetscCall(cheb_err(stokes_saddle_setup(s, stream)));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+PetscErrorCode StokesPCApply_hip(PC pc, Vec x, Vec y) {
+  stokes_saddle *s; const PetscScalar *xx; PetscScalar *yy; void *stream;
+  PetscFunctionBegin;
+  PetscCall(PCShellGetContext(pc, &s));
+  PetscCall(cheb_petsc_stream(&stream));
+  PetscCall(VecHIPGetArrayRead(x, &xx)); PetscCall(VecHIPGetArrayWrite(y, &yy));
+  PetscCall(cheb_err(stokes_saddle_apply(s, xx, yy, stream)));
+  PetscCall(VecHIPRestoreArrayWrite(y, &yy)); PetscCall(VecHIPRestoreArrayRead(x, &xx));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 #endif /* device Vecs: the Stokes callbacks exist only for VECHIP vectors */
