@@ -210,6 +210,34 @@ static int cheb_geom(int rank, int tr, const int *dims, long *ntot, int *P, long
   return 0;
 }
 
+/* ---- genuine FFTW, if the box has it: libfftw3.so.3 is looked up at run time and used exactly as
+ * chebyshev.c does -- fftw_plan_guru_r2r with FFTW_ESTIMATE, batched strided REDFT00 x -> work (PRESERVE_INPUT,
+ * chebyshev.c:127) and RODFT00 on n-1 points work+os -> y+is (DESTROY_INPUT, :128-129), fftw_execute_r2r (:157,181).
+ * mode ORC_FFTW = 2.  Not available in the build image (no FFTW): this path is exercised only where the library
+ * exists; everything else about the call (passes 2 and 4) is the restatement below. */
+#include <dlfcn.h>
+typedef struct { int n, is, os; } orc_fftw_iodim;
+static struct {
+  int tried, ok;
+  void *(*plan_guru_r2r)(int, const orc_fftw_iodim *, int, const orc_fftw_iodim *, double *, double *, const int *, unsigned);
+  void (*execute_r2r)(void *, double *, double *);
+  void (*destroy_plan)(void *);
+} g_fftw;
+int orc_fftw_available(void) {
+  if (!g_fftw.tried) {
+    g_fftw.tried = 1;
+    void *L = dlopen("libfftw3.so.3", RTLD_NOW | RTLD_LOCAL);
+    if (!L) L = dlopen("libfftw3.so", RTLD_NOW | RTLD_LOCAL);
+    if (L) {
+      *(void **)&g_fftw.plan_guru_r2r = dlsym(L, "fftw_plan_guru_r2r");
+      *(void **)&g_fftw.execute_r2r = dlsym(L, "fftw_execute_r2r");
+      *(void **)&g_fftw.destroy_plan = dlsym(L, "fftw_destroy_plan");
+      g_fftw.ok = g_fftw.plan_guru_r2r && g_fftw.execute_r2r && g_fftw.destroy_plan;
+    }
+  }
+  return g_fftw.ok;
+}
+
 int orc_cheb_mult(int rank, int tr, const int *dims, const double *x, double *y, int mode, int nthreads) {
   long ntot, inner, outer; int P;
   int err = cheb_geom(rank, tr, dims, &ntot, &P, &inner, &outer);
@@ -218,7 +246,20 @@ int orc_cheb_mult(int rank, int tr, const int *dims, const double *x, double *y,
   const long ts = inner;                                  /* tdim.is         */
   const long nlines = outer * inner;
   double *work = (double *)malloc(sizeof(double) * (size_t)ntot); /* chebyshev.c:102 */
-  xplan *p = xplan_make(n, mode);
+  void *fp1 = NULL, *fp2 = NULL;
+  if (mode == 2) {                                        /* the reference's two plans, chebyshev.c:124-129 */
+    if (!orc_fftw_available() || P < 3) { free(work); return 7; }
+    orc_fftw_iodim tdim = { P, (int)ts, (int)ts };
+    orc_fftw_iodim batch[2] = { { (int)outer, (int)(P * inner), (int)(P * inner) }, { (int)inner, 1, 1 } };
+    const int redft00 = 3, rodft00 = 7;                   /* fftw3.h: FFTW_REDFT00, FFTW_RODFT00 */
+    const unsigned estimate = 1u << 6, preserve = 1u << 4, destroy = 1u << 0;
+    fp1 = g_fftw.plan_guru_r2r(1, &tdim, 2, batch, (double *)x, work, &redft00, estimate | preserve);
+    tdim.n = P - 2;
+    fp2 = g_fftw.plan_guru_r2r(1, &tdim, 2, batch, work + ts, y + ts, &rodft00, estimate | destroy);
+    if (!fp1 || !fp2) { if (fp1) g_fftw.destroy_plan(fp1); if (fp2) g_fftw.destroy_plan(fp2); free(work); return 7; }
+    nthreads = 1;                                         /* the reference is serial */
+  }
+  xplan *p = xplan_make(n, mode == 2 ? 1 : mode);
   if (nthreads < 1) nthreads = 1;
   const double N = (double)n;
   const double pin = ORC_PI / N;                          /* chebyshev.c:183 */
@@ -232,9 +273,14 @@ int orc_cheb_mult(int rank, int tr, const int *dims, const double *x, double *y,
 #pragma omp for schedule(static)
 #endif
     for (long l = 0; l < nlines; l++) {
+      if (fp1) continue;
       const long off = (l / inner) * P * inner + (l % inner);
       redft00_line(p, &s, x + off, ts, work + off, ts);
     }
+#ifdef _OPENMP
+#pragma omp single
+#endif
+    { if (fp1) g_fftw.execute_r2r(fp1, (double *)x, work); }   /* chebyshev.c:157 */
     /* pass 2: coefficient scaling and endpoint sums (chebyshev.c:162-179) */
 #ifdef _OPENMP
 #pragma omp for schedule(static)
@@ -260,9 +306,14 @@ int orc_cheb_mult(int rank, int tr, const int *dims, const double *x, double *y,
 #pragma omp for schedule(static)
 #endif
     for (long l = 0; l < nlines; l++) {
+      if (fp2) continue;
       const long off = (l / inner) * P * inner + (l % inner);
       rodft00_line(p, &s, work + off + ts, ts, y + off + ts, ts);
     }
+#ifdef _OPENMP
+#pragma omp single
+#endif
+    { if (fp2) g_fftw.execute_r2r(fp2, work + ts, y + ts); }   /* chebyshev.c:181 */
     /* pass 4: metric scaling (chebyshev.c:186-193) */
 #ifdef _OPENMP
 #pragma omp for schedule(static)
@@ -279,6 +330,8 @@ int orc_cheb_mult(int rank, int tr, const int *dims, const double *x, double *y,
     xscratch_free(&s);
   }
   xplan_free(p);
+  if (fp1) g_fftw.destroy_plan(fp1);
+  if (fp2) g_fftw.destroy_plan(fp2);
   free(work);
   return 0;
 }

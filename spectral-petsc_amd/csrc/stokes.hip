@@ -173,6 +173,7 @@ __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict
 // (scatterLV/VG, VecAXPY stokes.C:513-517,750-756).  Any of yL / gp0 / p2 may be null.
 template <int D>
 __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const double *__restrict__ yL,
+                         const double *__restrict__ yL1, const double *__restrict__ yL2,
                          const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
                          const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out) {
   GS_LOOP(l, N) {
@@ -182,7 +183,13 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
     if (yL || gp0) {
       double v[D];
 #pragma unroll
-      for (int k = 0; k < D; k++) v[k] = yL ? yL[k * N + l] : 0.0;
+      for (int k = 0; k < D; k++) {
+        // yL (+ yL1 + yL2): the terms -DV[j] V[j] of stokes.C:668-671 / :737-740, summed in the order j = 0, 1, 2
+        double t = yL ? yL[k * N + l] : 0.0;
+        if (yL1) t = t + yL1[k * N + l];
+        if (yL2) t = t + yL2[k * N + l];
+        v[k] = t;
+      }
       if (gp0) {
         const double g0 = gp0[l], g1 = gp1[l], g2 = (D == 3) ? gp2[l] : 0.0;
         if (yL) { v[0] += 1.0 * g0; v[1] += 1.0 * g1; if (D == 3) v[D - 1] += 1.0 * g2; }
@@ -206,6 +213,7 @@ struct stokes_op {
   std::vector<unsigned> innerP, ncolsP, innerV, ncolsV;      // DP[i] / DV[i] geometry
   int *ixL = nullptr;
   double *xL = nullptr, *yL = nullptr;                       // workV[0], workV[1]
+  double *yLx[3] = {nullptr, nullptr, nullptr};              // serial handles: terms 1, 2 of the stress divergence (summed in the final scatter)
   double *V[3] = {nullptr, nullptr, nullptr};                // workV[2..]
   double *strain[3] = {nullptr, nullptr, nullptr};           // c->strain[]
   double *eta = nullptr, *deta = nullptr;
@@ -239,7 +247,7 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
-                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force};
+                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2]};
   for (double *p : all) if (p) (void)hipFree(p);
   if (op->sv0) (void)hipFree(op->sv0);
   if (op->sv1) (void)hipFree(op->sv1);
@@ -310,6 +318,7 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
   }
   const size_t nd = (size_t)N * d;
   OPRC(st_alloc(&op->xL, nd)); OPRC(st_alloc(&op->yL, nd));
+  if (!slab) for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
   for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
   OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
   OPRC(st_alloc(&op->pL, (size_t)N)); OPRC(st_alloc(&op->p2, (size_t)N));
@@ -431,20 +440,51 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
   ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL);
 }
 
-// yL = -sum_j DV[j] V[j]   (stokes.C:668-671, 737-740)
-static int st_div_stress(stokes_op *op, hipStream_t st) {
-  for (int j = 0; j < op->d; j++) {
-    int rc = sweep_plain(op, true, j, op->V[j], op->yL, j == 0 ? OUT_STORE : OUT_ACC, op->yL, -1.0, st);
-    if (rc) return rc;
+// d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
+// kernels allow it (sweep_launch_multi), else one launch each.  Serial handles only.
+static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st) {
+  const DiffMat *m[3]; SweepParams sp[3];
+  int n = 0;
+  for (int k = k0; k < op->d; k++, n++) {
+    sp[n] = SweepParams{};
+    sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
+    sp[n].in0 = x[k]; sp[n].in_mode = IN_PLAIN; sp[n].out = y[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = alpha;
+    m[n] = &op->mats[op->dims[k]];
   }
+  SHIPCHK(sweep_launch_multi(n, m, sp, st));
   return 0;
+}
+
+// yL (+ yLx[1] + yLx[2]) = -sum_j DV[j] V[j]   (stokes.C:668-671, 737-740): one launch, the sum is taken by the final scatter
+// in the order j = 0, 1, 2; slab mode keeps the accumulating chain (the sweep along dimension 0 is the driver's)
+static int st_div_stress(stokes_op *op, hipStream_t st) {
+  if (op->slab) {
+    for (int j = 0; j < op->d; j++) {
+      int rc = sweep_plain(op, true, j, op->V[j], op->yL, j == 0 ? OUT_STORE : OUT_ACC, op->yL, -1.0, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const double *x[3] = {op->V[0], op->V[1], op->V[2]};
+  double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
+  return sweeps_multi(op, true, 0, x, y, -1.0, st);
+}
+
+// V[j] = DV[j] xL (stokes.C:639) / strain[j] = DV[j] xL (:701)
+static int st_gradient(stokes_op *op, double *const *out, hipStream_t st) {
+  if (op->slab) {
+    for (int j = 0; j < op->d; j++) { int rc = sweep_plain(op, true, j, op->xL, out[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
+    return 0;
+  }
+  const double *x[3] = {op->xL, op->xL, op->xL};
+  return sweeps_multi(op, true, 0, x, out, 1.0, st);
 }
 
 // viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]; div (may be null)
 // receives the trace of the gradient = StokesDivergence of the same xL
 static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st) {
   const int d = op->d;
-  for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->V[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :639
+  { int rc = st_gradient(op, op->V, st); if (rc) return rc; }                                                                   // :639
 #define NODE_VV(D_, DETA_) hipLaunchKernelGGL((k_st_node_vv<D_, DETA_>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
     (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
   if (d == 2) { if (op->deta_nonzero) NODE_VV(2, true); else NODE_VV(2, false); }
@@ -490,8 +530,12 @@ static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
     // planes of pL it would have filled only feed DP[1], DP[2] on those planes, which the final scatter never reads.
     int rc = op->dim0(op->dim0_ctx, 1, 1, op->pL, nullptr, 1.0, op->gp[0], st); if (rc) return rc;
   }
-  for (int i = op->slab ? 1 : 0; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
-  return 0;
+  if (op->slab) {
+    for (int i = 1; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
+    return 0;
+  }
+  const double *x[3] = {op->pL, op->pL, op->pL};
+  return sweeps_multi(op, false, 0, x, op->gp, 1.0, st);
 }
 
 // pressure chain on the second stream, between the gather (already enqueued on st) and the final scatter
@@ -521,7 +565,7 @@ extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, v
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
   int rc = st_viscous_jacobian(op, nullptr, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, CDP(op->yL), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out);
+  ST_OUT(d, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -533,7 +577,7 @@ extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, 
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
   int rc = st_divergence(op, st); if (rc) return rc;
-  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout);
+  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -545,7 +589,7 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
   const int d = op->d;
   st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
   int rc = st_pressure_gradient(op, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout);
+  ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -561,7 +605,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   int rc = st_pressure_gradient_forked(op, st); if (rc) return rc;                                                               // MatVP (:512)
   if ((rc = st_viscous_jacobian(op, op->p2, st))) return rc;
   if ((rc = st_join(op, st))) return rc;
-  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(nullptr), yG);
+  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(nullptr), yG);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -574,13 +618,13 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
   { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                           // :747
-  for (int j = 0; j < d; j++) { int rc = sweep_plain(op, true, j, op->xL, op->strain[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }   // :701
+  { int rc = st_gradient(op, op->strain, st); if (rc) return rc; }                                                                // :701
   ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
        op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
   op->deta_nonzero = (op->rh_kind == 1);
   int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
   if ((rc = st_join(op, st))) return rc;
-  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(op->force), yG);   // :750-756
+  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(op->force), yG);   // :750-756
   SHIPCHK(hipGetLastError());
   return 0;
 }

@@ -101,6 +101,9 @@ void sweep_note_launch();
 // 16-byte-access specialisation (sweep_vec.hip); used by sweep_launch when eligible
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *jobs, hipStream_t stream, bool *done);
+// n independent sweeps (plain in, STORE out): one launch when they qualify (sweep_vec.hip), else n launches
+hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream);
 
 long sweep_launch_count();
 // compute units of the CURRENT device (cached per device id); 0 on error with *err set

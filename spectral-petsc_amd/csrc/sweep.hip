@@ -508,4 +508,26 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   }
 }
 
+static void sweep_fill(const DiffMat &m, SweepParams &p) {
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink;
+  p.sym = m.sym; p.ablate = g_ablate; p.variant = sweep_get_variant(); p.longDT = m.longDT; p.longD = m.longD;
+}
+
+hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {
+  static int nomulti = -1;
+  if (nomulti < 0) { const char *e = getenv("CHEBHIP_NOMULTI"); nomulti = (e && e[0] == '1') ? 1 : 0; }
+  if (n >= 2 && n <= 3 && !nomulti) {
+    SweepParams jobs[3];
+    bool ok = true;
+    for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); ok = ok && m[j]->KS != 0; }
+    if (ok) {
+      bool done = false;
+      hipError_t e = sweep_vec_launch_multi(n, m, jobs, stream, &done);
+      if (e != hipSuccess || done) return e;
+    }
+  }
+  for (int j = 0; j < n; j++) { hipError_t e = sweep_launch(*m[j], p[j], stream); if (e != hipSuccess) return e; }
+  return hipSuccess;
+}
+
 }  // namespace chebhip

@@ -34,8 +34,19 @@ __device__ __forceinline__ double swap1(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// LDS doubles of the 16-byte kernels for a (KS, tiling) pair: two (E, O) tile images, double-buffered, plus the
+// LDS-resident matrix fragments at KS = 32
 template <int KS, bool JFAST>
-__global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p) {
+constexpr int vec_lds_doubles() {
+  constexpr int MTP = KS / 4, NG = 8 / MTP, HP = 4 * KS, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB, LDJ = HP + 2;
+  constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
+  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
+  return 4 * LDS_ELEMS + 8 * NFL * 64;
+}
+
+// Body of cheb_sweep_vec_kernel: workgroup BID of NBLK (the launch's, or those of one job of a multi-job launch)
+template <int KS, bool JFAST>
+__device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
   constexpr int HP = 4 * KS;
@@ -53,7 +64,6 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
   // left over by the tile images instead (32 KiB), which frees 2*NFL VGPRs for a deeper operand prefetch.
   constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
   constexpr int KR = KS - NFL;                       // odd-half fragments kept in registers
-  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mt = w % MTP, ng = w / MTP;
@@ -74,11 +84,11 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see sweep.hip
 
   const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
-  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 nxcd = (NBLK % 8 == 0) ? 8u : 1u;
   const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
-  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_lo = (BID % nxcd) * t_per;
   const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
-  const u32 t_step = gridDim.x / nxcd;
+  const u32 t_step = NBLK / nxcd;
 
   // loader slots: COLFAST (line pair 2*ld_a, j-pair ld_b + s*QSTEP); JFAST (points 2*ld_a, 2*ld_a+1 of line ld_b + s*QSTEP)
   const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #ifdef CHEB_STAMPS
   STAMP(st_begin);
 #endif
-  u32 tile = t_lo + blockIdx.x / nxcd;
+  u32 tile = t_lo + BID / nxcd;
   if (tile < t_hi) {
 #pragma unroll 1
     for (int ch = 0; ch < NSUB; ch++) { issue_loads(tile, ch, rjA, rmA); park_chunk(0, ch, rjA, rmA); }
@@ -320,11 +330,17 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #ifdef CHEB_STAMPS
   STAMP(st_end);
   if (lane == 0 && p.in4) {
-    unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)blockIdx.x * 8 + w) * 8;
+    unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 8;
     dbg[0] = st_pre; dbg[1] = st_chain; dbg[2] = st_post; dbg[3] = st_bar;
     dbg[4] = st_loop - st_begin; dbg[5] = st_end - st_loop; dbg[6] = st_begin; dbg[7] = st_end;
   }
 #endif
+}
+
+template <int KS, bool JFAST>
+__global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p) {
+  __shared__ double smem[vec_lds_doubles<KS, JFAST>()];
+  vec1_body<KS, JFAST>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Diagnostic builds only (make diag, tools/stamp_probe3.py): in-kernel cycle stamps kept in SGPRs
@@ -623,7 +639,7 @@ static hipError_t launch_v3(const SweepParams &p, unsigned grid, hipStream_t str
 //   * the lane exchange that makes 16-byte pieces is one DPP broadcast + one select per dword;
 //   * the centro-symmetry sign rides in the scalar factor of the mirror row.
 template <int KS, bool JFAST, bool ACC>
-__global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams p) {
+__device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
   constexpr int HP = 4 * KS;
@@ -642,7 +658,6 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
   // part of an offset T_INVALID, and their sum must not wrap back into range
   constexpr u32 INVALID = 0x80000000u, T_INVALID = 0x40000000u;
   static_assert(KS >= 16 && CH >= 1, "v4 needs two sub-tiles per tile");
-  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
 
 #ifdef CHEB_STAMPS
   unsigned long long st_seg[5] = {0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0, st_loop = 0;   // diagnostic build only: see v3
@@ -665,11 +680,11 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
   double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
 
   const u32 tpo = JFAST ? 1u : (qmax + NT - 1) / NT;
-  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
+  const u32 nxcd = (NBLK % 8 == 0) ? 8u : 1u;
   const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
-  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
+  const u32 t_lo = (BID % nxcd) * t_per;
   const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
-  const u32 t_step = gridDim.x / nxcd;
+  const u32 t_step = NBLK / nxcd;
 
   // loader slots as in v1: COLFAST (line pair 2*ld_a, point pair ld_b + s*QSTEP); JFAST (points 2*ld_a, 2*ld_a+1 of
   // line ld_b + s*QSTEP).  Per-lane byte offsets of slot 0 (point / mirror); a slot adds a scalar
@@ -758,7 +773,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
     for (int rp = 0; rp < 2; rp++) { ah[rp] = ld16(r_acc, c_hi[rp] + t0); al[rp] = ld16(r_acc, c_lo[rp] + t0); }
   };
 
-  u32 tile = t_lo + blockIdx.x / nxcd;
+  u32 tile = t_lo + BID / nxcd;
   if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
   // the first tile's lines are requested BEFORE the matrix fragments: one memory round trip instead of two
   issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
@@ -778,7 +793,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
       if (2 * g + 1 < KR) ao[2 * g + 1] = vo.y; else aoL[(2 * g + 1 - KR) * 64] = vo.y;
     }
   };
-  switch ((blockIdx.x / nxcd) & 3u) {
+  switch ((BID / nxcd) & 3u) {
     case 0: load_frags(std::integral_constant<int, 0>{}); break;
     case 1: load_frags(std::integral_constant<int, KS / 8>{}); break;
     case 2: load_frags(std::integral_constant<int, KS / 4>{}); break;
@@ -907,12 +922,42 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
   {
     unsigned long long st_end; STAMP3_MARK(st_end);
     if (lane == 0 && p.in4) {
-      unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)blockIdx.x * 8 + w) * 8;
+      unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 8;
       dbg[0] = st_seg[0]; dbg[1] = st_seg[1]; dbg[2] = st_seg[2]; dbg[3] = st_seg[3]; dbg[4] = st_seg[4];
       dbg[5] = st_loop - st_begin; dbg[6] = st_wait - st_begin; dbg[7] = st_park - st_begin; (void)st_end;
     }
   }
 #endif
+}
+
+template <int KS, bool JFAST, bool ACC>
+__global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams p) {
+  __shared__ double smem[vec_lds_doubles<KS, JFAST>()];
+  vec4_body<KS, JFAST, ACC>(p, smem, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-job launch: up to MULTI_MAX independent plain STORE sweeps with the same KS in ONE launch.  The workgroups
+// [bstart[j], bstart[j+1]) run job j with the single-launch code; a job's share is a multiple of 8 workgroups so
+// that its XCD-aware tile walk holds.  Small grids are bound by the fixed cost of a launch (~5 us at 64^3), not
+// by its work: the d gradient sweeps of a Stokes callback, its d divergence sweeps and its d pressure-gradient
+// sweeps are one launch each this way (stokes.hip).
+constexpr int MULTI_MAX = 3;
+struct MultiParams { int njobs; unsigned bstart[MULTI_MAX + 1]; SweepParams job[MULTI_MAX]; };
+
+template <int KS>
+__global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams mp) {
+  constexpr int LDS = vec_lds_doubles<KS, true>() > vec_lds_doubles<KS, false>() ? vec_lds_doubles<KS, true>() : vec_lds_doubles<KS, false>();
+  __shared__ double smem[LDS];
+  int j = 0;
+  while (j + 1 < mp.njobs && blockIdx.x >= mp.bstart[j + 1]) j++;
+  const SweepParams &p = mp.job[j];
+  const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
+  if (p.inner < 16) {
+    if constexpr (KS >= 16) vec4_body<KS, true, false>(p, smem, bid, nblk); else vec1_body<KS, true>(p, smem, bid, nblk);
+  } else {
+    if constexpr (KS >= 16) vec4_body<KS, false, false>(p, smem, bid, nblk); else vec1_body<KS, false>(p, smem, bid, nblk);
+  }
 }
 
 template <int KS, bool JFAST>
@@ -923,10 +968,11 @@ static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t str
   return hipGetLastError();
 }
 
+// Geometry defaults, tile count and (v4) the byte sizes of the buffer descriptors.  Returns 4 / 3 / 1: which kernel
+// generation can run the launch, 0: none (per-array geometry on short lines).
 template <int KS, bool JFAST>
-static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
+static int prepare_v(SweepParams &p) {
   constexpr int MTP = KS / 4, NG = 8 / MTP, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB;
-  SweepParams p = p0;
   const bool custom = p.qmax != 0 || p.in_os != 0;         // per-array geometry given by the caller (v3 / v4 only)
   if (JFAST) {
     if (!p.in_os) p.in_os = (unsigned)p.P;
@@ -941,10 +987,6 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
     if (!p.out_os) { p.out_os = (unsigned)p.P * p.inner; p.out_rs = p.inner; }
     p.ntiles = p.nouter * ((p.qmax + NT - 1) / NT);
   }
-  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
-  if (cu_err != hipSuccess) return cu_err;
-  const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
-  if (grid == 0) return hipSuccess;
   if constexpr (KS >= 16) {
     static int v1 = -1;
     if (v1 < 0) { const char *e = getenv("CHEBHIP_VEC_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
@@ -959,12 +1001,27 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
       const bool fits = bi < 0x38000000ull && ba < 0x38000000ull && bo < 0x38000000ull;   // < 1 GiB minus slack: see T_INVALID
       if (fits && !(p.variant & 8)) {
         p.in_bytes = (unsigned)bi; p.acc_bytes = (unsigned)ba; p.out_bytes = (unsigned)bo;
-        return launch_v4<KS, JFAST>(p, grid, stream);
+        return 4;
       }
-      return launch_v3<KS, JFAST>(p, grid, stream);
+      return 3;
     }
   }
-  if (custom) return hipErrorInvalidValue;                 // per-array geometry exists in the v3 / v4 kernels only
+  return custom ? 0 : 1;                                   // per-array geometry exists in the v3 / v4 kernels only
+}
+
+template <int KS, bool JFAST>
+static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
+  SweepParams p = p0;
+  const int gen = prepare_v<KS, JFAST>(p);
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (cu_err != hipSuccess) return cu_err;
+  const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
+  if (grid == 0) return hipSuccess;
+  if constexpr (KS >= 16) {
+    if (gen == 4) return launch_v4<KS, JFAST>(p, grid, stream);
+    if (gen == 3) return launch_v3<KS, JFAST>(p, grid, stream);
+  }
+  if (gen == 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
@@ -993,6 +1050,47 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
     case 16: return jfast ? launch_v<16, true>(p, stream) : launch_v<16, false>(p, stream);
     case 32: return jfast ? launch_v<32, true>(p, stream) : launch_v<32, false>(p, stream);
     default: return hipErrorInvalidValue;
+  }
+}
+
+// n <= MULTI_MAX independent sweeps as ONE launch when they qualify (plain in, STORE out, 16-byte kernel, same KS);
+// *done = false: the caller launches them one by one
+template <int KS>
+static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done) {
+  MultiParams mp = {};
+  mp.njobs = n;
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (cu_err != hipSuccess) return cu_err;
+  unsigned b = 0;
+  for (int j = 0; j < n; j++) {
+    SweepParams &p = jobs[j];
+    const bool jfast = p.inner < 16;
+    const int gen = jfast ? prepare_v<KS, true>(p) : prepare_v<KS, false>(p);
+    if (gen != (KS >= 16 ? 4 : 1)) return hipSuccess;      // not for this launch: done stays false
+    unsigned g = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
+    g = (g + 7u) & ~7u;                                     // whole XCD rounds: the surplus workgroups exit at once
+    mp.bstart[j] = b; b += g; mp.job[j] = p;
+  }
+  mp.bstart[n] = b;
+  if (b == 0) { *done = true; return hipSuccess; }
+  hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
+  sweep_note_launch();
+  *done = true;
+  return hipGetLastError();
+}
+
+hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *jobs, hipStream_t stream, bool *done) {
+  *done = false;
+  if (n < 1 || n > MULTI_MAX) return hipSuccess;
+  for (int j = 0; j < n; j++) {
+    if (m[j]->KS != m[0]->KS || jobs[j].out_mode != OUT_STORE || !sweep_vec_eligible(*m[j], jobs[j]) || jobs[j].ablate) return hipSuccess;
+  }
+  switch (m[0]->KS) {
+    case 4: return launch_multi_t<4>(n, jobs, stream, done);
+    case 8: return launch_multi_t<8>(n, jobs, stream, done);
+    case 16: return launch_multi_t<16>(n, jobs, stream, done);
+    case 32: return launch_multi_t<32>(n, jobs, stream, done);
+    default: return hipSuccess;
   }
 }
 

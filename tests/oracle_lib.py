@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB = os.path.join(_ORACLE_DIR, "liboracle.so")
 
-DIRECT, FAST = 0, 1
+DIRECT, FAST, FFTW = 0, 1, 2      # FFTW: genuine libfftw3 through dlopen, where the box has it (fftw_available())
 
 
 def build(force=False):
@@ -44,6 +44,10 @@ def lib():
         _lib.orc_elliptic_exact.argtypes = [C.c_int, ip, C.c_int, C.c_double, C.c_double, C.c_double,
                                             dp, dp, dp]
     return _lib
+
+
+def fftw_available():
+    return bool(lib().orc_fftw_available())
 
 
 def _dp(a):
