@@ -46,7 +46,7 @@ extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 // Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
 extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
-// Undocumented profiling hook: schedule switches of the 16-byte kernels (4 = dense accumulator W, 8 = flat-address kernel v3 instead of v4)
+// Undocumented profiling hook: schedule switches of the 16-byte kernels (4 = dense accumulator W, 8 = flat-address kernel v3 instead of v4, 16 = fused.hip instead of fused4.hip)
 extern "C" void chebhip_debug_variant(int bits) { sweep_set_variant(bits); }
 // Diagnostic builds (-DCHEB_STAMPS) only: device buffer of 256*8*4 uint64 receiving per-wave phase cycle sums.
 static const double *g_stamp_buf = nullptr;
@@ -351,7 +351,7 @@ __global__ void k_gather_coeff(long N, const int *__restrict__ ixL, const double
 __global__ void k_cprod(long N, const double *__restrict__ eta, const double *__restrict__ deta, const double *__restrict__ du,
                         double2 *__restrict__ ec) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x)
-    ec[i] = make_double2(eta[i], deta[i] * du[i]);
+    ec[i] = make_double2(eta[i], 0.5 * (deta[i] * du[i]));   // c / 2: the fused kernels hold 2 u (parity sums)
 }
 
 // f = eta * g (+ deta * u * du0): the pointwise flux of elliptic.C:319-323 / :511 as a pass of its own (slab mode,
@@ -412,7 +412,7 @@ struct ell_op {
   ell_dim0_fn dim0 = nullptr;
   void *dim0_ctx = nullptr;
   bool has_long = false;                // some extent > 256: every sweep goes through the unfused path (cheb_sweep_long_kernel)
-  std::vector<double *> cprod;          // pairs {eta, deta * gradu[k]} (2N doubles): what the Jacobian apply reads, refreshed when the state changes
+  std::vector<double *> cprod;          // pairs {eta, deta * gradu[k] / 2} (2N doubles): what the Jacobian apply reads, refreshed when the state changes
   bool cdirty = true;
   double *eta = nullptr, *deta = nullptr, *dirloc = nullptr;
   CoeffMode mode = COEFF_UNIT;
@@ -643,6 +643,76 @@ static bool use_unfused() {
   return v == 1;
 }
 
+// ---- the straight-line fused kernel (fused4.hip): d = 2, 3, every extent even and 66..256, no slab ----
+static bool ell_fused4_ok(ell_op *op) {
+  if (op->slab || op->has_long || (op->d != 2 && op->d != 3) || op->G == 0) return false;
+  static int legacy = -1;
+  if (legacy < 0) { const char *e = getenv("CHEBHIP_FUSED_LEGACY"); legacy = (e && e[0] == '1') ? 1 : 0; }
+  if (legacy || (sweep_get_variant() & 16)) return false;
+  for (int k = 0; k < op->d; k++) if (!fused4_eligible(op->mats[op->dims[k]])) return false;
+  return (size_t)op->N * 16 < 0x38000000ull;
+}
+
+// Jacobian apply, direction k: V (+)= -D_k( eta D_k U + c_k U ) on the interior lines.  U and V in the interior layout,
+// the coefficient pairs in the local one (entered at the first interior line), W in its padded interior layout.
+static int ell_fused4_jacobian(ell_op *op, int k, const double *U, double *V, hipStream_t st) {
+  const int d = op->d;
+  const unsigned n1 = d == 3 ? op->dims[1] : 0, nlast = op->dims[d - 1];
+  const unsigned nl = nlast - 2, nm = d == 3 ? n1 - 2 : 1u, n0i = op->dims[0] - 2, wp = op->wpad;
+  const unsigned s0 = d == 3 ? n1 * nlast : nlast;                       // local stride of dimension 0
+  Fused4Params q = {};
+  q.alpha = -1.0;                                                        // VecAXPY(w0,-1,.) elliptic.C:333
+  q.in = U; q.in_bytes = (unsigned)((size_t)op->G * 8);
+  size_t shift;                                                          // first interior line in the local layout
+  const size_t wbytes = (size_t)(d == 3 ? n0i * nm : n0i) * wp * 8;
+  const bool last = k == d - 1;
+  if (!last) {
+    const bool first = d == 3 && k == 0;
+    q.qmax = nl;
+    if (d == 2) { q.nouter = 1; q.gi = {0, 1, nl}; q.gc = {0, 1, nlast}; q.go = {0, 1, wp}; shift = 1; }
+    else if (first) { q.nouter = nm; q.gi = {nl, 1, nm * nl}; q.gc = {nlast, 1, s0}; q.go = {wp, 1, nm * wp}; shift = nlast + 1; }
+    else { q.nouter = n0i; q.gi = {nm * nl, 1, nl}; q.gc = {s0, 1, nlast}; q.go = {nm * wp, 1, wp}; shift = s0 + 1; }
+    q.ga = q.go; q.out = op->W; q.out_bytes = (unsigned)wbytes;
+    if (k > 0) { q.acc = op->W; q.acc_bytes = (unsigned)wbytes; }
+  } else {
+    q.nouter = d == 3 ? n0i : 1u; q.qmax = d == 3 ? nm : n0i;
+    q.gi = {nm * nl, nl, 1}; q.gc = {s0, nlast, 1}; q.ga = {nm * wp, wp, 1}; q.go = q.gi;
+    shift = d == 3 ? s0 + nlast : nlast;
+    q.acc = op->W; q.acc_bytes = (unsigned)wbytes; q.out = V; q.out_bytes = (unsigned)((size_t)op->G * 8);
+  }
+  q.coef = (const void *)(op->cprod[k] + 2 * shift); q.coef_bytes = (unsigned)(((size_t)op->N - shift) * 16);
+  HIPCHK(fused4_launch(op->mats[op->dims[k]], q, last, true, k > 0, false, st));
+  return 0;
+}
+
+// FormFunction, direction k (elliptic.C:497-528): gradu[k] = D_k w0 is stored on the way, W (+)= -D_k( eta gradu[k] ) in
+// the local layout; the last direction writes rhs = scatter(W) - b in the interior layout.
+static int ell_fused4_function(ell_op *op, int k, const double *b, double *rhs, hipStream_t st) {
+  const int d = op->d;
+  const unsigned n0 = op->dims[0], n1 = d == 3 ? op->dims[1] : 0, nlast = op->dims[d - 1];
+  const unsigned nl = nlast - 2, nm = d == 3 ? n1 - 2 : 1u, s0 = d == 3 ? n1 * nlast : nlast;
+  const unsigned nbytes = (unsigned)((size_t)op->N * 8), gbytes = (unsigned)((size_t)op->G * 8);
+  Fused4Params q = {};
+  q.alpha = -1.0;
+  q.in = op->w0; q.in_bytes = nbytes; q.coef = op->eta; q.coef_bytes = nbytes; q.gout = op->gradu[k]; q.gout_bytes = nbytes;
+  const bool last = k == d - 1;
+  if (!last) {
+    if (k == 0) { q.nouter = 1; q.qmax = s0; q.gi = {0, 1, s0}; }         // lines along dimension 0: every (i1, i2)
+    else { q.nouter = n0; q.qmax = nlast; q.gi = {s0, 1, nlast}; }
+    q.gc = q.ga = q.go = q.gi;
+    q.out = op->W; q.out_bytes = nbytes;
+    if (k > 0) { q.acc = op->W; q.acc_bytes = nbytes; }
+  } else {
+    q.nouter = d == 3 ? n0 : 1u; q.qmax = d == 3 ? n1 : n0;
+    q.gi = {s0, nlast, 1}; q.gc = q.ga = q.gi;
+    q.go = {nm * nl, nl, 1};
+    q.acc = op->W; q.acc_bytes = nbytes; q.out = rhs; q.out_bytes = gbytes;
+    q.sub = b; q.sub_bytes = b ? gbytes : 0u;
+  }
+  HIPCHK(fused4_launch(op->mats[op->dims[k]], q, last, false, k > 0, last, st));
+  return 0;
+}
+
 // Where the k-th term -D_k f_k of the divergence goes: W = -t0; W -= t_k; out_global = scatter(W - t_{d-1}).
 static void ell_out_chain(ell_op *op, int k, double *out_global, SweepParams *sp) {
   const int d = op->d;
@@ -820,6 +890,10 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
                          (const double *)op->gradu[k], (double2 *)op->cprod[k]);
     op->cdirty = false;
   }
+  if (op->wpad && ell_fused4_ok(op)) {
+    for (int k = 0; k < op->d; k++) { int rc = ell_fused4_jacobian(op, k, U, V, st); if (rc) return rc; }
+    return 0;
+  }
   for (int k = 0; k < op->d; k++) {
     SweepParams sp = {};
     sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
@@ -880,6 +954,9 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     if (op->G == 0) return 0;
     rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);             // w = eta*gradu (:511), :521-528
     if (rc) return rc;
+  } else if (ell_fused4_ok(op)) {
+    for (int k = 0; k < d; k++) if ((rc = ell_fused4_function(op, k, b, rhs, st))) return rc;   // includes rhs -= b (:530)
+    return 0;
   } else {
     // fused: gradu[k] = D_k w0 is stored on the way (:497-499), w_k = eta gradu[k] (:511) feeds the
     // divergence without leaving the chip (:521-528)

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
             // u is on chip: the parity-split tile holds e = u_i + u_{n-i} and o = u_i - u_{n-i}
             const int uidx = JFAST ? (nb + 4 * r + kq) * LDJ + i : i * NT + ((nb + l16) ^ ((i & 1) << 4));
             const double ue = inE[uidx], uo = inO[uidx];
-            const double ui = (im != i) ? 0.5 * (ue + uo) : ue, um = 0.5 * (ue - uo);
+            const double ui = (im != i) ? ue + uo : 2.0 * ue, um = ue - uo;   // 2 u: in2 carries c / 2
             fi = fi + cc[2 * r] * ui;
             fm = fm + cc[2 * r + 1] * um;
           }

@@ -48,7 +48,7 @@ struct SweepParams {
   unsigned ntiles;
   int sym;            // mirror rows are a - b (centro-symmetric matrix) instead of b - a
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
-  int coef_mode;      // fused launches only: CoefMode; COEF_ETA: eta = in1; COEF_FULL: in2 = pairs {eta, c = deta * du0} (local layout)
+  int coef_mode;      // fused launches only: CoefMode; COEF_ETA: eta = in1; COEF_FULL: in2 = pairs {eta, c / 2}, c = deta * du0 (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
   // Per-array geometry of the 16-byte kernels (sweep_vec.hip, v3 / v4); 0 = derive from P / inner / ncols.
   //   COLFAST: a tile is (outer block o, NT neighbouring columns q < qmax); element (o, q, point j) of
@@ -97,6 +97,28 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 int sweep_get_ablate();
 void sweep_note_launch();
+
+// Straight-line fused kernel (fused4.hip).  The launch walks a line space of nouter blocks x qmax lines; element
+// (block o, line q, point j) of array X sits at o * X.os + q * X.ls + j * X.rs, counted in elements of X (COLFAST: ls = 1,
+// JFAST: rs = 1).  Arrays marked "trimmed" hold the points 1..n-1 of a line only (point j at (j-1) * rs): the interior
+// layout of the MatShell vectors.
+struct F4Geom { unsigned os, ls, rs; };
+struct Fused4Params {
+  int P, H;
+  unsigned nouter, qmax, ntiles, tpo, tpo_inv;    // tpo = tiles per block, tpo_inv = ceil(2^32 / tpo)
+  const double *in; F4Geom gi; unsigned in_bytes;              // trimmed in the Jacobian mode (full), whole lines otherwise
+  const void *coef; F4Geom gc; unsigned coef_bytes;            // full: pairs {eta, c / 2} (16 B); otherwise eta (8 B)
+  double *gout; unsigned gout_bytes;                           // eta mode: g = D u is stored here, geometry gc
+  const double *acc; F4Geom ga; unsigned acc_bytes;            // trimmed in the Jacobian mode
+  double *out; F4Geom go; unsigned out_bytes;                  // trimmed in the Jacobian mode and in the window mode
+  const double *sub; unsigned sub_bytes;                       // window mode: out -= sub (geometry go), may be null
+  double alpha;
+  const double *fragE2, *fragO2;
+};
+// full: Jacobian mode (coefficient pairs, trimmed vectors); acc: out = acc + alpha t; win (JFAST only): `out` and `sub`
+// are indexed by (o - 1, q - 1) and exist only for 1 <= o <= nouter - 2 (nouter > 1), 1 <= q <= qmax - 2
+bool fused4_eligible(const DiffMat &m);
+hipError_t fused4_launch(const DiffMat &m, Fused4Params p, bool jfast, bool full, bool acc, bool win, hipStream_t stream);
 
 // 16-byte-access specialisation (sweep_vec.hip); used by sweep_launch when eligible
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);

@@ -278,6 +278,33 @@ def test_elliptic_nonlinear_random_state(dims, exponent):
     op.destroy()
 
 
+@pytest.mark.parametrize("dims,exponent", [((136, 200), 2.0), ((68, 70, 72), 2.0), ((132, 68, 130), 3.0), ((256, 66, 68), 2.5),
+                                           ((66, 128, 254), 2.0)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else "e%g" % v)
+def test_elliptic_nonlinear_straight_line_kernel(dims, exponent):
+    """The shapes cheb_fused4_kernel serves (d = 2, 3, even extents of 66..256 points, KS = 16 and 32 mixed): FormFunction
+    with and without b, the stored gradient (c->gradu, elliptic.C:497-499), the Jacobian apply -- against the oracle."""
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED + 1)
+    u = rng.random(op.global_size) + 0.5
+    b = rng.standard_normal(op.global_size)
+    dv = rng.random(op.dirichlet_size) + 0.5
+    op.set_dirichlet(dv)
+    rhs0 = op.function_host(u, None, 1.5, exponent)
+    rhs = op.function_host(u, b, 1.5, exponent)
+    rhs_o, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, 1.5, exponent, mode=orc.FAST, nthreads=16)
+    assert relerr(rhs, rhs_o) < TOL
+    assert relerr(rhs0, rhs_o + b) < TOL
+    for k in range(len(dims)):
+        assert relerr(op.get_state(2 + k), gradu[k]) < TOL
+    for seed in (0, 1):
+        U = np.random.default_rng(SEED + 7 + seed).standard_normal(op.global_size)
+        V = op.mult_host(U)
+        ref = orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST, nthreads=16)
+        assert relerr(V, ref) < TOL
+    op.destroy()
+
+
 def test_elliptic_exact_residual():
     """elliptic.C:193-209 with -exact 2: the residual of the polynomial exact solution is ~0."""
     dims = (12, 11, 10)
