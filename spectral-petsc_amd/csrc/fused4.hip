@@ -36,6 +36,13 @@ constexpr int f4_lds_doubles() {
   return 4 * LDS_ELEMS + 8 * NFL * 64;
 }
 
+// Diagnostic builds only (-DF4_ABLATE=bits; tools/f4_ablate.sh): 1 = no coefficient loads, 2 = no accumulator loads,
+// 4 = no next-tile input loads, 8 = no global stores, 16 = no MFMA chains.  Results are wrong; the timing shows what
+// each stream costs.
+#ifndef F4_ABLATE
+#define F4_ABLATE 0
+#endif
+
 #define AO4(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
 
 template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN>
@@ -79,9 +86,9 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_sub = __builtin_amdgcn_make_buffer_rsrc((void *)((WIN && p.sub) ? p.sub : p.in), 0, (WIN && p.sub) ? p.sub_bytes : 0u, 0x00020000);
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
-  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
+  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { if (!(F4_ABLATE & 8) || v.x == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
   auto ld8 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); };
-  auto st8 = [](__amdgpu_buffer_rsrc_t r, u32 off, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)off, 0, 0); };
+  auto st8 = [](__amdgpu_buffer_rsrc_t r, u32 off, double v) { if (!(F4_ABLATE & 8) || v == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)off, 0, 0); };
 
   double ae[KS], ao[KR > 0 ? KR : 1];
   double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
@@ -115,6 +122,10 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
 
   auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
     const u32 t0 = tile_off(tl, p.gi, 8u);
+    if constexpr (F4_ABLATE & 4) { if (tl != p.ntiles + 12345u) {
+#pragma unroll
+      for (int s = 0; s < CH; s++) { rj[s] = d2{1.0 + s, 2.0}; rm[s] = d2{0.5, 0.25 * chunk}; }
+      return; } }
 #pragma unroll
     for (int s = 0; s < CH; s++) {
       const int sg = chunk * CH + s;
@@ -179,7 +190,10 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
         tv1[JFAST ? r : 0] = (q < qmax) ? t0 : T_INVALID;               // lines past the block's end
       }
       const u32 tv = tv1[JFAST ? r : 0];
-      if constexpr (FULL) { cv_hi[r] = ld16(r_coef, k_hi[r] + tv); cv_lo[r] = ld16(r_coef, k_lo[r] + tv); }
+      if constexpr (F4_ABLATE & 1) {
+        if constexpr (FULL) { cv_hi[r] = d2{1.0, 0.5}; cv_lo[r] = d2{1.0, 0.25}; } else { cv_hi[r] = 1.0; cv_lo[r] = 1.5; }
+        (void)tv;
+      } else if constexpr (FULL) { cv_hi[r] = ld16(r_coef, k_hi[r] + tv); cv_lo[r] = ld16(r_coef, k_lo[r] + tv); }
       else { cv_hi[r] = ld8(r_coef, k_hi[r] + tv); cv_lo[r] = ld8(r_coef, k_lo[r] + tv); }
     }
   };
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
     if (!JFAST) {
       const u32 q = q0 + nb + (u32)l16e;
       tv2[0] = (q < qmax) ? o * (p.go.os * 8u) + (q0 + nb) * 8u : T_INVALID;
-      if (ACC) {
+      if (ACC && !(F4_ABLATE & 2)) {
         const u32 ta = o * (p.ga.os * 8u) + (q0 + nb) * 8u;
 #pragma unroll
         for (int rp = 0; rp < 2; rp++) { acc_hi[rp] = ld16(r_acc, c_hi[rp] + ta); acc_lo[rp] = ld16(r_acc, c_lo[rp] + ta); }
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
       for (int r = 0; r < 4; r++) {
         const u32 q = q0 + nb + (u32)(4 * r + kq) - qt;
         tv2[r] = (q < qmax - 2u * qt) ? to + (u32)(4 * r) * o_ls8 : T_INVALID;
-        const double ah = ld8(r_acc, c_hi[0] + ta + (u32)(4 * r) * a_ls8), al = ld8(r_acc, c_lo[0] + ta + (u32)(4 * r) * a_ls8);
+        const double ah = (F4_ABLATE & 2) ? 1.0 : ld8(r_acc, c_hi[0] + ta + (u32)(4 * r) * a_ls8), al = (F4_ABLATE & 2) ? 2.0 : ld8(r_acc, c_lo[0] + ta + (u32)(4 * r) * a_ls8);
         if (r & 1) { acc_hi[r >> 1].y = ah; acc_lo[r >> 1].y = al; } else { acc_hi[r >> 1].x = ah; acc_lo[r >> 1].x = al; }
         if constexpr (WIN) {
           const double sh = ld8(r_sub, o_hi[0] + tv2[r]), sl = ld8(r_sub, o_lo[0] + tv2[r]);
@@ -318,6 +332,11 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
     ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
     const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
     const double *fE = sE + frag, *fO = sO + frag;
+    if constexpr (F4_ABLATE & 16) {                    // no matrix work: what the memory streams cost alone
+      fn_a(); fn_b(); fn_c();
+      ce[0] = fE[0] + ae[0]; co[0] = fO[KSTR] + AO4(KS - 1); ce[1] = fE[2 * KSTR]; co[2] = fO[3 * KSTR];
+      return;
+    }
     double fb[2][4];
     fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
 #pragma unroll

@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
+if os.environ.get("CHEBHIP_LIB_PATH"):      # diagnostic builds (tools/f4_ablate.sh)
+    sp.LIB_PATH = os.environ["CHEBHIP_LIB_PATH"]
 
 def timeit(fn, reps):
     for _ in range(reps):
