@@ -83,15 +83,36 @@ def cpu_baseline(P, threads, U, V=None):
     return out, parity
 
 
-def dist_parity_check(make, dist, torch, rank, world, P=34):
+def _all_ok(ok, dist, torch, backend):
+    """True iff every rank reports success (a rank that failed must not leave the others inside a collective)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def dist_parity_check(make, dist, torch, rank, world, backend, P=34):
     """N > 1: the slab-partitioned matvec at a reduced size (P^3) against the oracle's serial matvec, checked on rank 0.
-    Returns {"rel_l2_vs_oracle": .., "P": ..}; a mismatch aborts the bench."""
+    Returns ({"rel_l2_vs_oracle": .., "P": ..}, None), or (None, reason) when the implementation could not be set up or
+    run on some rank (every rank then gets the same answer); a numerical mismatch aborts the bench."""
     import numpy as np
-    op = make((P, P, P))
-    U = op.random_input(SEED + 1)
-    V = torch.empty_like(U)
-    op.mult(U, V)
-    torch.cuda.synchronize()
+    op, U, V, why = None, None, None, None
+    try:
+        op = make((P, P, P))
+    except Exception as e:                                  # e.g. RCCL bootstrap of the C-side host refused
+        why = "setup: %r" % (e,)
+    if not _all_ok(op is not None, dist, torch, backend):
+        if op is not None and hasattr(op, "destroy"):
+            op.destroy()
+        return None, why or "setup failed on another rank"
+    try:
+        U = op.random_input(SEED + 1)
+        V = torch.empty_like(U)
+        op.mult(U, V)
+        torch.cuda.synchronize()
+    except Exception as e:
+        why, V = "matvec: %r" % (e,), None
+    if not _all_ok(V is not None, dist, torch, backend):
+        return None, why or "matvec failed on another rank"
     pieces = [None] * world
     dist.all_gather_object(pieces, V.cpu().numpy())
     if hasattr(op, "destroy"):
@@ -106,7 +127,7 @@ def dist_parity_check(make, dist, torch, rank, world, P=34):
         out = {"rel_l2_vs_oracle": err, "tolerance": 1e-10, "P": P, "ranks": world}
         if not err <= 1e-10:
             raise SystemExit("parity failure: %d-rank %d^3 matvec differs from the oracle by %.3e" % (world, P, err))
-    return out
+    return out, None
 
 
 def extras(sp, torch):
@@ -190,8 +211,18 @@ def main():
         # The slab driver behind the C ABI (csrc/dist.hip: chebhip_dist_*, RCCL grouped send/recv on its own
         # communicator); BENCH_DIST_IMPL=python selects its Python twin (torch.distributed all_to_all_single).
         impl = os.environ.get("BENCH_DIST_IMPL", "c")
-        make = (lambda dm: dsp.DistPoissonC(dm, sp)) if impl == "c" else (lambda dm: dsp.DistPoissonOp(dm, backend=dsp.HipBackend(sp)))
-        dist_parity = dist_parity_check(make, dist, torch, rank, world)      # reduced size, against the oracle on rank 0
+        make_c = lambda dm: dsp.DistPoissonC(dm, sp)
+        make_py = lambda dm: dsp.DistPoissonOp(dm, backend=dsp.HipBackend(sp))
+        make = make_c if impl == "c" else make_py
+        dist_parity, why = dist_parity_check(make, dist, torch, rank, world, backend)   # reduced size, against the oracle on rank 0
+        dist_fallback = None
+        if dist_parity is None and why is not None and impl == "c":
+            # the C-side host could not run on this node: time its Python twin instead and say so in the line
+            dist_fallback = why
+            impl, make = "python", make_py
+            dist_parity, why = dist_parity_check(make, dist, torch, rank, world, backend)
+        if why is not None:
+            raise SystemExit("the %d-rank matvec could not be run: %s" % (world, why))
         op = make(dims)
         U = op.random_input(SEED)
         V = torch.empty_like(U)
@@ -272,6 +303,8 @@ def main():
         }
         if world > 1:
             out["parity"] = dist_parity
+            if dist_fallback:
+                out["config"]["c_host_fallback"] = dist_fallback
         if world == 1 and not args.no_cpu_baseline:
             try:
                 Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
