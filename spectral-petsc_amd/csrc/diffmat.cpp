@@ -18,6 +18,7 @@
 #include "sweep.h"
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 namespace chebhip {
@@ -130,6 +131,23 @@ hipError_t diffmat_create(int P, DiffMat *out) {
 hipError_t diffmat_from_dense(int M, const long double *A, int sym, DiffMat *out) {
   if (M < 1 || M > 256) return hipErrorInvalidValue;
   const int m = M - 1, H = (M + 1) / 2;
+  std::vector<long double> ME((size_t)H * H), MO((size_t)H * H);
+  for (int i = 0; i < H; i++)
+    for (int j = 0; j < H; j++) {
+      long double me, mo;
+      if (2 * j == m) { me = A[(size_t)i * M + j]; mo = 0.0L; }
+      else {
+        const long double a = A[(size_t)i * M + j], b = A[(size_t)i * M + (m - j)];
+        me = 0.5L * (a + b); mo = 0.5L * (a - b);
+      }
+      ME[(size_t)i * H + j] = me; MO[(size_t)i * H + j] = mo;
+    }
+  return diffmat_from_blocks(M, ME.data(), MO.data(), sym, out);
+}
+
+hipError_t diffmat_from_blocks(int M, const long double *ME, const long double *MO, int sym, DiffMat *out) {
+  if (M < 1 || M > 256) return hipErrorInvalidValue;
+  const int H = (M + 1) / 2;
   int KS = 4;
   while (4 * KS < H) KS *= 2;
   const int MTP = KS / 4;
@@ -140,14 +158,8 @@ hipError_t diffmat_from_dense(int M, const long double *A, int sym, DiffMat *out
       for (int l = 0; l < 64; l++) {
         const int i = mt * 16 + (l & 15), j = 4 * s + (l >> 4);
         if (i >= H || j >= H) continue;
-        long double me, mo;
-        if (2 * j == m) { me = A[(size_t)i * M + j]; mo = 0.0L; }
-        else {
-          const long double a = A[(size_t)i * M + j], b = A[(size_t)i * M + (m - j)];
-          me = 0.5L * (a + b); mo = 0.5L * (a - b);
-        }
-        fe[((size_t)mt * KS + s) * 64 + l] = (double)me;
-        fo[((size_t)mt * KS + s) * 64 + l] = (double)mo;
+        fe[((size_t)mt * KS + s) * 64 + l] = (double)ME[(size_t)i * H + j];
+        fo[((size_t)mt * KS + s) * 64 + l] = (double)MO[(size_t)i * H + j];
       }
   DiffMat r;
   r.P = M; r.H = H; r.KS = KS; r.MTP = MTP; r.sym = sym;
@@ -260,14 +272,47 @@ bool fdm_line(int P, std::vector<long double> &S, std::vector<long double> &Sinv
     kd[q] = -(idxP + idxM);                            // K = -(reference's bracket): positive diagonal
     if (q > 0) ke[q] = idxM;                           // K[q][q-1] = idxM < 0
   }
-  std::vector<long double> d(M), e(M, 0.0L), W((size_t)M * M, 0.0L);
-  for (int q = 0; q < M; q++) { d[q] = kd[q] / h[q]; if (q > 0) e[q] = ke[q] / sqrtl(h[q] * h[q - 1]); W[(size_t)q * M + q] = 1.0L; }
-  if (!tql2(M, d, e, W)) return false;
-  S.assign((size_t)M * M, 0.0L); Sinv.assign((size_t)M * M, 0.0L); lam = d;
+  // A = H^-1/2 K H^-1/2: symmetric tridiagonal, diagonal d, sub-diagonal e[q] = A[q][q-1]
+  std::vector<long double> d(M), e(M, 0.0L);
+  for (int q = 0; q < M; q++) { d[q] = kd[q] / h[q]; if (q > 0) e[q] = ke[q] / sqrtl(h[q] * h[q - 1]); }
+  // The nodes are symmetric about 0, so A is centro-symmetric and every eigenvector is even or odd under i -> M-1-i.
+  // The modes localised at the two ends of the line come in even / odd pairs whose eigenvalues agree to far below
+  // rounding, so a solver for the whole matrix returns arbitrary mixtures of each pair.  The two parity classes are
+  // therefore diagonalised SEPARATELY: restricted to even (odd) vectors A is again tridiagonal, of half the size, with
+  // simple well-separated eigenvalues.  Modes are laid out by parity -- position p < ceil(M/2): the p-th even mode,
+  // position M-1-q: the q-th odd mode, both by ascending eigenvalue -- which is the layout the raw modes of the sweep
+  // kernels read and write (sweep.h: SweepParams::raw).
+  const int m = M - 1, He = (M + 1) / 2, Ho = M / 2;
+  const bool has_mid = (M & 1) != 0;
+  const long double r2 = sqrtl(2.0L);
+  std::vector<long double> W((size_t)M * M, 0.0L);       // W[i][position]
+  lam.assign(M, 0.0L);
+  for (int parity = 0; parity < 2; parity++) {           // 0: even, 1: odd
+    const int n = parity == 0 ? He : Ho;
+    if (n == 0) continue;
+    std::vector<long double> dd(n), ee(n, 0.0L), Z((size_t)n * n, 0.0L);
+    for (int i = 0; i < n; i++) { dd[i] = d[i]; if (i > 0) ee[i] = e[i]; Z[(size_t)i * n + i] = 1.0L; }
+    if (!has_mid) dd[n - 1] += (parity == 0 ? e[n] : -e[n]);        // the two middle points couple to each other
+    else if (parity == 0 && n > 1) ee[n - 1] = r2 * e[n - 1];       // the middle point is its own mirror
+    if (!tql2(n, dd, ee, Z)) return false;
+    std::vector<int> ord(n);
+    for (int j = 0; j < n; j++) ord[j] = j;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return dd[a] < dd[b]; });
+    for (int q = 0; q < n; q++) {
+      const int j = ord[q], pos = parity == 0 ? q : m - q;
+      lam[pos] = dd[j];
+      for (int i = 0; i < n; i++) {
+        const long double v = Z[(size_t)i * n + j];
+        if (has_mid && parity == 0 && i == n - 1) W[(size_t)i * M + pos] = v;
+        else { W[(size_t)i * M + pos] = v / r2; W[(size_t)(m - i) * M + pos] = (parity == 0 ? v : -v) / r2; }
+      }
+    }
+  }
+  S.assign((size_t)M * M, 0.0L); Sinv.assign((size_t)M * M, 0.0L);
   for (int i = 0; i < M; i++)
-    for (int j = 0; j < M; j++) {
-      S[(size_t)i * M + j] = W[(size_t)i * M + j] / sqrtl(h[i]);
-      Sinv[(size_t)j * M + i] = W[(size_t)i * M + j] * sqrtl(h[i]);
+    for (int pos = 0; pos < M; pos++) {
+      S[(size_t)i * M + pos] = W[(size_t)i * M + pos] / sqrtl(h[i]);
+      Sinv[(size_t)pos * M + i] = W[(size_t)i * M + pos] * sqrtl(h[i]);
     }
   return true;
 }

@@ -113,7 +113,7 @@ __global__ void k_resid_over_eta(long G, int nf, const double *__restrict__ a, c
 __global__ void k_deinterleave(long G, int nf, const double *__restrict__ a, double *__restrict__ b) { GS_LOOP(q, G * nf) { const long f = q / G, g = q - f * G; b[q] = a[g * nf + f]; } }
 __global__ void k_interleave(long G, int nf, const double *__restrict__ b, double *__restrict__ a) { GS_LOOP(q, G * nf) { const long f = q / G, g = q - f * G; a[g * nf + f] = b[q]; } }
 
-struct LineMats { DiffMat Fcs, Fca, Bcs, Bca; double *lam = nullptr; bool ok = false; };
+struct LineMats { DiffMat Fcs, Fca, Bcs, Bca, Fraw, Braw; double *lam = nullptr; bool ok = false; };
 
 }  // namespace
 
@@ -139,6 +139,7 @@ static void fdpc_free(chebhip_fdpc *pc) {
   for (auto &kv : pc->lines) {
     if (!kv.second.ok) continue;
     diffmat_destroy(&kv.second.Fcs); diffmat_destroy(&kv.second.Fca); diffmat_destroy(&kv.second.Bcs); diffmat_destroy(&kv.second.Bca);
+    diffmat_destroy(&kv.second.Fraw); diffmat_destroy(&kv.second.Braw);
     if (kv.second.lam) (void)hipFree(kv.second.lam);
   }
   for (int k = 0; k < MAXD; k++) if (pc->xs[k]) (void)hipFree(pc->xs[k]);
@@ -178,6 +179,26 @@ static int fdpc_create(const FdView &v, int nf, bool interleaved, chebhip_fdpc *
     centro_part(M, Si, 0, part); PCCHK(diffmat_from_dense(M, part.data(), 0, &lm.Fca));
     centro_part(M, S, 1, part);  PCCHK(diffmat_from_dense(M, part.data(), 1, &lm.Bcs));
     centro_part(M, S, 0, part);  PCCHK(diffmat_from_dense(M, part.data(), 0, &lm.Bca));
+    {
+      // The same two transforms as ONE product each.  fdm_line orders the modes by parity (even modes at the positions
+      // p < H, the q-th odd mode at M-1-q), so with e, o the parity split of a nodal line
+      //   forward:  c_p = sum_j Sinv[p][j] e_j (p < H),  c_{M-1-q} = sum_j Sinv[M-1-q][j] o_j      -> halves stored raw
+      //   backward: x_i = sum_p S[i][p] c_p + sum_q S[i][M-1-q] c_{M-1-q},  x_{M-1-i} = the difference -> input taken raw
+      const int m = M - 1, Hh = (M + 1) / 2;
+      std::vector<long double> E((size_t)Hh * Hh, 0.0L), O((size_t)Hh * Hh, 0.0L);
+      for (int q = 0; q < Hh; q++)
+        for (int j = 0; j < Hh; j++) {
+          E[(size_t)q * Hh + j] = Si[(size_t)q * M + j];
+          O[(size_t)q * Hh + j] = (2 * q == m || 2 * j == m) ? 0.0L : Si[(size_t)(m - q) * M + j];
+        }
+      PCCHK(diffmat_from_blocks(M, E.data(), O.data(), 1, &lm.Fraw));
+      for (int i = 0; i < Hh; i++)
+        for (int j = 0; j < Hh; j++) {
+          E[(size_t)i * Hh + j] = S[(size_t)i * M + j];
+          O[(size_t)i * Hh + j] = (2 * j == m) ? 0.0L : S[(size_t)i * M + (m - j)];
+        }
+      PCCHK(diffmat_from_blocks(M, E.data(), O.data(), 1, &lm.Braw));
+    }
     std::vector<double> ld(M); for (int i = 0; i < M; i++) ld[i] = (double)lam[i];
     PCCHK(hipMalloc((void **)&lm.lam, M * sizeof(double)));
     PCCHK(hipMemcpy(lm.lam, ld.data(), M * sizeof(double), hipMemcpyHostToDevice));
@@ -208,13 +229,19 @@ static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
   return 0;
 }
 
-// y = (Xcs + Xca) x along dimension k of nf stacked interior fields (x != y)
+// y = S^-1 x (forward) or S x (backward) along dimension k of nf stacked interior fields (x != y): one raw-mode launch
+// where the 16-byte kernels can run it, otherwise the centro-symmetric plus the centro-antisymmetric part (two launches)
 static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st) {
   LineMats &lm = pc->lines[pc->geo.dims[k]];
   SweepParams sp = {};
   sp.ncols = pc->ncols_g[k] * (unsigned)pc->nf; sp.inner = pc->inner_g[k];
   sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.alpha = 1.0;
   sp.out_mode = OUT_STORE;
+  if (sweep_vec_raw_eligible(backward ? lm.Braw : lm.Fraw, sp)) {       // one launch: the parity split is the transform's own
+    sp.raw = backward ? 2 : 1;
+    PHIPCHK(sweep_launch(backward ? lm.Braw : lm.Fraw, sp, st));
+    return 0;
+  }
   PHIPCHK(sweep_launch(backward ? lm.Bcs : lm.Fcs, sp, st));
   sp.out_mode = OUT_ACC; sp.acc = y;
   PHIPCHK(sweep_launch(backward ? lm.Bca : lm.Fca, sp, st));

@@ -47,6 +47,9 @@ struct SweepParams {
   double *sink;                 // 512 x 16 B in HBM: where masked-off stores of the straight-line kernel go
   unsigned ntiles;
   int sym;            // mirror rows are a - b (centro-symmetric matrix) instead of b - a
+  int raw;            // 16-byte kernels, STORE only (the line transforms of precond.hip): 1 = the two halves of the product are
+                      //   stored as they are (row i <- (ME e)_i, row m-i <- (MO o)_i) instead of being recombined;
+                      //   2 = the input is taken as already split (e_j = x_j, o_j = x_{m-j})
   int trim;           // fused launches only: arrays in0/out/acc hold interior points only (see fused.hip)
   int coef_mode;      // fused launches only: CoefMode; COEF_ETA: eta = in1; COEF_FULL: in2 = pairs {eta, c / 2}, c = deta * du0 (local layout)
   double *gout;       // fused launches only: if non-null the gradient g = D u is also stored here (local layout)
@@ -86,6 +89,8 @@ hipError_t diffmat_create_lap(int P, DiffMat *out);
 void diffmat_destroy(DiffMat *m);
 // Fragments of an arbitrary centro-symmetric (sym = 1) / centro-antisymmetric (sym = 0) dense M x M matrix, M <= 256.
 hipError_t diffmat_from_dense(int M, const long double *A, int sym, DiffMat *out);
+// The same from the two H x H blocks themselves (H = ceil(M/2), row-major): y_i = (ME e)_i + (MO o)_i etc.
+hipError_t diffmat_from_blocks(int M, const long double *ME, const long double *MO, int sym, DiffMat *out);
 // Host-side dense differentiation matrix (row-major P x P), for tests and the adapter.
 void diffmat_dense_host(int P, double *D);
 
@@ -122,6 +127,8 @@ hipError_t fused4_launch(const DiffMat &m, Fused4Params p, bool jfast, bool full
 
 // 16-byte-access specialisation (sweep_vec.hip); used by sweep_launch when eligible
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);
+// ... and may carry p.raw != 0 (the kernel generations that implement the raw modes)
+bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p);
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *jobs, hipStream_t stream, bool *done);
 // n independent sweeps (plain in, STORE out): one launch when they qualify (sweep_vec.hip), else n launches
@@ -135,6 +142,7 @@ void sweep_set_variant(int bits);
 int sweep_get_variant();
 
 // Fast diagonalisation of the 1-D three-point operator of the finite-difference preconditioners (diffmat.cpp)
+// Modes are ordered by parity: position p < ceil(M/2) holds the p-th even mode, position M-1-q the q-th odd one
 bool fdm_line(int P, std::vector<long double> &S, std::vector<long double> &Sinv, std::vector<long double> &lam);
 void centro_part(int M, const std::vector<long double> &A, int part, std::vector<long double> &out);
 

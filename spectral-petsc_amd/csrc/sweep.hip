@@ -498,6 +498,7 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
       return sweep_vec_launch(m, p, stream);
     }
   }
+  if (p.raw) return hipErrorInvalidValue;               // the raw modes exist in the 16-byte kernels only (sweep_vec_raw_eligible)
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);

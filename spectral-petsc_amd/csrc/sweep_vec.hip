@@ -102,6 +102,7 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
   const d2 *zero2 = (const d2 *)p.zero;
 
   const int ablate = p.ablate;   // profiling only (sweep.h)
+  const bool raw_in = p.raw == 2, raw_out = p.raw == 1;   // the line transforms of precond.hip (sweep.h)
   auto issue_loads = [&](u32 tile, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
     if (ablate & 1) {
 #pragma unroll
@@ -144,14 +145,17 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
       d2 e, o;
       if (!JFAST) {
         const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn;   // rm was left 0 there
-        e = rj[s] + rm[s];
-        o = rj[s] - rm[s];
+        if (raw_in) { e = rj[s]; o = rm[s]; }                           // already split: e_j = x_j, o_j = x_{n-j}
+        else { e = rj[s] + rm[s]; o = rj[s] - rm[s]; }
         if (mid) o = d2{0.0, 0.0};
       } else {
         // rj = (x_j, x_{j+1}), rm = (x_{n-j-1}, x_{n-j}); point j+1 may be past the half (H odd) -> 0
         const bool v1 = 2 * ld_a + 1 < H;
-        e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
-        o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
+        if (raw_in) { e = d2{rj[s].x, v1 ? rj[s].y : 0.0}; o = d2{rm[s].y, v1 ? rm[s].x : 0.0}; }
+        else {
+          e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
+          o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
+        }
       }
       *(d2 *)(dE + idx) = e;
       *(d2 *)(dO + idx) = o;
@@ -286,7 +290,10 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
       // hi = value of row i, lo = value of the mirror row n-i  (D: b - a;  D D: a - b)
       double hi[4], lo[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
+      for (int r = 0; r < 4; r++) {
+        if (raw_out) { hi[r] = ce[r]; lo[r] = co[r]; }
+        else { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
+      }
 #pragma unroll
       for (int rp = 0; rp < 2; rp++) {
         // even lane keeps row 2rp and gets the neighbour's row 2rp; odd lane keeps row 2rp+1
@@ -638,8 +645,9 @@ static hipError_t launch_v3(const SweepParams &p, unsigned grid, hipStream_t str
 //     the end of the array), which only meet zero entries of the matrix or feed columns that are never stored;
 //   * the lane exchange that makes 16-byte pieces is one DPP broadcast + one select per dword;
 //   * the centro-symmetry sign rides in the scalar factor of the mirror row.
-template <int KS, bool JFAST, bool ACC>
+template <int KS, bool JFAST, bool ACC, int RAW = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
+  static_assert(RAW == 0 || !ACC, "the raw modes (sweep.h) are STORE-only");
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
   constexpr int HP = 4 * KS;
@@ -721,7 +729,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     for (int s = 0; s < CH; s++) {
       const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
       d2 e, o;
-      if (!JFAST) {
+      if (RAW == 2) {                                  // already split: e_j = x_j, o_j = x_{n-j} (a middle o meets a zero column)
+        e = rj[s];
+        o = JFAST ? d2{rm[s].y, rm[s].x} : rm[s];
+      } else if (!JFAST) {
         e = rj[s] + rm[s];
         o = rj[s] - rm[s];                             // the middle point of an odd line is its own mirror: o = 0
         if (oddP) { const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn; if (mid) e = rj[s]; }
@@ -764,7 +775,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   const u32 out_os8 = p.out_os * 8u, acc_os8 = p.acc_os * 8u;
   const u32 sub8_out = JFAST ? 16u * out_os8 : 16u * 8u, sub8_acc = JFAST ? 16u * acc_os8 : 16u * 8u;   // sub-tile 1 vs 0
   const u32 ng8_out = (u32)ng * NSUB * sub8_out, ng8_acc = (u32)ng * NSUB * sub8_acc;
-  const double alpha = p.alpha, alpha_lo = p.sym ? p.alpha : -p.alpha;      // mirror row: D: b - a; D D: a - b
+  const double alpha = p.alpha, alpha_lo = (p.sym || RAW == 1) ? p.alpha : -p.alpha;      // mirror row: D: b - a; D D: a - b
 
   auto acc_issue = [&](u32 tl, bool valid, int sub, d2 (&ah)[2], d2 (&al)[2]) {
     if (!ACC) return;
@@ -860,7 +871,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     }
     double hi[4], lo[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = ce[r] - co[r]; }
+    for (int r = 0; r < 4; r++) {
+      if (RAW == 1) { hi[r] = ce[r]; lo[r] = co[r]; }  // the halves as they are: row i <- (ME e)_i, row n-i <- (MO o)_i
+      else { hi[r] = ce[r] + co[r]; lo[r] = ce[r] - co[r]; }
+    }
 #pragma unroll
     for (int rp = 0; rp < 2; rp++) {
       // even lane: row 2rp of its own column and of the odd neighbour's; odd lane: row 2rp+1 of the even neighbour's and its own
@@ -930,10 +944,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
 #endif
 }
 
-template <int KS, bool JFAST, bool ACC>
+template <int KS, bool JFAST, bool ACC, int RAW = 0>
 __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams p) {
   __shared__ double smem[vec_lds_doubles<KS, JFAST>()];
-  vec4_body<KS, JFAST, ACC>(p, smem, blockIdx.x, gridDim.x);
+  vec4_body<KS, JFAST, ACC, RAW>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -963,6 +977,8 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams
 template <int KS, bool JFAST>
 static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t stream) {
   if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
+  else if (p.raw == 1) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false, 1>), dim3(grid), dim3(512), 0, stream, p);
+  else if (p.raw == 2) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false, 2>), dim3(grid), dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
@@ -1019,6 +1035,7 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   if (grid == 0) return hipSuccess;
   if constexpr (KS >= 16) {
     if (gen == 4) return launch_v4<KS, JFAST>(p, grid, stream);
+    if (p.raw) return hipErrorInvalidValue;              // see sweep_vec_raw_eligible
     if (gen == 3) return launch_v3<KS, JFAST>(p, grid, stream);
   }
   if (gen == 0) return hipErrorInvalidValue;
@@ -1042,6 +1059,28 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p) {
   return m.KS == 4 || m.KS == 8 || m.KS == 16 || m.KS == 32;
 }
 
+template <int KS>
+static bool raw_ok_t(SweepParams p, bool jfast) {
+  const int gen = jfast ? prepare_v<KS, true>(p) : prepare_v<KS, false>(p);
+  return KS >= 16 ? gen == 4 : gen == 1;
+}
+bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p0) {
+  if (p0.out_mode != OUT_STORE || !sweep_vec_eligible(m, p0)) return false;
+  static int noraw = -1;
+  if (noraw < 0) { const char *e = getenv("CHEBHIP_NORAW"); noraw = (e && e[0] == '1') ? 1 : 0; }
+  if (noraw) return false;
+  SweepParams p = p0;
+  p.P = m.P; p.H = m.H; p.sink = m.sink; p.ablate = sweep_get_ablate(); p.variant = sweep_get_variant();
+  const bool jfast = p.inner < 16;
+  switch (m.KS) {
+    case 4: return raw_ok_t<4>(p, jfast);
+    case 8: return raw_ok_t<8>(p, jfast);
+    case 16: return raw_ok_t<16>(p, jfast);
+    case 32: return raw_ok_t<32>(p, jfast);
+    default: return false;
+  }
+}
+
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   const bool jfast = p.inner < 16;
   switch (m.KS) {
@@ -1057,6 +1096,7 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
 // *done = false: the caller launches them one by one
 template <int KS>
 static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done) {
+  for (int j = 0; j < n; j++) if (jobs[j].raw) { *done = false; return hipSuccess; }
   MultiParams mp = {};
   mp.njobs = n;
   hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
