@@ -186,7 +186,8 @@ int stokes_op_inner_iterations(const stokes_op *op);   /* MatVV applies of the l
 int stokes_op_set_inner_reduce(stokes_op *op, chebhip_reduce_fn reduce, void *ctx);
 /* StokesFunction (:680-758): yG = F(xG) - force; refreshes eta, deta, strain. */
 int stokes_op_function(stokes_op *op, const double *xG_dev, double *yG_dev, void *stream);
-/* Operator state to/from the host: which = 0 eta (N), 1 deta (N), 2+j strain[j] (N*d). */
+/* Operator state to/from the host: which = 0 eta (N), 1 deta (N), 2+j strain[j] (N*d).  The strain is the symmetrised
+ * velocity gradient (stokes.C:718-722): strain[j][k] == strain[k][j]; the Jacobian apply reads the entries with j <= k. */
 int stokes_op_get_state(stokes_op *op, int which, double *dst_host);
 int stokes_op_set_state(stokes_op *op, int which, const double *src_host);
 

@@ -122,7 +122,13 @@ __global__ void k_st_node_vv(long N, double *__restrict__ V0, double *__restrict
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
-      for (int k = 0; k < D; k++) { g[j][k] = V[j][k * N + i]; S0v[j][k] = DETA ? S[j][k * N + i] : 0.0; }
+      for (int k = 0; k < D; k++) g[j][k] = V[j][k * N + i];
+    // the stored strain S0 is symmetric (StokesFunction writes the symmetrised gradient, stokes.C:718-722): the upper
+    // triangle is read, D (D - 1) / 2 fewer loads per node
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = j; k < D; k++) { S0v[j][k] = DETA ? S[j][k * N + i] : 0.0; S0v[k][j] = S0v[j][k]; }
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll

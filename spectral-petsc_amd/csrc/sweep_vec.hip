@@ -1101,16 +1101,44 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
   mp.njobs = n;
   hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
   if (cu_err != hipSuccess) return cu_err;
-  unsigned b = 0;
+  unsigned long long total = 0;
   for (int j = 0; j < n; j++) {
     SweepParams &p = jobs[j];
     const bool jfast = p.inner < 16;
     const int gen = jfast ? prepare_v<KS, true>(p) : prepare_v<KS, false>(p);
     if (gen != (KS >= 16 ? 4 : 1)) return hipSuccess;      // not for this launch: done stays false
-    unsigned g = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
-    g = (g + 7u) & ~7u;                                     // whole XCD rounds: the surplus workgroups exit at once
-    mp.bstart[j] = b; b += g; mp.job[j] = p;
+    total += p.ntiles;
   }
+  // One workgroup per CU in all, shared out in proportion to the jobs' tiles: every workgroup walks several tiles with
+  // its prefetch pipeline running (one fill, one drain per launch) instead of the jobs taking the chip one after another.
+  static int split = -1;
+  if (split < 0) { const char *e = getenv("CHEBHIP_MULTI_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+  unsigned gs[MULTI_MAX];
+  for (int j = 0; j < n; j++) {
+    const unsigned nt = jobs[j].ntiles;
+    gs[j] = ((nt < (unsigned)ncu ? nt : (unsigned)ncu) + 7u) & ~7u;   // whole XCD rounds: the surplus workgroups exit at once
+  }
+  if (split && total > (unsigned long long)ncu && ncu % 8 == 0 && ncu >= 8 * n) {
+    // shares in units of 8 workgroups (one per XCD) that add up to the CU count exactly: one workgroup too many would
+    // wait for a whole job to finish
+    const unsigned units = (unsigned)ncu / 8u;
+    unsigned u[MULTI_MAX], used = 0;
+    unsigned long long rem[MULTI_MAX];
+    for (int j = 0; j < n; j++) {
+      const unsigned long long x = (unsigned long long)units * jobs[j].ntiles;
+      u[j] = (unsigned)(x / total); rem[j] = x % total;
+      if (u[j] == 0 && jobs[j].ntiles) { u[j] = 1; rem[j] = 0; }
+      used += u[j];
+    }
+    while (used < units) {                                  // largest remainders first
+      int best = 0;
+      for (int j = 1; j < n; j++) if (rem[j] > rem[best]) best = j;
+      u[best]++; rem[best] = 0; used++;
+    }
+    if (used == units) for (int j = 0; j < n; j++) if (8u * u[j] < gs[j]) gs[j] = 8u * u[j];
+  }
+  unsigned b = 0;
+  for (int j = 0; j < n; j++) { mp.bstart[j] = b; b += gs[j]; mp.job[j] = jobs[j]; }
   mp.bstart[n] = b;
   if (b == 0) { *done = true; return hipSuccess; }
   hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
