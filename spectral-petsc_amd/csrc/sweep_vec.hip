@@ -645,6 +645,12 @@ static hipError_t launch_v3(const SweepParams &p, unsigned grid, hipStream_t str
 //     the end of the array), which only meet zero entries of the matrix or feed columns that are never stored;
 //   * the lane exchange that makes 16-byte pieces is one DPP broadcast + one select per dword;
 //   * the centro-symmetry sign rides in the scalar factor of the mirror row.
+// Diagnostic builds only (-DV4_ABLATE=bits; tools/v4_ablate.sh): 1 = no input loads, 2 = no accumulator loads, 8 = no global
+// stores, 16 = no MFMA chains.  Results are wrong; the timing shows what each stream costs.
+#ifndef V4_ABLATE
+#define V4_ABLATE 0
+#endif
+
 template <int KS, bool JFAST, bool ACC, int RAW = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
   static_assert(RAW == 0 || !ACC, "the raw modes (sweep.h) are STORE-only");
@@ -682,7 +688,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC ? p.acc : p.in0), 0, ACC ? p.acc_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
-  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
+  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { if (!(V4_ABLATE & 8) || v.x == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
 
   double ae[KS], ao[KR > 0 ? KR : 1];
   double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
@@ -715,6 +721,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
 
   auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
     const u32 t0 = tile_off(tl, true, in_os8);
+    if constexpr (V4_ABLATE & 1) { if (tl != p.ntiles + 12345u) {
+#pragma unroll
+      for (int s = 0; s < CH; s++) { rj[s] = d2{1.0 + s, 2.0}; rm[s] = d2{0.5, 0.25 * chunk}; }
+      return; } }
 #pragma unroll
     for (int s = 0; s < CH; s++) {
       const u32 so = (u32)(chunk * CH + s) * slot8;                          // scalar
@@ -779,6 +789,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
 
   auto acc_issue = [&](u32 tl, bool valid, int sub, d2 (&ah)[2], d2 (&al)[2]) {
     if (!ACC) return;
+    if constexpr (V4_ABLATE & 2) { ah[0] = d2{1.0, 2.0}; ah[1] = ah[0]; al[0] = d2{3.0, 4.0}; al[1] = al[0]; if (tl != p.ntiles + 12345u) return; }
     const u32 t0 = tile_off(tl, valid, acc_os8) + ng8_acc + (u32)sub * sub8_acc;
 #pragma unroll
     for (int rp = 0; rp < 2; rp++) { ah[rp] = ld16(r_acc, c_hi[rp] + t0); al[rp] = ld16(r_acc, c_lo[rp] + t0); }
@@ -825,6 +836,11 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
     const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
     const double *fE = sE + frag, *fO = sO + frag;
+    if constexpr (V4_ABLATE & 16) {                    // no matrix work: what the memory streams cost alone
+      issue_fn(); park_fn();
+      ce[0] = fE[0] + ae[0]; co[0] = fO[KSTR] + AO(KS - 1); ce[1] = fE[2 * KSTR]; co[2] = fO[3 * KSTR];
+      return;
+    }
     double fb[2][4];
     fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
 #pragma unroll

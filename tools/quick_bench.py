@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
+if os.environ.get("CHEBHIP_LIB_PATH"):      # diagnostic builds (tools/v4_ablate.sh)
+    sp.LIB_PATH = os.environ["CHEBHIP_LIB_PATH"]
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 abl = [int(a) for a in sys.argv[2:]] or [0]
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]   # chebhip_debug_variant bits, A/B in one process
