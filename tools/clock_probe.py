@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
+if os.environ.get("CHEBHIP_LIB_PATH"):      # diagnostic builds (tools/v4_ablate.sh): then only the first setting is meaningful
+    sp.LIB_PATH = os.environ["CHEBHIP_LIB_PATH"]
 P = 256
 op = sp.EllipticOp((P, P, P))
 U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
@@ -18,7 +20,8 @@ def smi():
         return " | ".join(keep)
     except Exception as e:
         return "smi failed: %r" % e
-for ab, name in ((0, "full"), (3, "compute only"), (4, "memory only")):
+settings = ((0, "full"),) if os.environ.get("CHEBHIP_LIB_PATH") else ((0, "full"), (3, "compute only"), (4, "memory only"))
+for ab, name in settings:
     L.chebhip_debug_ablate(ab)
     stop = False
     res = []
