@@ -23,6 +23,9 @@
 // MFMA is kept off the per-element path: offsets are 32-bit and tile-invariant, the mode
 // switches are hoisted around the unrolled loops, LDS fragment reads run one group ahead.
 #include "sweep.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include <dlfcn.h>
 #include <atomic>
 #include <type_traits>
@@ -415,32 +418,48 @@ __global__ __launch_bounds__(256) void cheb_sweep_long_kernel(const SweepParams 
 // flux / scatter modes, cheb_sweep_long_kernel above runs.
 namespace {
 struct RocblasApi {
-  void *lib = nullptr, *handle = nullptr;
+  void *lib = nullptr;
   int (*create)(void **) = nullptr;
   int (*set_stream)(void *, hipStream_t) = nullptr;
   int (*dgemm_sb)(void *, int, int, int, int, int, const double *, const double *, int, long long, const double *, int, long long,
                   const double *, double *, int, long long, int) = nullptr;
-  bool tried = false;
+  bool ok = false;
+  std::once_flag once;
+  std::mutex mu;
+  std::map<std::pair<int, hipStream_t>, void *> handles;    // one handle per (device, stream): a handle is bound to one stream
 };
 RocblasApi g_rb;
 
 bool rocblas_ready() {
-  if (g_rb.tried) return g_rb.handle != nullptr;
-  g_rb.tried = true;
-  const char *off = getenv("CHEBHIP_NO_ROCBLAS");
-  if (off && off[0] == '1') return false;
-  const char *names[] = {"librocblas.so.5", "librocblas.so.4", "librocblas.so"};
-  for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // already in the process?
-  for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-  if (!g_rb.lib) return false;
-  g_rb.create = (int (*)(void **))dlsym(g_rb.lib, "rocblas_create_handle");
-  g_rb.set_stream = (int (*)(void *, hipStream_t))dlsym(g_rb.lib, "rocblas_set_stream");
-  g_rb.dgemm_sb = (decltype(g_rb.dgemm_sb))dlsym(g_rb.lib, "rocblas_dgemm_strided_batched");
-  if (!g_rb.create || !g_rb.set_stream || !g_rb.dgemm_sb) return false;
+  std::call_once(g_rb.once, [] {
+    const char *off = getenv("CHEBHIP_NO_ROCBLAS");
+    if (off && off[0] == '1') return;
+    const char *names[] = {"librocblas.so.5", "librocblas.so.4", "librocblas.so"};
+    for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // already in the process?
+    for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!g_rb.lib) return;
+    g_rb.create = (int (*)(void **))dlsym(g_rb.lib, "rocblas_create_handle");
+    g_rb.set_stream = (int (*)(void *, hipStream_t))dlsym(g_rb.lib, "rocblas_set_stream");
+    g_rb.dgemm_sb = (decltype(g_rb.dgemm_sb))dlsym(g_rb.lib, "rocblas_dgemm_strided_batched");
+    g_rb.ok = g_rb.create && g_rb.set_stream && g_rb.dgemm_sb;
+  });
+  return g_rb.ok;
+}
+
+// The handle of (current device, stream), created on first use.  Two streams of one operator (the Stokes pressure chain
+// runs beside the viscous chain) therefore never re-target each other's handle.
+void *rocblas_handle_for(hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_rb.mu);
+  auto key = std::make_pair(dev, stream);
+  auto it = g_rb.handles.find(key);
+  if (it != g_rb.handles.end()) return it->second;
   void *h = nullptr;
-  if (g_rb.create(&h) != 0 || !h) return false;
-  g_rb.handle = h;
-  return true;
+  if (g_rb.create(&h) != 0 || !h) return nullptr;
+  if (g_rb.set_stream(h, stream) != 0) return nullptr;
+  g_rb.handles[key] = h;
+  return h;
 }
 }  // namespace
 
@@ -453,14 +472,15 @@ static hipError_t launch_long_gemm(const SweepParams &p, hipStream_t stream, boo
     if (e != hipSuccess) return e;
   }
   const double alpha = p.alpha, beta = (p.out_mode == OUT_ACC) ? 1.0 : 0.0;
-  if (g_rb.set_stream(g_rb.handle, stream) != 0) return hipErrorUnknown;
+  void *handle = rocblas_handle_for(stream);
+  if (!handle) return hipErrorUnknown;
   const int P = p.P;
   int st;
   if (p.inner == 1)        // lines contiguous: Y (P x ncols, column-major) = D X
-    st = g_rb.dgemm_sb(g_rb.handle, OP_T, OP_N, P, (int)p.ncols, P, &alpha, p.longD, P, 0, p.in0, P, 0, &beta, p.out, P, 0, 1);
+    st = g_rb.dgemm_sb(handle, OP_T, OP_N, P, (int)p.ncols, P, &alpha, p.longD, P, 0, p.in0, P, 0, &beta, p.out, P, 0, 1);
   else {                   // per outer block o: Y_o^T (inner x P, column-major) = X_o^T D^T
     const long long blk = (long long)P * p.inner;
-    st = g_rb.dgemm_sb(g_rb.handle, OP_N, OP_N, (int)p.inner, P, P, &alpha, p.in0, (int)p.inner, blk, p.longD, P, 0, &beta,
+    st = g_rb.dgemm_sb(handle, OP_N, OP_N, (int)p.inner, P, P, &alpha, p.in0, (int)p.inner, blk, p.longD, P, 0, &beta,
                        p.out, (int)p.inner, blk, (int)(p.ncols / p.inner));
   }
   if (st != 0) return hipErrorUnknown;
