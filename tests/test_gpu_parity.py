@@ -238,6 +238,26 @@ def test_elliptic_mult_256_vs_oracle():
     op.destroy()
 
 
+def test_elliptic_nonlinear_256_vs_oracle():
+    """BASELINE config 3 with variable coefficients (-gamma 4 -exponent 2, tests.sh:10) at full size: FormFunction and the
+    Jacobian apply of cheb_fused4_kernel at 256^3 against the oracle (16 threads)."""
+    dims = (256, 256, 256)
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED + 3)
+    u = rng.random(op.global_size) + 0.5
+    b = rng.standard_normal(op.global_size)
+    dv = rng.random(op.dirichlet_size) + 0.5
+    op.set_dirichlet(dv)
+    rhs = op.function_host(u, b, 4.0, 2.0)
+    rhs_o, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, 4.0, 2.0, mode=orc.FAST, nthreads=16)
+    assert relerr(rhs, rhs_o) < TOL
+    U = rng.standard_normal(op.global_size)
+    V = op.mult_host(U)
+    ref = orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST, nthreads=16)
+    assert relerr(V, ref) < TOL
+    op.destroy()
+
+
 @pytest.mark.parametrize("dims", [(24, 20), (12, 11, 10)])
 def test_elliptic_nonlinear_vs_oracle(dims):
     """FormFunction + Jacobian apply with gamma != 0 (elliptic.C:481-533, 297-339)."""
