@@ -687,7 +687,7 @@ static int ell_fused4_jacobian(ell_op *op, int k, const double *U, double *V, hi
 
 // FormFunction, direction k (elliptic.C:497-528): gradu[k] = D_k w0 is stored on the way, W (+)= -D_k( eta gradu[k] ) in
 // the local layout; the last direction writes rhs = scatter(W) - b in the interior layout.
-static int ell_fused4_function(ell_op *op, int k, const double *b, double *rhs, hipStream_t st) {
+static int ell_fused4_function(ell_op *op, int k, double gamma, double exponent, const double *b, double *rhs, hipStream_t st) {
   const int d = op->d;
   const unsigned n0 = op->dims[0], n1 = d == 3 ? op->dims[1] : 0, nlast = op->dims[d - 1];
   const unsigned nl = nlast - 2, nm = d == 3 ? n1 - 2 : 1u, s0 = d == 3 ? n1 * nlast : nlast;
@@ -695,6 +695,10 @@ static int ell_fused4_function(ell_op *op, int k, const double *b, double *rhs, 
   Fused4Params q = {};
   q.alpha = -1.0;
   q.in = op->w0; q.in_bytes = nbytes; q.coef = op->eta; q.coef_bytes = nbytes; q.gout = op->gradu[k]; q.gout_bytes = nbytes;
+  // the reference's default exponent (elliptic.C:141): eta = 1 + gamma w0^2 is formed from the line in LDS instead of being read
+  static int noetasq = -1;
+  if (noetasq < 0) { const char *e = getenv("CHEBHIP_NO_ETASQ"); noetasq = (e && e[0] == '1') ? 1 : 0; }
+  if (exponent == 2.0 && !noetasq) { q.eta_square = 1; q.gamma4 = 0.25 * gamma; }
   const bool last = k == d - 1;
   if (!last) {
     if (k == 0) { q.nouter = 1; q.qmax = s0; q.gi = {0, 1, s0}; }         // lines along dimension 0: every (i1, i2)
@@ -955,7 +959,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);             // w = eta*gradu (:511), :521-528
     if (rc) return rc;
   } else if (ell_fused4_ok(op)) {
-    for (int k = 0; k < d; k++) if ((rc = ell_fused4_function(op, k, b, rhs, st))) return rc;   // includes rhs -= b (:530)
+    for (int k = 0; k < d; k++) if ((rc = ell_fused4_function(op, k, gamma, exponent, b, rhs, st))) return rc;   // includes rhs -= b (:530)
     return 0;
   } else {
     // fused: gradu[k] = D_k w0 is stored on the way (:497-499), w_k = eta gradu[k] (:511) feeds the

@@ -45,7 +45,7 @@ constexpr int f4_lds_doubles() {
 
 #define AO4(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
 
-template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN>
+template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ>
 __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) {
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   static_assert(KS >= 16 && CH >= 1, "two sub-tiles per tile");
   static_assert(!WIN || (JFAST && ACC && !FULL), "the window mode is the last launch of FormFunction");
   static_assert(!JFAST || ACC, "the contiguous direction is never the first one");
+  static_assert(!ETASQ || !FULL, "eta = 1 + gamma u^2 formed on chip: FormFunction only (the line being differentiated is u)");
 
   __shared__ double smem[f4_lds_doubles<KS, JFAST>()];
   double *inE = smem, *inO = smem + LDS_ELEMS, *fE_ = smem + 2 * LDS_ELEMS, *fO_ = smem + 3 * LDS_ELEMS;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
 
   typename std::conditional<FULL, d2, double>::type cv_hi[4], cv_lo[4];  // coefficients of the sub-tile in flight
   u32 tv1[JFAST ? 4 : 1];                                               // their masked tile offsets (gradient store)
-  double ue[FULL ? 4 : 1], uo[FULL ? 4 : 1];
+  double ue[(FULL || ETASQ) ? 4 : 1], uo[(FULL || ETASQ) ? 4 : 1];
 
   auto coef_issue = [&](u32 tl, int sub) {
     const u32 o = tile_o(tl), q0 = (tl - o * tpo) * NT;
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
         tv1[JFAST ? r : 0] = (q < qmax) ? t0 : T_INVALID;               // lines past the block's end
       }
       const u32 tv = tv1[JFAST ? r : 0];
-      if constexpr (F4_ABLATE & 1) {
+      if constexpr (ETASQ) { (void)tv; }                                // eta comes from the tile image, see epi1
+      else if constexpr (F4_ABLATE & 1) {
         if constexpr (FULL) { cv_hi[r] = d2{1.0, 0.5}; cv_lo[r] = d2{1.0, 0.25}; } else { cv_hi[r] = 1.0; cv_lo[r] = 1.5; }
         (void)tv;
       } else if constexpr (FULL) { cv_hi[r] = ld16(r_coef, k_hi[r] + tv); cv_lo[r] = ld16(r_coef, k_lo[r] + tv); }
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
     }
   };
   auto u_read = [&](int sub) {
-    if constexpr (FULL) {
+    if constexpr (FULL || ETASQ) {
       const int f0 = f_idx0(sub);
 #pragma unroll
       for (int r = 0; r < 4; r++) { ue[r] = inE[f0 + r * f_r]; uo[r] = inO[f0 + r * f_r]; }
@@ -217,7 +219,13 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
       } else {
         st8(r_gout, k_hi[r] + tv1[JFAST ? r : 0], gi);                  // c->gradu[k], elliptic.C:498
         st8(r_gout, k_lo[r] + tv1[JFAST ? r : 0], gm);
-        fi = cv_hi[r] * gi; fm = cv_lo[r] * gm;                         // eta * g, elliptic.C:511
+        if constexpr (ETASQ) {
+          // eta = 1 + gamma u^2 (elliptic.C:508 with the default exponent) from the u the tile image holds (2 u_i = e + o,
+          // 2 u_{n-i} = e - o): two multiply-adds instead of 8 bytes from HBM per value -- a byte costs the package about
+          // twenty times what a flop does
+          const double si = ue[r] + uo[r], sm = ue[r] - uo[r];
+          fi = __builtin_fma(p.gamma4 * si, si, 1.0) * gi; fm = __builtin_fma(p.gamma4 * sm, sm, 1.0) * gm;
+        } else { fi = cv_hi[r] * gi; fm = cv_lo[r] * gm; }              // eta * g, elliptic.C:511
       }
       fE_[f0 + r * f_r] = fi + fm;
       fO_[f0 + r * f_r] = fi - fm;
@@ -424,9 +432,9 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
 
 bool fused4_eligible(const DiffMat &m) { return (m.KS == 16 || m.KS == 32) && (m.P & 1) == 0 && m.fragE2 && m.sym == 0; }
 
-template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN>
+template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ = false>
 static hipError_t launch4(const Fused4Params &p, unsigned grid, hipStream_t stream) {
-  hipLaunchKernelGGL((cheb_fused4_kernel<KS, JFAST, FULL, ACC, WIN>), dim3(grid), dim3(512), 0, stream, p);
+  hipLaunchKernelGGL((cheb_fused4_kernel<KS, JFAST, FULL, ACC, WIN, ETASQ>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
 }
@@ -442,13 +450,20 @@ static hipError_t launch4_ks(Fused4Params &p, bool jfast, bool full, bool acc, b
   hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
   if (cu_err != hipSuccess) return cu_err;
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
+  const bool sq = p.eta_square != 0;                      // FormFunction with exponent 2: eta formed on chip
+  if (full && sq) return hipErrorInvalidValue;
   if (jfast) {
     if (!acc) return hipErrorInvalidValue;
-    if (win) return full ? hipErrorInvalidValue : launch4<KS, true, false, true, true>(p, grid, stream);
-    return full ? launch4<KS, true, true, true, false>(p, grid, stream) : launch4<KS, true, false, true, false>(p, grid, stream);
+    if (win) {
+      if (full) return hipErrorInvalidValue;
+      return sq ? launch4<KS, true, false, true, true, true>(p, grid, stream) : launch4<KS, true, false, true, true>(p, grid, stream);
+    }
+    if (full) return launch4<KS, true, true, true, false>(p, grid, stream);
+    return sq ? launch4<KS, true, false, true, false, true>(p, grid, stream) : launch4<KS, true, false, true, false>(p, grid, stream);
   }
   if (win) return hipErrorInvalidValue;
   if (full) return acc ? launch4<KS, false, true, true, false>(p, grid, stream) : launch4<KS, false, true, false, false>(p, grid, stream);
+  if (sq) return acc ? launch4<KS, false, false, true, false, true>(p, grid, stream) : launch4<KS, false, false, false, false, true>(p, grid, stream);
   return acc ? launch4<KS, false, false, true, false>(p, grid, stream) : launch4<KS, false, false, false, false>(p, grid, stream);
 }
 
@@ -460,7 +475,7 @@ hipError_t fused4_launch(const DiffMat &m, Fused4Params p, bool jfast, bool full
   if (p.in_bytes >= lim || p.coef_bytes >= lim || p.gout_bytes >= lim || p.acc_bytes >= lim || p.out_bytes >= lim || p.sub_bytes >= lim)
     return hipErrorInvalidValue;
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
-  if (!al(p.in) || !al(p.coef) || !al(p.out) || (acc && !al(p.acc))) return hipErrorInvalidValue;
+  if (!al(p.in) || (!p.eta_square && !al(p.coef)) || !al(p.out) || (acc && !al(p.acc))) return hipErrorInvalidValue;
   if (jfast) { if ((p.gi.os | p.gi.ls) & 1) return hipErrorInvalidValue; }
   else if ((p.gi.os | p.gi.rs | p.go.os | p.go.rs | p.qmax) & 1 || (acc && ((p.ga.os | p.ga.rs) & 1))) return hipErrorInvalidValue;
   return m.KS == 16 ? launch4_ks<16>(p, jfast, full, acc, win, stream) : launch4_ks<32>(p, jfast, full, acc, win, stream);

@@ -118,6 +118,7 @@ struct Fused4Params {
   double *out; F4Geom go; unsigned out_bytes;                  // trimmed in the Jacobian mode and in the window mode
   const double *sub; unsigned sub_bytes;                       // window mode: out -= sub (geometry go), may be null
   double alpha;
+  int eta_square; double gamma4;                               // eta mode: eta = 1 + 4 gamma4 u^2 is formed from the line itself (coef is not read)
   const double *fragE2, *fragO2;
 };
 // full: Jacobian mode (coefficient pairs, trimmed vectors); acc: out = acc + alpha t; win (JFAST only): `out` and `sub`
