@@ -41,16 +41,21 @@ while time.time() - t0 < budget:
         rank = int(rng.integers(1, 4)); dims = rand_dims(rank, 3, 48 if rank > 1 else 200, 120000)
         if rank == 2 and rng.random() < 0.1:
             dims = (int(rng.integers(257, 400)), int(rng.integers(3, 12)))[::int(rng.choice([1, -1]))]
+        elif rank in (2, 3) and rng.random() < 0.35:
+            # the shapes of cheb_fused4_kernel / the padded-W path: even extents of 66..256 points, mixed KS = 16 / 32
+            hi = 256 if rank == 2 else 110
+            dims = tuple(int(2 * rng.integers(33, hi // 2 + 1)) for _ in range(rank))
+            if rng.random() < 0.3: dims = dims[:-1] + (int(rng.choice([66, 128, 130, 254, 256])),)
         op = sp.EllipticOp(dims)
         U = rng.standard_normal(op.global_size)
-        note("ell-lin", rel(op.mult_host(U), orc.elliptic_mult(dims, U, mode=orc.FAST)), dims)
+        note("ell-lin", rel(op.mult_host(U), orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=8)), dims)
         u = rng.random(op.global_size) + 0.5; b = rng.standard_normal(op.global_size); dv = rng.random(op.dirichlet_size) + 0.5
         gam, ex = float(rng.random() * 3), float(rng.choice([1.0, 2.0, 3.0, 2.5]))
         op.set_dirichlet(dv)
         r = op.function_host(u, b, gam, ex)
-        ro, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, gam, ex, mode=orc.FAST)
+        ro, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, gam, ex, mode=orc.FAST, nthreads=8)
         note("ell-fn", rel(r, ro), (dims, gam, ex))
-        note("ell-jac", rel(op.mult_host(U), orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST)), (dims, gam, ex))
+        note("ell-jac", rel(op.mult_host(U), orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST, nthreads=8)), (dims, gam, ex))
         op.destroy()
     elif kind == 2:      # Stokes
         d = int(rng.integers(2, 4)); dims = rand_dims(d, 3, 40 if d == 2 else 22, 12000)
