@@ -643,6 +643,10 @@ static bool use_unfused() {
   return v == 1;
 }
 
+// the 16-byte kernels with per-array geometry need 16-B aligned MatShell vectors (hipMalloc and PETSc give them); a vector that
+// is not goes through the general kernels
+static inline bool aligned16(const void *q) { return ((size_t)q & 15) == 0; }
+
 // ---- the straight-line fused kernel (fused4.hip): d = 2, 3, every extent even and 66..256, no slab ----
 static bool ell_fused4_ok(ell_op *op) {
   if (op->slab || op->has_long || (op->d != 2 && op->d != 3) || op->G == 0) return false;
@@ -843,7 +847,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
     //            of D D (constant coefficient), cheb_sweep_kernel, half the MFMA work;
     //  two-stage (CHEBHIP_TWO_STAGE=1 / chebhip_debug_two_stage): the same fused gradient ->
     //            flux -> divergence kernel the variable-coefficient path uses.
-    if (op->wpad && !use_two_stage() && !(sweep_get_variant() & 4)) {
+    if (op->wpad && !use_two_stage() && !(sweep_get_variant() & 4) && aligned16(U) && aligned16(V)) {
       // d = 2, 3 with lines of more than 64 points: the accumulator W keeps its rows padded to a multiple of
       // 128 B (pitch wpad), so that the strided launches read and write whole cache lines of it; U and V stay
       // dense.  Tiles of the strided directions are (outer index, 32 neighbouring points of the last dimension).
@@ -894,7 +898,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
                          (const double *)op->gradu[k], (double2 *)op->cprod[k]);
     op->cdirty = false;
   }
-  if (op->wpad && ell_fused4_ok(op)) {
+  if (op->wpad && ell_fused4_ok(op) && aligned16(U) && aligned16(V)) {
     for (int k = 0; k < op->d; k++) { int rc = ell_fused4_jacobian(op, k, U, V, st); if (rc) return rc; }
     return 0;
   }
@@ -958,7 +962,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     if (op->G == 0) return 0;
     rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);             // w = eta*gradu (:511), :521-528
     if (rc) return rc;
-  } else if (ell_fused4_ok(op)) {
+  } else if (ell_fused4_ok(op) && aligned16(rhs)) {
     for (int k = 0; k < d; k++) if ((rc = ell_fused4_function(op, k, gamma, exponent, b, rhs, st))) return rc;   // includes rhs -= b (:530)
     return 0;
   } else {

@@ -238,6 +238,37 @@ def test_elliptic_mult_256_vs_oracle():
     op.destroy()
 
 
+def test_elliptic_misaligned_vectors_take_the_general_kernels():
+    """MatShell vectors that are only 8-byte aligned (a sub-vector of a bigger allocation): the 16-byte kernels with
+    per-array geometry do not apply; the general kernels must give the same answers (linear matvec, FormFunction, Jacobian)."""
+    import torch
+    dims = (68, 70, 72)
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED + 11)
+    n = op.global_size
+
+    def off8(a=None):
+        buf = torch.empty(n + 1, dtype=torch.float64, device="cuda")
+        v = buf[1:]
+        assert v.data_ptr() % 16 == 8
+        if a is not None:
+            v.copy_(torch.from_numpy(a))
+        return v
+    Uh = rng.standard_normal(n)
+    U, V = off8(Uh), off8()
+    op.mult(U, V); torch.cuda.synchronize()
+    assert relerr(V.cpu().numpy(), orc.elliptic_mult(dims, Uh, mode=orc.FAST, nthreads=16)) < TOL
+    uh = rng.random(n) + 0.5; bh = rng.standard_normal(n); dv = rng.random(op.dirichlet_size) + 0.5
+    op.set_dirichlet(dv)
+    u, b, r = off8(uh), off8(bh), off8()
+    op.function(u, b, r, 1.5, 2.0); torch.cuda.synchronize()
+    rhs_o, eta, deta, gradu = orc.elliptic_function(dims, uh, bh, dv, 1.5, 2.0, mode=orc.FAST, nthreads=16)
+    assert relerr(r.cpu().numpy(), rhs_o) < TOL
+    op.mult(U, V); torch.cuda.synchronize()
+    assert relerr(V.cpu().numpy(), orc.elliptic_mult(dims, Uh, eta, deta, gradu, mode=orc.FAST, nthreads=16)) < TOL
+    op.destroy()
+
+
 def test_elliptic_nonlinear_256_vs_oracle():
     """BASELINE config 3 with variable coefficients (-gamma 4 -exponent 2, tests.sh:10) at full size: FormFunction and the
     Jacobian apply of cheb_fused4_kernel at 256^3 against the oracle (16 threads)."""
