@@ -51,6 +51,32 @@ __global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restric
   if (threadIdx.x == 0) part[(long)blockIdx.y * RB + blockIdx.x] = r;
 }
 
+// The same for k rows with w read once per group of KB rows instead of once per row (the orthogonalisation of restarted
+// GMRES is the largest mover of bytes in a preconditioned solve at 256^3): block (b, g) forms the partial sums of the rows
+// g KB .. g KB + KB - 1 over chunk b.  Every sum runs over the same elements in the same order as in k_multidot.
+constexpr int KB = 8;
+__global__ __launch_bounds__(RT) void k_multidot_grouped(long n, int k, const double *__restrict__ V, long ldv, const double *__restrict__ w,
+                                                         double *__restrict__ part) {
+  __shared__ double sh[RT / 64];
+  const int kk0 = blockIdx.y * KB;
+  const double *v[KB];
+#pragma unroll
+  for (int q = 0; q < KB; q++) v[q] = V + (long)(kk0 + q < k ? kk0 + q : k - 1) * ldv;   // rows past the end: a row read again, dropped below
+  double s[KB];
+#pragma unroll
+  for (int q = 0; q < KB; q++) s[q] = 0.0;
+  for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)RB * RT) {
+    const double wi = w[i];
+#pragma unroll
+    for (int q = 0; q < KB; q++) s[q] += v[q][i] * wi;
+  }
+#pragma unroll
+  for (int q = 0; q < KB; q++) {
+    const double r = block_sum(s[q], sh);
+    if (threadIdx.x == 0 && kk0 + q < k) part[(long)(kk0 + q) * RB + blockIdx.x] = r;
+  }
+}
+
 // out[row] = sum_b part[row][b] (fixed order), optionally the square root; one block per row
 __global__ __launch_bounds__(RT) void k_rows_finish(const double *__restrict__ part, double *__restrict__ out, int take_sqrt) {
   __shared__ double sh[RT / 64];
@@ -303,7 +329,7 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       if (M) { double *z = k->Z + (long)j * ld; if ((rc = M(mctx, vj, z, st))) return rc; zj = z; }
       double *w = k->V + (long)(j + 1) * ld;
       if ((rc = A(actx, zj, w, st))) return rc;
-      hipLaunchKernelGGL(k_multidot, dim3(RB, j + 1), dim3(RT), 0, st, n, (const double *)k->V, ld, (const double *)w, k->part);
+      hipLaunchKernelGGL(k_multidot_grouped, dim3(RB, (j + KB) / KB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       if (!k->reduce) {
         hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
         hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
