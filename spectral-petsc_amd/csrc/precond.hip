@@ -102,6 +102,18 @@ __global__ void k_modal_scale(Geo geo, long G, int nf, LamPtrs lam, double *__re
     t[q] = t[q] / s;
   }
 }
+// The same for d <= 3 without an integer-division chain per element (four 64-bit divisions cost more than the pass moves):
+// block (x, line, field) scales a piece of one line of the last dimension; the line's indices are formed once per block.
+__global__ __launch_bounds__(256) void k_modal_scale3(int d, int n1, int nl, long G, const double *__restrict__ l0, const double *__restrict__ l1,
+                                                      const double *__restrict__ l2, double *__restrict__ t) {
+  const unsigned line = blockIdx.y;                       // d = 3: i0 * n1 + i1; d = 2: i0; d = 1: 0
+  double s = 0.0;
+  if (d == 3) { const unsigned i0 = line / (unsigned)n1, i1 = line - i0 * (unsigned)n1; s = l0[i0] + l1[i1]; }
+  else if (d == 2) s = l0[line];
+  const double *ll = d == 3 ? l2 : (d == 2 ? l1 : l0);
+  double *row = t + (long)blockIdx.z * G + (long)line * nl;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nl; i += gridDim.x * 256) row[i] = row[i] / (s + ll[i]);
+}
 
 // out = (a - (y ? y : 0)) / eta_g  on nf stacked fields
 __global__ void k_resid_over_eta(long G, int nf, const double *__restrict__ a, const double *__restrict__ y,
@@ -110,8 +122,19 @@ __global__ void k_resid_over_eta(long G, int nf, const double *__restrict__ a, c
 }
 
 // node-major interleaved (I nodes x d components, the reference's velocity vectors) <-> component-major
-__global__ void k_deinterleave(long G, int nf, const double *__restrict__ a, double *__restrict__ b) { GS_LOOP(q, G * nf) { const long f = q / G, g = q - f * G; b[q] = a[g * nf + f]; } }
-__global__ void k_interleave(long G, int nf, const double *__restrict__ b, double *__restrict__ a) { GS_LOOP(q, G * nf) { const long f = q / G, g = q - f * G; a[g * nf + f] = b[q]; } }
+// one thread per node: its nf values are contiguous on the node-major side (a wave moves 64 nf contiguous doubles) and
+// coalesced field by field on the other
+__global__ void k_deinterleave(long G, int nf, const double *__restrict__ a, double *__restrict__ b) {
+  GS_LOOP(g, G) { for (int f = 0; f < nf; f++) b[(long)f * G + g] = a[g * nf + f]; }
+}
+__global__ void k_interleave(long G, int nf, const double *__restrict__ b, double *__restrict__ a) {
+  GS_LOOP(g, G) { for (int f = 0; f < nf; f++) a[g * nf + f] = b[(long)f * G + g]; }
+}
+// out (component-major) = a (node-major) / eta_g: the first step of P_1^-1 (1/eta) on the Stokes velocity vectors, without a
+// component-major copy of the right-hand side in between
+__global__ void k_deinterleave_over_eta(long G, int nf, const double *__restrict__ a, const double *__restrict__ eta_g, double *__restrict__ out) {
+  GS_LOOP(g, G) { const double e = eta_g[g]; for (int f = 0; f < nf; f++) out[(long)f * G + g] = a[g * nf + f] / e; }
+}
 
 struct LineMats { DiffMat Fcs, Fca, Bcs, Bca, Fraw, Braw; double *lam = nullptr; bool ok = false; };
 
@@ -255,7 +278,16 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
   double *a = pc->t0, *b = pc->t1;
   for (int k = 0; k < d; k++) { int rc = line_transform(pc, k, false, src, a, st); if (rc) return rc; src = a; std::swap(a, b); }
   LamPtrs lam; for (int k = 0; k < MAXD; k++) lam.p[k] = k < d ? pc->lines[pc->geo.dims[k]].lam : nullptr;
-  hipLaunchKernelGGL(k_modal_scale, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, lam, (double *)src);
+  {
+    const int nl = pc->geo.dims[d - 1] - 2;
+    const long lines = pc->G / nl;
+    if (d <= 3 && lines <= 65535 && pc->nf <= 65535) {
+      const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
+      hipLaunchKernelGGL(k_modal_scale3, dim3((unsigned)((nl + 255) / 256), (unsigned)lines, (unsigned)pc->nf), dim3(256), 0, st, d, n1, nl, pc->G,
+                         lam.p[0], lam.p[1], lam.p[2], (double *)src);
+    } else
+      hipLaunchKernelGGL(k_modal_scale, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, lam, (double *)src);
+  }
   for (int k = d - 1; k >= 0; k--) {
     double *dst = (k == 0) ? z : a;
     int rc = line_transform(pc, k, true, src, dst, st); if (rc) return rc;
@@ -270,9 +302,9 @@ static int fdpc_mult(chebhip_fdpc *pc, const double *x, double *y, hipStream_t s
   if (pc->G == 0) return 0;
   const long n = pc->G * pc->nf;
   const double *xin = x; double *yout = y;
-  if (pc->interleaved) { hipLaunchKernelGGL(k_deinterleave, dim3(pgrid(n)), dim3(256), 0, st, pc->G, pc->nf, x, pc->t2); xin = pc->t2; yout = pc->t3; }
+  if (pc->interleaved) { hipLaunchKernelGGL(k_deinterleave, dim3(pgrid(pc->G)), dim3(256), 0, st, pc->G, pc->nf, x, pc->t2); xin = pc->t2; yout = pc->t3; }
   hipLaunchKernelGGL(k_fd_mult, dim3(pgrid(n)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, (const double *)pc->cf, xin, yout);
-  if (pc->interleaved) hipLaunchKernelGGL(k_interleave, dim3(pgrid(n)), dim3(256), 0, st, pc->G, pc->nf, (const double *)pc->t3, y);
+  if (pc->interleaved) hipLaunchKernelGGL(k_interleave, dim3(pgrid(pc->G)), dim3(256), 0, st, pc->G, pc->nf, (const double *)pc->t3, y);
   PHIPCHK(hipGetLastError());
   return 0;
 }
@@ -295,13 +327,16 @@ static int fdpc_apply(chebhip_fdpc *pc, const double *r, double *z, hipStream_t 
   if (!pc->assembled) { int rc = fdpc_update(pc, st); if (rc) return rc; }
   if (pc->G == 0) return 0;
   const long n = pc->G * pc->nf;
-  const unsigned grid = pgrid(n);
   // component-major copies of r and of the iterate where the ABI vectors are node-major (Stokes velocity)
   const double *rin = r; double *zc = z;
-  if (pc->interleaved) { hipLaunchKernelGGL(k_deinterleave, dim3(grid), dim3(256), 0, st, pc->G, pc->nf, r, pc->t2); rin = pc->t2; zc = pc->t4; }
-  if (pc->sweeps == 0) {                       // z = P_1^-1 (r / eta)
+  if (pc->interleaved && pc->sweeps == 0) {    // z = P_1^-1 (r / eta), the division applied while the components are pulled apart
+    zc = pc->t4;
+    hipLaunchKernelGGL(k_deinterleave_over_eta, dim3(pgrid(pc->G)), dim3(256), 0, st, pc->G, pc->nf, r, (const double *)pc->eta_g, pc->t3);
+    int rc = fdm_solve(pc, pc->t3, zc, st); if (rc) return rc;
+  } else if (pc->sweeps == 0) {                // z = P_1^-1 (r / eta)
     int rc = cb_fdm(pc, rin, zc, st); if (rc) return rc;
   } else {
+    if (pc->interleaved) { hipLaunchKernelGGL(k_deinterleave, dim3(pgrid(pc->G)), dim3(256), 0, st, pc->G, pc->nf, r, pc->t2); rin = pc->t2; zc = pc->t4; }
     // `sweeps` iterations of GMRES on P z = r, right-preconditioned by P_1^-1 (1/eta): monotone in the residual for
     // any coefficient state (a stationary defect correction diverges once eta varies by more than a factor ~2)
     if (!pc->inner || pc->inner_m != pc->sweeps) {
@@ -313,7 +348,7 @@ static int fdpc_apply(chebhip_fdpc *pc, const double *r, double *z, hipStream_t 
     int rc = chebhip_fgmres_set_tolerances(pc->inner, 1e-12, 1e-300, pc->sweeps); if (rc) return rc;
     if ((rc = chebhip_fgmres_solve(pc->inner, cb_fd_mult, pc, cb_fdm, pc, rin, zc, 0, st))) return rc;
   }
-  if (pc->interleaved) hipLaunchKernelGGL(k_interleave, dim3(grid), dim3(256), 0, st, pc->G, pc->nf, (const double *)zc, z);
+  if (pc->interleaved) hipLaunchKernelGGL(k_interleave, dim3(pgrid(pc->G)), dim3(256), 0, st, pc->G, pc->nf, (const double *)zc, z);
   PHIPCHK(hipGetLastError());
   return 0;
 }

@@ -40,16 +40,26 @@ __global__ void k_merge(long I, int d, const double *__restrict__ v, int addv, c
 }
 // a = s * a + (b ? b : 0)
 __global__ void k_scale_add(long n, double s, double *__restrict__ a, const double *__restrict__ b) { GS_LOOP(q, n) a[q] = s * a[q] + (b ? b[q] : 0.0); }
-// out = in - mean(in): MatNullSpaceRemove with the constant vector; one block, fixed summation order
-__global__ __launch_bounds__(1024) void k_remove_mean(long n, const double *__restrict__ in, double *__restrict__ out) {
-  __shared__ double sh[1024];
+// out = in - mean(in): MatNullSpaceRemove with the constant vector, in two launches with a fixed summation order
+// (256 chunk sums, then every block adds the 256 partials in the same order).  The first version summed the vector in ONE
+// workgroup: 1.08 ms per call at 128^3, 39 % of the device time of the config-5 solve (profiles/r02_stokes_power_kernel_summary.txt).
+constexpr int MEAN_RB = 256, MEAN_RT = 256;
+__global__ __launch_bounds__(MEAN_RT) void k_mean_partial(long n, const double *__restrict__ in, double *__restrict__ part) {
+  __shared__ double sh[MEAN_RT];
   double s = 0.0;
-  for (long q = threadIdx.x; q < n; q += 1024) s += in[q];
+  for (long q = blockIdx.x * (long)MEAN_RT + threadIdx.x; q < n; q += (long)MEAN_RB * MEAN_RT) s += in[q];
   sh[threadIdx.x] = s;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  for (int o = MEAN_RT / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(MEAN_RT) void k_mean_subtract(long n, const double *__restrict__ part, const double *in, double *out) {   // in == out allowed
+  __shared__ double sh[MEAN_RB];
+  sh[threadIdx.x] = part[threadIdx.x];
+  __syncthreads();
+  for (int o = MEAN_RB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
   const double mean = sh[0] / (double)n;
-  for (long q = threadIdx.x; q < n; q += 1024) out[q] = in[q] - mean;
+  GS_LOOP(q, n) out[q] = in[q] - mean;
 }
 }  // namespace
 
@@ -59,6 +69,7 @@ struct stokes_saddle {
   int d = 0; long I = 0, gv = 0, gp = 0, g = 0;
   int type = 0;                                    // -pc_saddle_type (stokes.C:177-187)
   double *v0 = nullptr, *v1 = nullptr, *p0 = nullptr, *p1 = nullptr;      // vG0, vG1, pG0, pG1 (stokes.C:56-57)
+  double *red = nullptr;                           // partial sums of remove_mean
   chebhip_fgmres *kvel = nullptr, *kschur = nullptr, *ksvel = nullptr;
   // restart / max_it / rtol per inner solve; max_it 0 = "preonly": one application of the preconditioner
   int m_vel = 4, m_schur = 3, m_svel = 0;
@@ -77,10 +88,15 @@ static int svel_solve(void *ctx, const double *rhs, double *sol, void *stream) {
 // MatSchur followed by the removal of the constant: KSPSchur carries the constant null space (stokes.C:1020-1021) and
 // PETSc's (left-preconditioned) GMRES removes it from every vector it builds, i.e. it solves  P S x = P b  on
 // zero-mean vectors, P = I - 1 1^T / n.  (S P z = b would be inconsistent: S is singular and not symmetric.)
+static void remove_mean(stokes_saddle *s, const double *in, double *out, hipStream_t st) {
+  unsigned g = (unsigned)((s->gp + MEAN_RT - 1) / MEAN_RT); if (g < 1) g = 1; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_mean_partial, dim3(MEAN_RB), dim3(MEAN_RT), 0, st, s->gp, in, s->red);
+  hipLaunchKernelGGL(k_mean_subtract, dim3(g), dim3(MEAN_RT), 0, st, s->gp, (const double *)s->red, in, out);
+}
 static int schur_apply(void *ctx, const double *x, double *y, void *stream) {
   stokes_saddle *s = (stokes_saddle *)ctx;
   int rc = stokes_op_mult_schur(s->op, x, y, svel_solve, s, stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, s->gp, (const double *)y, y);
+  remove_mean(s, y, y, (hipStream_t)stream);
   SHIPCHK2(hipGetLastError());
   return 0;
 }
@@ -94,7 +110,7 @@ static int vel_solve(stokes_saddle *s, const double *b, double *x, void *stream)
 }
 // KSPSolve(KSPSchur, b, x); b is overwritten by its zero-mean part
 static int schur_solve(stokes_saddle *s, double *b, double *x, void *stream) {
-  hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, s->gp, (const double *)b, b);
+  remove_mean(s, b, b, (hipStream_t)stream);
   int rc = chebhip_fgmres_set_tolerances(s->kschur, s->rtol_schur, 1e-50, s->m_schur > 0 ? s->m_schur : 1); if (rc) return rc;
   rc = chebhip_fgmres_solve(s->kschur, schur_apply, s, nullptr, nullptr, b, x, 0, stream);
   s->its_schur += chebhip_fgmres_iterations(s->kschur);
@@ -107,7 +123,7 @@ extern "C" int stokes_saddle_destroy(stokes_saddle *s) {
   if (s->kschur) chebhip_fgmres_destroy(s->kschur);
   if (s->ksvel) chebhip_fgmres_destroy(s->ksvel);
   if (s->vvpc) chebhip_fdpc_destroy(s->vvpc);
-  double *all[] = {s->v0, s->v1, s->p0, s->p1};
+  double *all[] = {s->v0, s->v1, s->p0, s->p1, s->red};
   for (double *p : all) if (p) (void)hipFree(p);
   delete s;
   return 0;
@@ -129,7 +145,8 @@ extern "C" int stokes_saddle_create(stokes_op *op, stokes_saddle **out) {
   if (rc) { stokes_saddle_destroy(s); return rc; }
   const size_t nv = (size_t)(s->gv > 0 ? s->gv : 1) * sizeof(double), np = (size_t)(s->gp > 0 ? s->gp : 1) * sizeof(double);
   if (hipMalloc((void **)&s->v0, nv) != hipSuccess || hipMalloc((void **)&s->v1, nv) != hipSuccess ||
-      hipMalloc((void **)&s->p0, np) != hipSuccess || hipMalloc((void **)&s->p1, np) != hipSuccess) {
+      hipMalloc((void **)&s->p0, np) != hipSuccess || hipMalloc((void **)&s->p1, np) != hipSuccess ||
+      hipMalloc((void **)&s->red, MEAN_RB * sizeof(double)) != hipSuccess) {
     stokes_saddle_destroy(s); return chebhip_fail(CHEBHIP_ERR_MEMORY, "device allocation failed");
   }
   *out = s;
@@ -187,7 +204,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
       if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1           (:1734)
       hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)nullptr);   // v0 <- -v0 (:1735)
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0          (:1736)
-      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);      // KSPSetNullSpace (:1019)
+      remove_mean(s, s->p1, s->p1, st);      // KSPSetNullSpace (:1019)
       MERGE(s->v1, 1, s->p1);                                                      // y_v += v1, y_p <- p1   (:1733,1737)
       break;
     case 1:   // block upper triangular (stokes.C:1747-1765)
@@ -196,14 +213,14 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
       if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1
       hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)s->v1);   // v0 <- -v0 + x_v
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
-      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);
+      remove_mean(s, s->p1, s->p1, st);
       MERGE(s->v1, 0, s->p1);
       break;
     case 2:   // block diagonal (stokes.C:1772-1790)
       SPLIT(s->v0, s->p0);
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;
-      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);
+      remove_mean(s, s->p1, s->p1, st);
       MERGE(s->v1, 0, s->p1);
       break;
     default:  // block lower triangular (stokes.C:1797-1816)
@@ -213,7 +230,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
       hipLaunchKernelGGL(k_scale_add, dim3(gpn), dim3(256), 0, st, s->gp, -1.0, s->p0, (const double *)s->p1);   // p0 <- -p0 + x_p
       MERGE(s->v1, 0, nullptr);                                                    // y_v <- v1 (before v1 is reused by the Schur solve)
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0
-      hipLaunchKernelGGL(k_remove_mean, dim3(1), dim3(1024), 0, st, s->gp, (const double *)s->p1, s->p1);
+      remove_mean(s, s->p1, s->p1, st);
       MERGE((const double *)nullptr, 0, s->p1);
       break;
   }
