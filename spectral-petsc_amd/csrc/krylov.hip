@@ -28,17 +28,22 @@ namespace {
 constexpr int RB = 256;      // reduction blocks per dot product
 constexpr int RT = 256;      // threads per block
 
-__device__ __forceinline__ double block_sum(double v, double *sh) {
-  // wave reduction by DPP-free shuffles, then 4 wave sums through LDS in a fixed order
+constexpr int ST = 1024;     // threads per block of the two kernels that stream the whole basis (16 waves per CU keep HBM busy;
+                             // with 256 the orthogonalisation of a 256^3 solve ran at 3 TB/s and was 34 % of its device time)
+
+template <int NT>
+__device__ __forceinline__ double block_sum_t(double v, double *sh) {
+  // wave reduction by DPP-free shuffles, then the wave sums through LDS in a fixed order
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) sh[w] = v;
   __syncthreads();
   double r = 0.0;
-  if (threadIdx.x == 0) { for (int q = 0; q < RT / 64; q++) r += sh[q]; }
+  if (threadIdx.x == 0) { for (int q = 0; q < NT / 64; q++) r += sh[q]; }
   __syncthreads();
   return r;   // valid in thread 0
 }
+__device__ __forceinline__ double block_sum(double v, double *sh) { return block_sum_t<RT>(v, sh); }
 
 // part[kk][b] = sum over chunk b of V[kk][i] * w[i],  kk = blockIdx.y < k
 __global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restrict__ V, long ldv, const double *__restrict__ w,
@@ -55,9 +60,9 @@ __global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restric
 // GMRES is the largest mover of bytes in a preconditioned solve at 256^3): block (b, g) forms the partial sums of the rows
 // g KB .. g KB + KB - 1 over chunk b.  Every sum runs over the same elements in the same order as in k_multidot.
 constexpr int KB = 8;
-__global__ __launch_bounds__(RT) void k_multidot_grouped(long n, int k, const double *__restrict__ V, long ldv, const double *__restrict__ w,
+__global__ __launch_bounds__(ST) void k_multidot_grouped(long n, int k, const double *__restrict__ V, long ldv, const double *__restrict__ w,
                                                          double *__restrict__ part) {
-  __shared__ double sh[RT / 64];
+  __shared__ double sh[ST / 64];
   const int kk0 = blockIdx.y * KB;
   const double *v[KB];
 #pragma unroll
@@ -65,14 +70,14 @@ __global__ __launch_bounds__(RT) void k_multidot_grouped(long n, int k, const do
   double s[KB];
 #pragma unroll
   for (int q = 0; q < KB; q++) s[q] = 0.0;
-  for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)RB * RT) {
+  for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
     const double wi = w[i];
 #pragma unroll
     for (int q = 0; q < KB; q++) s[q] += v[q][i] * wi;
   }
 #pragma unroll
   for (int q = 0; q < KB; q++) {
-    const double r = block_sum(s[q], sh);
+    const double r = block_sum_t<ST>(s[q], sh);
     if (threadIdx.x == 0 && kk0 + q < k) part[(long)(kk0 + q) * RB + blockIdx.x] = r;
   }
 }
@@ -88,12 +93,12 @@ __global__ void k_sqrt1(double *__restrict__ p) { if (threadIdx.x == 0 && blockI
 
 // h[kk] = sum_b dpart[kk][b] (every block forms the same sums in the same order; block 0 publishes them);
 // w -= sum_{kk<k} h[kk] V[kk];  npart[b] = sum over chunk b of w^2
-__global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double *__restrict__ V, long ldv,
+__global__ __launch_bounds__(ST) void k_orth_update(long n, int k, const double *__restrict__ V, long ldv,
                                                     const double *__restrict__ dpart, double *hcol,
                                                     double *__restrict__ w, double *__restrict__ npart) {
-  __shared__ double sh[RT / 64];
-  __shared__ double h[RT];
-  for (int kk = threadIdx.x; kk < k; kk += RT) {
+  __shared__ double sh[ST / 64];
+  __shared__ double h[ST];
+  for (int kk = threadIdx.x; kk < k; kk += ST) {
     double s = 0.0;
     if (dpart) { for (int q = 0; q < RB; q++) s += dpart[(long)kk * RB + q]; if (blockIdx.x == 0) hcol[kk] = s; }
     else s = hcol[kk];                            // several ranks: the sums were completed by the reduction callback
@@ -101,12 +106,17 @@ __global__ __launch_bounds__(RT) void k_orth_update(long n, int k, const double 
   }
   __syncthreads();
   double s = 0.0;
-  for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)RB * RT) {
+  for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
     double x = w[i];
-    for (int kk = 0; kk < k; kk++) x -= h[kk] * V[(long)kk * ldv + i];
+    int kk = 0;
+    for (; kk + 4 <= k; kk += 4) {                // four basis rows in flight per thread; the subtractions stay in row order
+      const double a0 = V[(long)kk * ldv + i], a1 = V[(long)(kk + 1) * ldv + i], a2 = V[(long)(kk + 2) * ldv + i], a3 = V[(long)(kk + 3) * ldv + i];
+      x -= h[kk] * a0; x -= h[kk + 1] * a1; x -= h[kk + 2] * a2; x -= h[kk + 3] * a3;
+    }
+    for (; kk < k; kk++) x -= h[kk] * V[(long)kk * ldv + i];
     w[i] = x; s += x * x;
   }
-  const double r = block_sum(s, sh);
+  const double r = block_sum_t<ST>(s, sh);
   if (threadIdx.x == 0) npart[blockIdx.x] = r;
 }
 
@@ -329,15 +339,15 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       if (M) { double *z = k->Z + (long)j * ld; if ((rc = M(mctx, vj, z, st))) return rc; zj = z; }
       double *w = k->V + (long)(j + 1) * ld;
       if ((rc = A(actx, zj, w, st))) return rc;
-      hipLaunchKernelGGL(k_multidot_grouped, dim3(RB, (j + KB) / KB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
+      hipLaunchKernelGGL(k_multidot_grouped, dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       if (!k->reduce) {
-        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
+        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
         hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
                            (const double *)nullptr);
       } else {            // several ranks: local sums -> all-reduce -> update; the same for |w|^2
         hipLaunchKernelGGL(k_rows_finish, dim3(j + 1), dim3(RT), 0, st, (const double *)k->part, k->hcol, 0);
         if ((rc = k->reduce(k->reduce_ctx, k->hcol, j + 1, st))) return rc;
-        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(RT), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)nullptr, k->hcol, w, k->npart);
+        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)nullptr, k->hcol, w, k->npart);
         hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->nsq, 0);
         if ((rc = k->reduce(k->reduce_ctx, k->nsq, 1, st))) return rc;
         hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)nullptr, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
