@@ -39,6 +39,24 @@ def test_fd_matrix_and_exact_solve_linear_state(dims):
     pc.destroy(); op.destroy()
 
 
+@pytest.mark.parametrize("dims", [(130, 70), (131, 70), (258, 20), (70, 68, 40)], ids=lambda d: "x".join(map(str, d)))
+def test_exact_solve_long_lines(dims):
+    """The same on lines of more than 64 interior points: the one-launch line transforms of the KS = 16 / 32 straight-line
+    kernel (halves stored / read unsplit), even and odd line lengths, both tilings.  P P^-1 x = x through the stencil apply
+    keeps the check free of a large sparse factorisation."""
+    op = sp.EllipticOp(dims)
+    pc = sp.FdPc(op, sweeps=0)
+    rng = np.random.default_rng(SEED + 5)
+    x = rng.standard_normal(op.global_size)
+    z = pc.apply(dev(x), out(op.global_size))
+    back = pc.mult(z, out(op.global_size)).cpu().numpy()
+    assert relerr(back, x) < 1e-9
+    if len(dims) == 2:
+        P = orc.fd_matrix(dims)
+        assert relerr(z.cpu().numpy(), spl.spsolve(P.tocsc(), x)) < 1e-9
+    pc.destroy(); op.destroy()
+
+
 @pytest.mark.parametrize("dims", [(14, 12), (10, 9, 8)], ids=lambda d: "x".join(map(str, d)))
 def test_fd_matrix_nonlinear_state(dims):
     """After FormFunction with gamma != 0 the stencil carries eta, deta and grad u (elliptic.C:571-575)."""
