@@ -167,9 +167,10 @@ def test_stokes_power_law_96_vs_oracle():
     _power_state_test((96, 80, 72), 16)
 
 
-@pytest.mark.parametrize("dims", [(96, 96, 96), (128, 128, 128)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("dims", [(96, 96, 96), (128, 128, 128), (136, 132, 130), (200, 140)], ids=lambda s: "x".join(map(str, s)))
 def test_stokes_blocks_large_vs_oracle(dims):
-    """Linear VV / PV / VP / MatMult on lines of 65..128 points (the KS = 16 kernels) vs the oracle."""
+    """Linear VV / PV / VP / MatMult on lines of 65..128 points (the KS = 16 kernels) and of 130..200 points (KS = 32, the
+    multi-job launches included) vs the oracle."""
     N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
     rng = np.random.default_rng(SEED)
     v, p, x = rng.standard_normal(gv), rng.standard_normal(gp), rng.standard_normal(g)
