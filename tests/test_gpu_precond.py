@@ -57,6 +57,24 @@ def test_exact_solve_long_lines(dims):
     pc.destroy(); op.destroy()
 
 
+def test_apply_on_vectors_that_are_only_8_byte_aligned():
+    """Sub-vectors at an odd offset: the 16-byte line-transform kernels do not apply, the two-launch general route must give
+    the same preconditioner."""
+    dims = (130, 70)
+    op = sp.EllipticOp(dims)
+    pc = sp.FdPc(op, sweeps=0)
+    n = op.global_size
+    x = np.random.default_rng(SEED + 6).standard_normal(n)
+    z_al = pc.apply(dev(x), out(n)).cpu().numpy()
+    bx = torch.empty(n + 1, dtype=torch.float64, device="cuda"); bz = torch.full((n + 1,), float("nan"), dtype=torch.float64, device="cuda")
+    xo, zo = bx[1:], bz[1:]
+    assert xo.data_ptr() % 16 == 8 and zo.data_ptr() % 16 == 8
+    xo.copy_(torch.from_numpy(x))
+    pc.apply(xo, zo); torch.cuda.synchronize()
+    assert relerr(zo.cpu().numpy(), z_al) < 1e-12
+    pc.destroy(); op.destroy()
+
+
 @pytest.mark.parametrize("dims", [(14, 12), (10, 9, 8)], ids=lambda d: "x".join(map(str, d)))
 def test_fd_matrix_nonlinear_state(dims):
     """After FormFunction with gamma != 0 the stencil carries eta, deta and grad u (elliptic.C:571-575)."""
