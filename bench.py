@@ -171,6 +171,83 @@ def extras(sp, torch):
     return out
 
 
+def solves(sp, torch):
+    """End-to-end solves of the callers of the hot path at the BASELINE sizes, after the timed region:
+    Newton + FGMRES(30) + the finite-difference preconditioner on the 256^3 elliptic problem (-gamma 4 -exponent 2),
+    the linear Stokes solve at 64^3 (config 4) and the power-law Stokes solve with continuation at 128^3 (config 5,
+    README:52) with the block preconditioner StokesPCApply0.  Manufactured: a smooth field x* with zero boundary values is
+    put through the operator itself to get the right-hand side, the solve starts from 0 and must come back to x*.
+    Wall seconds (synchronised) and the error against x*; informational."""
+    import importlib
+    import numpy as np
+    solve = importlib.import_module(sp.__name__ + ".solve")
+    out = {}
+
+    def nodes(P):
+        return np.cos(np.pi * np.arange(1, P - 1) / (P - 1))
+
+    def smooth(P, d, seed):
+        x = nodes(P)
+        rng = np.random.default_rng(seed)
+        f = np.ones((P - 2,) * d)
+        for k in range(d):
+            a, b = rng.random(2) + 0.5
+            g = (1.0 - x * x) * (1.0 + 0.3 * np.cos(2.0 * a * x + b))
+            f = f * g.reshape([-1 if j == k else 1 for j in range(d)])
+        return f
+
+    # --- elliptic 256^3, gamma 4 (tests.sh:10 parameters)
+    P = 256
+    op = sp.EllipticOp((P, P, P))
+    op.set_dirichlet(np.zeros(op.dirichlet_size))
+    us = torch.from_numpy(smooth(P, 3, 1).ravel()).cuda()
+    b = torch.empty_like(us)
+    op.function(us, None, b, 4.0, 2.0)                      # b = A(u*) u*
+    x = torch.zeros_like(us)
+    pc = sp.FdPc(op, sweeps=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-10, ksp_rtol=1e-6, ksp_restart=30, ksp_max_it=300, M=pc,
+                                        monitor=lambda i, f, k: pc.update())
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out["elliptic_256_gamma4"] = {"seconds": dt, "newton_its": its, "krylov_its": kits,
+                                  "rel_err_vs_manufactured": float((x - us).abs().max() / us.abs().max())}
+    pc.destroy(); op.destroy(); del us, b, x
+
+    # --- Stokes: linear 64^3 (config 4), power law with continuation 128^3 (config 5), on the reference's own manufactured
+    # problem -exact 2 (StokesExact2, stokes.C:1963-2012; README:43,52): u = sin(pi x/2) cos(pi y/2), v = -cos(pi x/2) sin(pi y/2),
+    # w = 0, p = 0, force (pi/2)^2 (u, v, 0, 0), Dirichlet values = the field on the boundary nodes (row-major node order,
+    # components innermost).  For the power law the force stays the linear one, as in the reference's run.
+    def exact2(P):
+        c = np.cos(np.pi * np.arange(P) / (P - 1))
+        X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+        u = np.sin(0.5 * np.pi * X) * np.cos(0.5 * np.pi * Y); v = -np.cos(0.5 * np.pi * X) * np.sin(0.5 * np.pi * Y)
+        val = np.stack([u, v, np.zeros_like(u), np.zeros_like(u)], axis=-1).reshape(-1, 4)
+        idx = np.arange(P)
+        bd1 = (idx == 0) | (idx == P - 1)
+        bd = (bd1[:, None, None] | bd1[None, :, None] | bd1[None, None, :]).ravel()
+        U = val[~bd]
+        rhs = U.copy(); rhs[:, :2] *= (0.5 * np.pi) ** 2; rhs[:, 2:] = 0.0
+        return U.ravel(), rhs.ravel(), np.ascontiguousarray(val[bd][:, :3]).ravel()
+
+    for P, rheo, cont, key in ((64, (0, 1.0, 1.0, 1.0, 1.0), 1, "stokes_64_linear_exact2"), (128, (1, 1.0, 3.0, 1e-4, 1.0), 4, "stokes_128_powerlaw_cont4_exact2")):
+        st = sp.StokesOp((P, P, P))
+        U, U2, dv = exact2(P)
+        st.set_dirichlet(dv); st.set_force(U2)
+        x = torch.zeros(st.global_size, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        log = solve.stokes_solve(sp, st, x, rheology=rheo, cont0=0, cont=cont, snes_rtol=1e-8, ksp_rtol=1e-5 if rheo[0] else 1e-10,
+                                 ksp_restart=60, ksp_max_it=200, max_linear_fail=50, snes_max_it=20)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        rec = {"seconds": dt, "stages": len(log), "newton_its": int(sum(s[2] for s in log)), "krylov_its": int(sum(s[3] for s in log)),
+               "residual_norm": float(log[-1][4])}
+        if not rheo[0]:                                     # the field is the exact solution of the linear problem only
+            xs = x.cpu().numpy().reshape(-1, 4); Us = U.reshape(-1, 4)
+            rec["max_velocity_err_vs_exact2"] = float(np.abs(xs[:, :3] - Us[:, :3]).max())
+        out[key] = rec
+        st.destroy(); del x
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -316,6 +393,11 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "matvecs/s", "cores": args.cpu_threads, "kind": "port", "sample": "failed: " + repr(e)[:160]}
             if out.get("parity") and out["parity"]["rel_l2_vs_oracle"] > out["parity"]["tolerance"]:
                 raise SystemExit("parity failure: GPU matvec differs from the oracle by %.3e" % out["parity"]["rel_l2_vs_oracle"])
+        if world == 1 and not args.no_extras:
+            try:
+                out["solves"] = solves(sp, torch)
+            except Exception as e:
+                out["solves_error"] = repr(e)[:300]
         if world == 1 and not args.no_extras:
             try:                                            # informational: never at the expense of the metric line
                 out["extras_us"] = extras(sp, torch)
