@@ -64,16 +64,25 @@ __global__ __launch_bounds__(ST) void k_multidot_grouped(long n, int k, const do
                                                          double *__restrict__ part) {
   __shared__ double sh[ST / 64];
   const int kk0 = blockIdx.y * KB;
+  const int cnt = k - kk0 < KB ? k - kk0 : KB;          // rows of this group (the inner solves of the Stokes preconditioner have 1..4)
   const double *v[KB];
 #pragma unroll
-  for (int q = 0; q < KB; q++) v[q] = V + (long)(kk0 + q < k ? kk0 + q : k - 1) * ldv;   // rows past the end: a row read again, dropped below
+  for (int q = 0; q < KB; q++) v[q] = V + (long)(kk0 + (q < cnt ? q : 0)) * ldv;
   double s[KB];
 #pragma unroll
   for (int q = 0; q < KB; q++) s[q] = 0.0;
-  for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
-    const double wi = w[i];
+  if (cnt == KB) {
+    for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
+      const double wi = w[i];
 #pragma unroll
-    for (int q = 0; q < KB; q++) s[q] += v[q][i] * wi;
+      for (int q = 0; q < KB; q++) s[q] += v[q][i] * wi;
+    }
+  } else {
+    for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
+      const double wi = w[i];
+#pragma unroll
+      for (int q = 0; q < KB; q++) if (q < cnt) s[q] += v[q][i] * wi;   // uniform: no load for a row that is not there
+    }
   }
 #pragma unroll
   for (int q = 0; q < KB; q++) {
