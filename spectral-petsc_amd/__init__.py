@@ -22,7 +22,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchebhip.so")
+# CHEBHIP_LIB_PATH: a diagnostic build of the same library (tools/v4_ablate.sh, tools/f4_ablate.sh); production uses the in-tree one
+LIB_PATH = os.environ.get("CHEBHIP_LIB_PATH") or os.path.join(_HERE, "libchebhip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 # every symbol include/chebhip.h declares (checked by tests/test_abi.py)
