@@ -171,6 +171,47 @@ def extras(sp, torch):
     return out
 
 
+def package_power(step, torch, seconds=2.5):
+    """Package power (W) of GPU 0 as rocm-smi reports it, sampled while the metric's matvec loops for a few seconds, and
+    once more after a pause: the headline kernel runs into the board's power cap, so the figure belongs
+    next to the rate.  Informational; None when rocm-smi is not usable."""
+    import re
+    import subprocess
+    import threading
+
+    def read():
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"GPU\[0\].*?Power \(W\):\s*([0-9.]+)", out)
+            return float(m.group(1)) if m else None
+        except Exception:
+            return None
+    vals = []
+    stop = [False]
+
+    def sampler():
+        time.sleep(0.8)
+        while not stop[0]:
+            v = read()
+            if v is not None:
+                vals.append(v)
+            time.sleep(0.3)
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    time.sleep(1.5)
+    idle = read()
+    if not vals:
+        return None
+    return {"package_w_under_matvec_loop": max(vals), "package_w_after_pause": idle, "samples": len(vals), "source": "rocm-smi --showpower, GPU[0]"}
+
+
 def solves(sp, torch):
     """End-to-end solves of the callers of the hot path at the BASELINE sizes, after the timed region:
     Newton + FGMRES(30) + the finite-difference preconditioner on the 256^3 elliptic problem (-gamma 4 -exponent 2),
@@ -393,6 +434,13 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "matvecs/s", "cores": args.cpu_threads, "kind": "port", "sample": "failed: " + repr(e)[:160]}
             if out.get("parity") and out["parity"]["rel_l2_vs_oracle"] > out["parity"]["tolerance"]:
                 raise SystemExit("parity failure: GPU matvec differs from the oracle by %.3e" % out["parity"]["rel_l2_vs_oracle"])
+        if world == 1 and not args.no_extras:
+            try:
+                pw = package_power(step, torch)
+                if pw:
+                    out["power"] = pw
+            except Exception as e:
+                out["power_error"] = repr(e)[:200]
         if world == 1 and not args.no_extras:
             try:
                 out["solves"] = solves(sp, torch)
