@@ -108,3 +108,39 @@ def test_vtk_dump(dims, tmp_path):
         for k in range(d):
             assert np.abs(T[:, j, k] - ref[j][:, k]).max() <= 1e-6 * max(1.0, np.abs(ref).max())
     st.destroy()
+
+
+def test_results_are_bitwise_reproducible():
+    """Every kernel sums in a fixed order (no atomics on data): the same call on the same input gives the same bits -- the
+    Poisson matvec, FormFunction + Jacobian apply, StokesMatMult, the preconditioner and a whole FGMRES solve."""
+    import numpy as np
+    import torch
+    torch.manual_seed(3)
+    op = sp.EllipticOp((132, 70, 68))
+    u = torch.rand(op.global_size, dtype=torch.float64, device="cuda") + 0.5
+    b = torch.randn_like(u)
+    outs = []
+    for _ in range(2):
+        v = torch.empty_like(u); r = torch.empty_like(u); j = torch.empty_like(u); z = torch.empty_like(u); x = torch.zeros_like(u)
+        lin = sp.EllipticOp((132, 70, 68)); lin.mult(b, v); lin.destroy()
+        op.set_dirichlet(np.full(op.dirichlet_size, 0.25))
+        op.function(u, b, r, 2.0, 2.0); op.mult(b, j)
+        pc = sp.FdPc(op, sweeps=0); pc.apply(b, z)
+        ks = sp.Fgmres(op.global_size, restart=10, rtol=1e-6, max_it=10)
+        ks.solve(op, b, x, M=pc)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (v, r, j, z, x)])
+        pc.destroy()
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    op.destroy()
+    st = sp.StokesOp((40, 36, 34))
+    st.set_dirichlet(np.zeros(st.dirichlet_size)); st.set_force(np.zeros(st.global_size)); st.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
+    xs = torch.randn(st.global_size, dtype=torch.float64, device="cuda")
+    ys = []
+    for _ in range(2):
+        f = torch.empty_like(xs); m = torch.empty_like(xs)
+        st.function(xs, f); st.mult(xs, m); torch.cuda.synchronize()
+        ys.append((f.clone(), m.clone()))
+    assert torch.equal(ys[0][0], ys[1][0]) and torch.equal(ys[0][1], ys[1][1])
+    st.destroy()
