@@ -144,3 +144,31 @@ def test_results_are_bitwise_reproducible():
         ys.append((f.clone(), m.clone()))
     assert torch.equal(ys[0][0], ys[1][0]) and torch.equal(ys[0][1], ys[1][1])
     st.destroy()
+
+
+def test_calls_on_a_non_default_stream():
+    """Every entry point takes the caller's stream: results on a side stream (with the default stream kept busy) equal those on
+    the default stream -- the Stokes pressure chain forks to the operator's own second stream and must join the caller's."""
+    import numpy as np
+    import torch
+    torch.manual_seed(11)
+    st = sp.StokesOp((48, 40, 36))
+    st.set_dirichlet(np.zeros(st.dirichlet_size)); st.set_force(np.zeros(st.global_size)); st.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
+    op = sp.EllipticOp((132, 70, 68)); op.set_dirichlet(np.full(op.dirichlet_size, 0.5))
+    xs = torch.randn(st.global_size, dtype=torch.float64, device="cuda")
+    u = torch.rand(op.global_size, dtype=torch.float64, device="cuda") + 0.5
+    ref = [torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(u), torch.empty_like(u)]
+    st.function(xs, ref[0]); st.mult(xs, ref[1]); op.function(u, None, ref[2], 1.0, 2.0); op.mult(u, ref[3])
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    out = [torch.full_like(r, float("nan")) for r in ref]
+    busy = torch.randn(4096, 4096, device="cuda")
+    for _ in range(3):
+        busy = busy @ busy * 1e-4                        # the default stream has work queued while the side stream runs
+    with torch.cuda.stream(side):
+        st.function(xs, out[0]); st.mult(xs, out[1]); op.function(u, None, out[2], 1.0, 2.0); op.mult(u, out[3])
+    side.synchronize()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    st.destroy(); op.destroy()
