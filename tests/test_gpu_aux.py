@@ -172,3 +172,38 @@ def test_calls_on_a_non_default_stream():
         assert torch.equal(a, b)
     torch.cuda.synchronize()
     st.destroy(); op.destroy()
+
+
+def test_two_host_threads_with_their_own_handles():
+    """One handle belongs to one host thread at a time, but two threads may drive two handles at once (ctypes releases the GIL):
+    the library's shared state -- lazily read environment switches, the CU-count cache, the timer registry, rocBLAS handles --
+    must not couple them."""
+    import threading
+    import numpy as np
+    import torch
+    results, errors = {}, []
+
+    def work(tag, dims, seed):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                op = sp.EllipticOp(dims)
+                g = torch.Generator(device="cuda").manual_seed(seed)
+                U = torch.randn(op.global_size, dtype=torch.float64, device="cuda", generator=g)
+                V = torch.empty_like(U); acc = torch.zeros_like(U)
+                for _ in range(40):
+                    op.mult(U, V); acc += V
+                s.synchronize()
+                results[tag] = (U.cpu().numpy(), (acc / 40).cpu().numpy(), dims)
+                op.destroy()
+        except Exception as e:                              # surfaced in the main thread
+            errors.append(repr(e))
+    ts = [threading.Thread(target=work, args=("a", (132, 70, 68), 1)), threading.Thread(target=work, args=("b", (40, 300), 2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for tag in ("a", "b"):
+        U, V, dims = results[tag]
+        assert relerr(V, orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=8)) < 1e-10
