@@ -237,6 +237,66 @@ int chebhip_rccl_comm_destroy(void *nccl_comm);
 int chebhip_rccl_reduce(void *nccl_comm, double *vals_dev, int count, void *stream);
 
 /* ------------------------------------------------------------------------- */
+/* Transports of the slab-partitioned operators.  A chebhip_comm   */
+/* carries the exchanges (slab <-> pencil transposes) and the few-double       */
+/* reductions of a Krylov iteration among G ranks:                             */
+/*   _create_rccl      one process per GPU; each exchange is one grouped       */
+/*                     ncclSend/ncclRecv launch over xGMI (rccl.h:700,722,923) */
+/*   _create_local     ranks are host threads of ONE process, one stream (and, */
+/*                     on a multi-GPU node, one device) each; exchanges are    */
+/*                     event-ordered device copies between the ranks' buffers  */
+/*                     (peer access).  Every rank must make the same sequence  */
+/*                     of collective calls from its own thread.                */
+/*   _create_callback  any other transport (the gloo staging of the tests)     */
+/* ------------------------------------------------------------------------- */
+typedef struct chebhip_comm chebhip_comm;
+typedef struct chebhip_local_group chebhip_local_group;
+/* One exchange: segment i sends send_counts[i] doubles at send_dev[i] to peers[i] and receives recv_counts[i] doubles
+ * from it into recv_dev[i]; the k-th segment a rank addresses to peer s meets the k-th segment s addresses to that
+ * rank.  The rank's own segments are not passed (device copies inside the library).  Ordered on `stream`. */
+typedef int (*chebhip_exchangev_fn)(void *ctx, int nseg, const int *peers, const double *const *send_dev, const long *send_counts,
+                                    double *const *recv_dev, const long *recv_counts, void *stream);
+int chebhip_comm_create_rccl(void *nccl_comm, int nranks, int rank, chebhip_comm **out);      /* the ncclComm_t is not owned */
+int chebhip_local_group_create(int nranks, chebhip_local_group **out);
+int chebhip_local_group_destroy(chebhip_local_group *g);
+int chebhip_local_group_abort(chebhip_local_group *g);   /* a failing rank releases the ranks waiting for it: their calls return an error */
+int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebhip_comm **out);          /* call with the rank's device current */
+int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn, chebhip_reduce_fn rfn, void *ctx, chebhip_comm **out);
+int chebhip_comm_destroy(chebhip_comm *c);
+int chebhip_comm_size(const chebhip_comm *c);
+int chebhip_comm_rank(const chebhip_comm *c);
+/* A chebhip_reduce_fn (ctx = the chebhip_comm): sums `count` device doubles over the ranks in place; every rank gets the
+ * same bits.  For chebhip_fgmres_set_reduce / stokes_op_set_inner_reduce. */
+int chebhip_comm_reduce(void *comm, double *vals_dev, int count, void *stream);
+/* The linear Poisson host above on any transport (chebhip_dist_use_rccl = _create_rccl + this). */
+int chebhip_dist_use_comm(chebhip_dist *D, chebhip_comm *comm);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU hosts for BASELINE config 5 and for the elliptic operator in any  */
+/* coefficient state, C++ behind this ABI (csrc/slabx.hip): each   */
+/* rank owns a slab-mode handle on its planes of grid dimension 0; whatever    */
+/* runs along dimension 0 (DV[0], DP[0], D_0, the x-line pressure              */
+/* extrapolation stokes.C:1064-1074) is done on pencils: pack -> one grouped   */
+/* exchange of all fields of the call -> pencil launch -> exchange -> unpack   */
+/* with the AXPY folded in.  The handle returned by *_op() takes every         */
+/* stokes_op_* / ell_op_* entry point; its vectors are this rank's contiguous  */
+/* pieces of the serial ones (node ranges from *_ranges: [0],[1] interior      */
+/* nodes lo/hi, [2],[3] boundary nodes lo/hi, in the serial BlockIt order).    */
+/* Every rank must make the same sequence of calls.  No counterpart in the     */
+/* serial reference (stokes.C:121 VecCreateSeq).                               */
+/* ------------------------------------------------------------------------- */
+typedef struct chebhip_dist_stokes chebhip_dist_stokes;
+int chebhip_dist_stokes_create(int d, const int *dims, chebhip_comm *comm, chebhip_dist_stokes **out);   /* comm NULL: one rank */
+int chebhip_dist_stokes_destroy(chebhip_dist_stokes *D);
+stokes_op *chebhip_dist_stokes_op(chebhip_dist_stokes *D);        /* owned by D; StokesMatMultSchur's built-in inner solve all-reduces through comm */
+int chebhip_dist_stokes_ranges(const chebhip_dist_stokes *D, long *ranges4);
+typedef struct chebhip_dist_ell chebhip_dist_ell;
+int chebhip_dist_ell_create(int d, const int *dims, chebhip_comm *comm, chebhip_dist_ell **out);
+int chebhip_dist_ell_destroy(chebhip_dist_ell *D);
+ell_op *chebhip_dist_ell_op(chebhip_dist_ell *D);
+int chebhip_dist_ell_ranges(const chebhip_dist_ell *D, long *ranges4);
+
+/* ------------------------------------------------------------------------- */
 /* Krylov driver on device vectors: the caller of the path.     */
 /* KSPSolve with KSPFGMRES around MatMult_Elliptic (elliptic.C:181-185) and    */
 /* KSPSchurVelocity inside StokesMatMultSchur (stokes.C:531).  Restarted       */

@@ -50,6 +50,11 @@ ABI_SYMBOLS = [
     "chebhip_dist_create", "chebhip_dist_destroy", "chebhip_dist_local_size", "chebhip_dist_slab_offset",
     "chebhip_dist_use_rccl", "chebhip_dist_set_exchange", "chebhip_dist_mult",
     "chebhip_rccl_unique_id", "chebhip_rccl_comm_create", "chebhip_rccl_comm_destroy", "chebhip_rccl_reduce",
+    "chebhip_comm_create_rccl", "chebhip_local_group_create", "chebhip_local_group_destroy", "chebhip_local_group_abort",
+    "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
+    "chebhip_comm_reduce", "chebhip_dist_use_comm",
+    "chebhip_dist_stokes_create", "chebhip_dist_stokes_destroy", "chebhip_dist_stokes_op", "chebhip_dist_stokes_ranges",
+    "chebhip_dist_ell_create", "chebhip_dist_ell_destroy", "chebhip_dist_ell_op", "chebhip_dist_ell_ranges",
 ]
 
 
@@ -167,6 +172,23 @@ def lib():
         L.chebhip_rccl_comm_create.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
         L.chebhip_rccl_comm_destroy.argtypes = [vp]
         L.chebhip_rccl_reduce.argtypes = [vp, vp, C.c_int, vp]
+        L.chebhip_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.chebhip_local_group_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.chebhip_local_group_destroy.argtypes = [vp]
+        L.chebhip_local_group_abort.argtypes = [vp]
+        L.chebhip_comm_create_local.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.chebhip_comm_create_callback.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)]
+        L.chebhip_comm_destroy.argtypes = [vp]
+        L.chebhip_comm_size.argtypes = [vp]
+        L.chebhip_comm_rank.argtypes = [vp]
+        L.chebhip_comm_reduce.argtypes = [vp, vp, C.c_int, vp]
+        L.chebhip_dist_use_comm.argtypes = [vp, vp]
+        for nm in ("stokes", "ell"):
+            getattr(L, "chebhip_dist_%s_create" % nm).argtypes = [C.c_int, ip, vp, C.POINTER(vp)]
+            getattr(L, "chebhip_dist_%s_destroy" % nm).argtypes = [vp]
+            getattr(L, "chebhip_dist_%s_op" % nm).argtypes = [vp]
+            getattr(L, "chebhip_dist_%s_op" % nm).restype = vp
+            getattr(L, "chebhip_dist_%s_ranges" % nm).argtypes = [vp, lp]
         _lib = L
     return _lib
 
@@ -330,12 +352,16 @@ def _dim0_trampoline(dim0):
 class EllipticOp:
     """The scalar elliptic MatShell (MatCreate_Elliptic, elliptic.C:250-293)."""
 
-    def __init__(self, dims, slab=None, dim0=None):
+    def __init__(self, dims, slab=None, dim0=None, handle=None):
         """slab = (lo, hi): the planes [lo, hi) of grid dimension 0 (ell_op_create_slab); dim0 is then the Python
-        callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the sweeps along dim 0."""
+        callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the sweeps along dim 0.
+        handle: wrap an ell_op owned by someone else (chebhip_dist_ell_op)."""
         self.dims = tuple(int(d) for d in dims)
         h = C.c_void_p()
-        if slab is None:
+        self._owned = handle is None
+        if handle is not None:
+            h = C.c_void_p(handle)
+        elif slab is None:
             _chk(lib().ell_op_create(len(self.dims), _ints(self.dims), C.byref(h)))
         else:
             self._cb = _dim0_trampoline(dim0)           # keep the trampoline alive as long as the handle
@@ -401,7 +427,8 @@ class EllipticOp:
 
     def destroy(self):
         if self._h:
-            lib().ell_op_destroy(self._h)
+            if self._owned:
+                lib().ell_op_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -417,13 +444,17 @@ class StokesOp:
     mult <-> StokesMatMult (stokes.C:499-519); mult_vv / mult_pv / mult_vp <-> MatVV / MatPV / MatVP
     (:623-676, :557-566, :599-619); function <-> StokesFunction (:680-758)."""
 
-    def __init__(self, dims, slab=None, dim0=None):
+    def __init__(self, dims, slab=None, dim0=None, handle=None):
         """slab = (lo, hi): the planes [lo, hi) of grid dimension 0 (stokes_op_create_slab); dim0 is then the Python
-        callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the work along dim 0."""
+        callable (kind, nfields, in_ptr, acc_ptr_or_None, alpha, out_ptr, stream) -> int doing the work along dim 0.
+        handle: wrap a stokes_op owned by someone else (chebhip_dist_stokes_op)."""
         self.dims = tuple(int(d) for d in dims)
         self.d = len(self.dims)
         h = C.c_void_p()
-        if slab is None:
+        self._owned = handle is None
+        if handle is not None:
+            h = C.c_void_p(handle)
+        elif slab is None:
             _chk(lib().stokes_op_create(self.d, _ints(self.dims), C.byref(h)))
         else:
             self._cb = _dim0_trampoline(dim0)           # keep the trampoline alive as long as the handle
@@ -517,7 +548,8 @@ class StokesOp:
 
     def destroy(self):
         if self._h:
-            lib().stokes_op_destroy(self._h)
+            if self._owned:
+                lib().stokes_op_destroy(self._h)
             self._h = None
 
     def __del__(self):

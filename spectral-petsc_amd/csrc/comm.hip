@@ -1,0 +1,360 @@
+// comm.hip -- transports of the slab-partitioned operators (the reference is serial: elliptic.C:262, nk.c:63).
+//
+// chebhip_comm is what the distributed drivers (dist.hip: linear Poisson; slabx.hip: general elliptic and Stokes)
+// exchange through.  Three kinds:
+//   RCCL      one process per GPU: every exchange is ONE grouped ncclSend / ncclRecv launch (rccl.h:700,722,923),
+//             G-1 direct xGMI messages per GPU; reductions are ncclAllReduce (rccl.h:611).  RCCL is looked up at run
+//             time (the copy the process already holds, e.g. PyTorch's, else the system one) and never linked.
+//   LOCAL     ranks are host threads of ONE process, each with its own stream (and its own device when the node's
+//             GPUs are driven from one process: peer access is enabled at create).  An exchange is event-ordered
+//             device copies: every rank PULLS its segments out of its peers' send buffers.  On one device this is the
+//             full-size rehearsal of an N-rank run (tests/test_gpu_dist_emul.py).
+//   CALLBACK  anything else (the gloo staging of the tests).
+#include "comm.h"
+#include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+
+#define CHIPCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+// ---- RCCL through dlopen (rccl.h:236-923; types restated so that no header of the library is needed) ---------
+struct Id128 { char internal[128]; };     // ncclUniqueId
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *id) = nullptr;                                       // ncclGetUniqueId(ncclUniqueId*): 128 bytes
+  int (*CommInitRank)(void **comm, int nranks, Id128 id, int rank) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*GroupStart)() = nullptr, (*GroupEnd)() = nullptr;
+  int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+  int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+  int (*AllReduce)(const void *s, void *r, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+
+bool rccl_ready() {
+  std::call_once(g_rccl_once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // the process's own copy first
+    for (const char *n : names) if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl.lib) return;
+    void *L = g_rccl.lib;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(L, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(L, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(L, "ncclCommDestroy");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(L, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(L, "ncclGroupEnd");
+    g_rccl.Send = (decltype(g_rccl.Send))dlsym(L, "ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(L, "ncclRecv");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(L, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(L, "ncclGetErrorString");
+    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd &&
+                g_rccl.Send && g_rccl.Recv && g_rccl.AllReduce;
+  });
+  return g_rccl.ok;
+}
+int rccl_fail(const char *what, int rc) {
+  return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+
+enum { KIND_RCCL = 1, KIND_LOCAL = 2, KIND_CALLBACK = 3 };
+constexpr int MAXR = 64;
+
+// sum of the G posted vectors, taken in rank order on every rank: all ranks get the same bits
+struct RedPtrs { const double *p[MAXR]; };
+__global__ void k_local_reduce(RedPtrs in, int G, int count, double *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    double s = in.p[0][i];
+    for (int r = 1; r < G; r++) s = s + in.p[r][i];
+    out[i] = s;
+  }
+}
+
+}  // namespace
+
+// ---- ranks as host threads of one process ----------------------------------------------------------------------
+struct chebhip_local_group {
+  int G = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int count = 0; long gen = 0; bool aborted = false;
+  double timeout_s = 120.0;
+  struct Slot { const chebhip::XSeg *segs = nullptr; int nseg = 0; hipEvent_t ready = nullptr, done = nullptr; const double *vals = nullptr; int device = -1; bool bound = false; } slot[MAXR];
+
+  // all G threads arrive, or the group is aborted (a rank failed, or did not come within the time limit)
+  int barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return chebhip_fail(CHEBHIP_ERR_DEVICE, "local group: aborted by another rank");
+    const long my = gen;
+    if (++count == G) { count = 0; gen++; cv.notify_all(); return 0; }
+    const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return gen != my || aborted; });
+    if (!ok) { aborted = true; cv.notify_all(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "local group: a rank did not arrive within %.0f s", timeout_s); }
+    if (gen == my && aborted) return chebhip_fail(CHEBHIP_ERR_DEVICE, "local group: aborted by another rank");
+    return 0;
+  }
+  void abort() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
+};
+
+struct chebhip_comm {
+  int kind = 0, G = 1, rank = 0;
+  void *nccl = nullptr;                         // RCCL communicator (not owned)
+  chebhip_exchangev_fn xfn = nullptr; chebhip_reduce_fn rfn = nullptr; void *ctx = nullptr;
+  chebhip_local_group *lg = nullptr;
+  double *scratch = nullptr;                    // LOCAL: the reduction's private result (MAXR doubles)
+};
+
+extern "C" int chebhip_local_group_create(int nranks, chebhip_local_group **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (nranks < 1 || nranks > MAXR) return chebhip_fail(CHEBHIP_ERR_ARG, "nranks = %d must be in 1..%d", nranks, MAXR);
+  chebhip_local_group *g = new (std::nothrow) chebhip_local_group;
+  if (!g) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  g->G = nranks;
+  if (const char *e = getenv("CHEBHIP_LOCAL_TIMEOUT")) { double t = atof(e); if (t > 0.0) g->timeout_s = t; }
+  *out = g;
+  return 0;
+}
+extern "C" int chebhip_local_group_destroy(chebhip_local_group *g) { delete g; return 0; }
+// A rank that cannot go on (an error outside the library) releases the ranks waiting for it: their calls fail.
+extern "C" int chebhip_local_group_abort(chebhip_local_group *g) { if (g) g->abort(); return 0; }
+
+extern "C" int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebhip_comm **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!g || rank < 0 || rank >= g->G) return chebhip_fail(CHEBHIP_ERR_ARG, "bad group or rank");
+  chebhip_comm *c = new (std::nothrow) chebhip_comm;
+  if (!c) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  c->kind = KIND_LOCAL; c->G = g->G; c->rank = rank; c->lg = g;
+  auto &s = g->slot[rank];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->scratch, MAXR * sizeof(double));
+  if (e != hipSuccess) { delete c; return chebhip_fail(CHEBHIP_ERR_DEVICE, "local comm: %s", hipGetErrorString(e)); }
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    s.device = dev; s.bound = true;
+    // ranks on other devices of this process: the pulls read their buffers directly (xGMI peer access)
+    for (int r = 0; r < g->G; r++)
+      if (g->slot[r].bound && g->slot[r].device != dev) {
+        (void)hipDeviceEnablePeerAccess(g->slot[r].device, 0);                                  // "already enabled" is fine
+        int cur = dev; (void)hipSetDevice(g->slot[r].device); (void)hipDeviceEnablePeerAccess(cur, 0); (void)hipSetDevice(cur);
+        (void)hipGetLastError();
+      }
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int chebhip_comm_create_rccl(void *nccl_comm, int nranks, int rank, chebhip_comm **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!nccl_comm || nranks < 1 || nranks > MAXR || rank < 0 || rank >= nranks) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  chebhip_comm *c = new (std::nothrow) chebhip_comm;
+  if (!c) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  c->kind = KIND_RCCL; c->G = nranks; c->rank = rank; c->nccl = nccl_comm;
+  *out = c;
+  return 0;
+}
+
+extern "C" int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn, chebhip_reduce_fn rfn, void *ctx, chebhip_comm **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (nranks < 1 || nranks > MAXR || rank < 0 || rank >= nranks || (!xfn && nranks > 1)) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  chebhip_comm *c = new (std::nothrow) chebhip_comm;
+  if (!c) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  c->kind = KIND_CALLBACK; c->G = nranks; c->rank = rank; c->xfn = xfn; c->rfn = rfn; c->ctx = ctx;
+  *out = c;
+  return 0;
+}
+
+extern "C" int chebhip_comm_destroy(chebhip_comm *c) {
+  if (!c) return 0;
+  if (c->kind == KIND_LOCAL && c->lg) {
+    auto &s = c->lg->slot[c->rank];
+    if (s.ready) (void)hipEventDestroy(s.ready);
+    if (s.done) (void)hipEventDestroy(s.done);
+    s.ready = s.done = nullptr; s.bound = false;
+  }
+  if (c->scratch) (void)hipFree(c->scratch);
+  delete c;
+  return 0;
+}
+extern "C" int chebhip_comm_size(const chebhip_comm *c) { return c ? c->G : -1; }
+extern "C" int chebhip_comm_rank(const chebhip_comm *c) { return c ? c->rank : -1; }
+
+namespace chebhip {
+int comm_size(const chebhip_comm *c) { return c ? c->G : 1; }
+int comm_rank(const chebhip_comm *c) { return c ? c->rank : 0; }
+
+static int self_copies(const chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
+  for (int i = 0; i < nseg; i++)
+    if (segs[i].peer == c->rank && segs[i].nrecv > 0) {
+      if (segs[i].nsend != segs[i].nrecv) return chebhip_fail(CHEBHIP_ERR_ARG, "exchange: a rank's own segment has unequal send / receive counts");
+      CHIPCHK(hipMemcpyAsync(segs[i].recv, segs[i].send, (size_t)segs[i].nrecv * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+  return 0;
+}
+
+static int exchange_rccl(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
+  // the own blocks first: nothing that can fail sits between ncclGroupStart and ncclGroupEnd except RCCL itself.
+  // CHEBHIP_DIST_SELF_RCCL=1 (one-rank smoke runs): the own block goes through ncclSend / ncclRecv as well.
+  static const bool self_rccl = [] { const char *e = getenv("CHEBHIP_DIST_SELF_RCCL"); return e && e[0] == '1'; }();
+  if (!self_rccl) { int rc = self_copies(c, segs, nseg, st); if (rc) return rc; }
+  bool any = false;
+  for (int i = 0; i < nseg; i++) if ((segs[i].peer != c->rank || self_rccl) && (segs[i].nsend > 0 || segs[i].nrecv > 0)) any = true;
+  if (!any) return 0;
+  int rc = g_rccl.GroupStart(); if (rc) return rccl_fail("ncclGroupStart", rc);
+  for (int i = 0; i < nseg; i++) {
+    const XSeg &s = segs[i];
+    if (s.peer == c->rank && !self_rccl) continue;
+    if (s.nsend > 0 && (rc = g_rccl.Send(s.send, (size_t)s.nsend, NCCL_DOUBLE, s.peer, c->nccl, st))) { g_rccl.GroupEnd(); return rccl_fail("ncclSend", rc); }
+    if (s.nrecv > 0 && (rc = g_rccl.Recv(s.recv, (size_t)s.nrecv, NCCL_DOUBLE, s.peer, c->nccl, st))) { g_rccl.GroupEnd(); return rccl_fail("ncclRecv", rc); }
+  }
+  rc = g_rccl.GroupEnd(); if (rc) return rccl_fail("ncclGroupEnd", rc);
+  return 0;
+}
+
+static int exchange_callback(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
+  int rc = self_copies(c, segs, nseg, st); if (rc) return rc;
+  std::vector<int> peers; std::vector<const double *> sp; std::vector<double *> rp; std::vector<long> sc, rcn;
+  for (int i = 0; i < nseg; i++) if (segs[i].peer != c->rank) {
+    peers.push_back(segs[i].peer); sp.push_back(segs[i].send); sc.push_back(segs[i].nsend); rp.push_back(segs[i].recv); rcn.push_back(segs[i].nrecv);
+  }
+  if (peers.empty()) return 0;
+  if (!c->xfn) return chebhip_fail(CHEBHIP_ERR_ARG, "exchange: no transport");
+  return c->xfn(c->ctx, (int)peers.size(), peers.data(), sp.data(), sc.data(), rp.data(), rcn.data(), (void *)st);
+}
+
+// every rank pulls: its k-th segment towards peer s is filled from the k-th segment s addresses to it
+static int exchange_local(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
+  chebhip_local_group *g = c->lg;
+  auto &me = g->slot[c->rank];
+  hipError_t e = hipEventRecord(me.ready, st);                         // my send buffers are complete at this point of my stream
+  if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+  me.segs = segs; me.nseg = nseg;
+  int rc = g->barrier(); if (rc) return rc;                            // every rank has posted and recorded
+  int fail = 0;
+  std::vector<int> taken(g->G, 0);                                     // how many of my segments towards s have been served
+  for (int s = 0; s < g->G && !fail; s++) {
+    bool waited = false;
+    for (int i = 0; i < nseg && !fail; i++) {
+      if (segs[i].peer != s) continue;
+      const int k = taken[s]++;
+      if (segs[i].nrecv <= 0) continue;
+      const auto &ps = g->slot[s];
+      const XSeg *match = nullptr; int seen = 0;
+      for (int j = 0; j < ps.nseg; j++) if (ps.segs[j].peer == c->rank && seen++ == k) { match = &ps.segs[j]; break; }
+      if (!match || match->nsend != segs[i].nrecv) { fail = chebhip_fail(CHEBHIP_ERR_ARG, "local exchange: rank %d has no matching segment %d for rank %d", s, k, c->rank); break; }
+      if (!waited && s != c->rank) { e = hipStreamWaitEvent(st, ps.ready, 0); waited = true; if (e != hipSuccess) { fail = chebhip_fail(CHEBHIP_ERR_DEVICE, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; } }
+      e = hipMemcpyAsync(segs[i].recv, match->send, (size_t)segs[i].nrecv * sizeof(double), hipMemcpyDefault, st);
+      if (e != hipSuccess) fail = chebhip_fail(CHEBHIP_ERR_DEVICE, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
+  }
+  if (!fail) { e = hipEventRecord(me.done, st); if (e != hipSuccess) fail = chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+  if (fail) { g->abort(); return fail; }
+  rc = g->barrier(); if (rc) return rc;                                // every rank has enqueued its pulls
+  for (int s = 0; s < g->G; s++)                                       // my send buffers may be rewritten once the peers have read them
+    if (s != c->rank) { e = hipStreamWaitEvent(st, g->slot[s].done, 0); if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipStreamWaitEvent: %s", hipGetErrorString(e)); } }
+  return 0;      // the peers read my list only between the two barriers: it may go once this call returns
+}
+
+int comm_exchange(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
+  if (!c) {   // one rank, no transport: own blocks only
+    chebhip_comm one; one.G = 1; one.rank = 0;
+    for (int i = 0; i < nseg; i++) if (segs[i].peer != 0) return chebhip_fail(CHEBHIP_ERR_ARG, "exchange: no transport set");
+    return self_copies(&one, segs, nseg, st);
+  }
+  switch (c->kind) {
+    case KIND_RCCL: return exchange_rccl(c, segs, nseg, st);
+    case KIND_LOCAL: return exchange_local(c, segs, nseg, st);
+    case KIND_CALLBACK: return exchange_callback(c, segs, nseg, st);
+  }
+  return chebhip_fail(CHEBHIP_ERR_ARG, "exchange: bad communicator");
+}
+}  // namespace chebhip
+
+// chebhip_reduce_fn over any communicator (ctx = the chebhip_comm): the all-reduce of the few doubles a Krylov iteration
+// needs, for chebhip_fgmres_set_reduce / stokes_op_set_inner_reduce.  Same result bits on every rank.
+extern "C" int chebhip_comm_reduce(void *comm, double *vals_dev, int count, void *stream) {
+  chebhip_comm *c = (chebhip_comm *)comm;
+  if (!c || !vals_dev || count < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  if (count == 0 || c->G == 1) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (c->kind == KIND_RCCL) {
+    int rc = g_rccl.AllReduce(vals_dev, vals_dev, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->nccl, st);
+    return rc ? rccl_fail("ncclAllReduce", rc) : 0;
+  }
+  if (c->kind == KIND_CALLBACK) {
+    if (!c->rfn) return chebhip_fail(CHEBHIP_ERR_ARG, "reduce: the communicator has no reduction");
+    return c->rfn(c->ctx, vals_dev, count, stream);
+  }
+  if (count > MAXR) return chebhip_fail(CHEBHIP_ERR_ARG, "local reduce: at most %d values", MAXR);
+  chebhip_local_group *g = c->lg;
+  auto &me = g->slot[c->rank];
+  hipError_t e = hipEventRecord(me.ready, st);
+  if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+  me.vals = vals_dev;
+  int rc = g->barrier(); if (rc) return rc;
+  RedPtrs in;
+  for (int r = 0; r < g->G; r++) {
+    in.p[r] = g->slot[r].vals;
+    if (r != c->rank && (e = hipStreamWaitEvent(st, g->slot[r].ready, 0)) != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipStreamWaitEvent: %s", hipGetErrorString(e)); }
+  }
+  hipLaunchKernelGGL(k_local_reduce, dim3(1), dim3(64), 0, st, in, g->G, count, c->scratch);
+  e = hipEventRecord(me.done, st);
+  if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+  rc = g->barrier(); if (rc) return rc;
+  for (int r = 0; r < g->G; r++)
+    if (r != c->rank && (e = hipStreamWaitEvent(st, g->slot[r].done, 0)) != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipStreamWaitEvent: %s", hipGetErrorString(e)); }
+  e = hipMemcpyAsync(vals_dev, c->scratch, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, st);   // everybody has read my values
+  if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipMemcpyAsync: %s", hipGetErrorString(e)); }
+  return 0;
+}
+
+// ---- communicator helpers for hosts that do not bring their own ncclComm_t ------------------------------------
+extern "C" int chebhip_rccl_unique_id(void *id128) {
+  if (!id128) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  int rc = g_rccl.GetUniqueId(id128); if (rc) return rccl_fail("ncclGetUniqueId", rc);
+  return 0;
+}
+extern "C" int chebhip_rccl_comm_create(int nranks, int rank, const void *id128, void **comm) {
+  if (!id128 || !comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  Id128 id; memcpy(&id, id128, sizeof id);
+  int rc = g_rccl.CommInitRank(comm, nranks, id, rank); if (rc) return rccl_fail("ncclCommInitRank", rc);
+  return 0;
+}
+extern "C" int chebhip_rccl_comm_destroy(void *comm) {
+  if (!comm) return 0;
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  int rc = g_rccl.CommDestroy(comm); if (rc) return rccl_fail("ncclCommDestroy", rc);
+  return 0;
+}
+// chebhip_reduce_fn over a bare RCCL communicator (ctx = the ncclComm_t)
+extern "C" int chebhip_rccl_reduce(void *comm, double *vals_dev, int count, void *stream) {
+  if (!comm || !vals_dev || count < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
+  int rc = g_rccl.AllReduce(vals_dev, vals_dev, (size_t)count, NCCL_DOUBLE, NCCL_SUM, comm, (hipStream_t)stream);
+  if (rc) return rccl_fail("ncclAllReduce", rc);
+  return 0;
+}

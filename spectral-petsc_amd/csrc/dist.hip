@@ -21,16 +21,14 @@
 // id the host distributes.  RCCL is looked up at run time (the copy the process already holds, e.g. PyTorch's,
 // else the system one) and never linked.  chebhip_dist_set_exchange plugs in any other transport with the same
 // contract (the CPU tests run the exchange logic under gloo that way).
-#include "../../include/chebhip.h"
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
+#include "comm.h"
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <vector>
 
 int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+using chebhip::XSeg;
 
 #define DHIPCHK(expr)                                                                                   \
   do {                                                                                                  \
@@ -39,49 +37,6 @@ int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
   } while (0)
 
 namespace {
-
-// ---- RCCL through dlopen (rccl.h:236-923; types restated so that no header of the library is needed) ---------
-struct Id128 { char internal[128]; };     // ncclUniqueId
-struct RcclApi {
-  void *lib = nullptr;
-  int (*GetUniqueId)(void *id) = nullptr;                                       // ncclGetUniqueId(ncclUniqueId*): 128 bytes
-  int (*CommInitRank)(void **comm, int nranks, Id128 id, int rank) = nullptr;
-  int (*CommDestroy)(void *comm) = nullptr;
-  int (*GroupStart)() = nullptr, (*GroupEnd)() = nullptr;
-  int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
-  int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
-  int (*AllReduce)(const void *s, void *r, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
-  bool ok = false;
-};
-constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;
-RcclApi g_rccl;
-std::once_flag g_rccl_once;
-
-bool rccl_ready() {
-  std::call_once(g_rccl_once, [] {
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *n : names) if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // the process's own copy first
-    for (const char *n : names) if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl.lib) return;
-    void *L = g_rccl.lib;
-    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(L, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(L, "ncclCommInitRank");
-    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(L, "ncclCommDestroy");
-    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(L, "ncclGroupStart");
-    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(L, "ncclGroupEnd");
-    g_rccl.Send = (decltype(g_rccl.Send))dlsym(L, "ncclSend");
-    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(L, "ncclRecv");
-    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(L, "ncclAllReduce");
-    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(L, "ncclGetErrorString");
-    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd &&
-                g_rccl.Send && g_rccl.Recv && g_rccl.AllReduce;
-  });
-  return g_rccl.ok;
-}
-int rccl_fail(const char *what, int rc) {
-  return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
-}
 
 // ---- pack / combine -------------------------------------------------------------------------------------------
 struct Split { int G; long c1[65]; };
@@ -127,7 +82,8 @@ struct chebhip_dist {
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   chebhip_exchange_fn xfn = nullptr; void *xctx = nullptr;
-  void *comm = nullptr;                       // RCCL communicator (not owned)
+  chebhip_comm *comm = nullptr, *own_comm = nullptr;   // transport (comm.hip); own_comm: made by chebhip_dist_use_rccl
+  std::vector<XSeg> segs;
   Split split;
 };
 
@@ -141,6 +97,7 @@ extern "C" int chebhip_dist_destroy(chebhip_dist *D) {
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->ev_in) (void)hipEventDestroy(D->ev_in);
   if (D->ev_out) (void)hipEventDestroy(D->ev_out);
+  if (D->own_comm) chebhip_comm_destroy(D->own_comm);
   delete D;
   return 0;
 }
@@ -200,32 +157,28 @@ extern "C" int chebhip_dist_set_exchange(chebhip_dist *D, chebhip_exchange_fn fn
   D->xfn = fn; D->xctx = ctx; D->comm = nullptr;
   return 0;
 }
-extern "C" int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm) {
-  if (!D || !nccl_comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
-  D->comm = nccl_comm; D->xfn = nullptr; D->xctx = nullptr;
+extern "C" int chebhip_dist_use_comm(chebhip_dist *D, chebhip_comm *comm) {
+  if (!D || !comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (chebhip::comm_size(comm) != D->G || chebhip::comm_rank(comm) != D->rank)
+    return chebhip_fail(CHEBHIP_ERR_ARG, "communicator is rank %d of %d, the handle rank %d of %d", chebhip::comm_rank(comm), chebhip::comm_size(comm), D->rank, D->G);
+  D->comm = comm; D->xfn = nullptr; D->xctx = nullptr;
   return 0;
 }
+extern "C" int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm) {
+  if (!D || !nccl_comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (D->own_comm) { chebhip_comm_destroy(D->own_comm); D->own_comm = nullptr; }
+  int rc = chebhip_comm_create_rccl(nccl_comm, D->G, D->rank, &D->own_comm); if (rc) return rc;
+  return chebhip_dist_use_comm(D, D->own_comm);
+}
 
-// send[s] (doubles, peer-major, contiguous) -> recv[s]: one grouped RCCL launch, the own block by a device copy
+// send[s] (doubles, peer-major, contiguous) -> recv[s]: one grouped launch of the transport, the own block a device copy
 static int exchange(chebhip_dist *D, const double *send, const long *sc, double *recv, const long *rc_, hipStream_t st) {
   if (D->xfn) return D->xfn(D->xctx, send, sc, recv, rc_, (void *)st);
+  if (D->G > 1 && !D->comm) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist: no transport set (chebhip_dist_use_comm / _use_rccl / _set_exchange)");
+  D->segs.clear();
   long so = 0, ro = 0;
-  if (D->G == 1 && !D->comm) { DHIPCHK(hipMemcpyAsync(recv, send, (size_t)sc[0] * sizeof(double), hipMemcpyDeviceToDevice, st)); return 0; }
-  if (!D->comm) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist: no transport set (chebhip_dist_use_rccl / chebhip_dist_set_exchange)");
-  int rc = g_rccl.GroupStart(); if (rc) return rccl_fail("ncclGroupStart", rc);
-  // CHEBHIP_DIST_SELF_RCCL=1 (smoke tests on one GPU): the rank's own block goes through ncclSend / ncclRecv as well
-  static const bool self_rccl = [] { const char *e = getenv("CHEBHIP_DIST_SELF_RCCL"); return e && e[0] == '1'; }();
-  for (int s = 0; s < D->G; s++) {
-    if (s == D->rank && !self_rccl) { if (sc[s]) DHIPCHK(hipMemcpyAsync(recv + ro, send + so, (size_t)sc[s] * sizeof(double), hipMemcpyDeviceToDevice, st)); }
-    else {
-      if (sc[s] && (rc = g_rccl.Send(send + so, (size_t)sc[s], NCCL_DOUBLE, s, D->comm, st))) { g_rccl.GroupEnd(); return rccl_fail("ncclSend", rc); }
-      if (rc_[s] && (rc = g_rccl.Recv(recv + ro, (size_t)rc_[s], NCCL_DOUBLE, s, D->comm, st))) { g_rccl.GroupEnd(); return rccl_fail("ncclRecv", rc); }
-    }
-    so += sc[s]; ro += rc_[s];
-  }
-  rc = g_rccl.GroupEnd(); if (rc) return rccl_fail("ncclGroupEnd", rc);
-  return 0;
+  for (int s = 0; s < D->G; s++) { D->segs.push_back(XSeg{s, send + so, sc[s], recv + ro, rc_[s]}); so += sc[s]; ro += rc_[s]; }
+  return chebhip::comm_exchange(D->comm, D->segs.data(), D->G, st);
 }
 
 extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, void *stream) {
@@ -234,50 +187,24 @@ extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, vo
   hipStream_t st = (hipStream_t)stream, side = D->side;
   const int d = D->d, r = D->rank;
   const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
-  int rc;
   // side stream: U is ready when the caller's stream gets here
   DHIPCHK(hipEventRecord(D->ev_in, st));
   DHIPCHK(hipStreamWaitEvent(side, D->ev_in, 0));
+  int rc = 0;
   hipLaunchKernelGGL(k_pack, dim3(dgrid(D->local)), dim3(256), 0, side, D->split, m0, M1, R, U, D->sendbuf);
-  if ((rc = exchange(D, D->sendbuf, D->fwd_send.data(), D->UT, D->fwd_recv.data(), side))) return rc;          // lands as the pencil
-  if ((rc = cheb_apply_lap1d(D->pencil_plan, D->UT, nullptr, -1.0, D->TT, side))) return rc;                    // TT = -L_0 UT
-  if ((rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), side))) return rc;           // pencil rows -> slab blocks
-  DHIPCHK(hipEventRecord(D->ev_out, side));
+  if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pack launch failed");
+  if (!rc) rc = exchange(D, D->sendbuf, D->fwd_send.data(), D->UT, D->fwd_recv.data(), side);            // lands as the pencil
+  if (!rc) rc = cheb_apply_lap1d(D->pencil_plan, D->UT, nullptr, -1.0, D->TT, side);                      // TT = -L_0 UT
+  if (!rc) rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), side);             // pencil rows -> slab blocks
   // main stream: the local directions, each into its own array (they overlap both exchanges)
-  for (int k = 1; k < d; k++) if ((rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[k - 1], st))) return rc;
-  DHIPCHK(hipStreamWaitEvent(st, D->ev_out, 0));
+  for (int k = 1; k < d && !rc; k++) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[k - 1], st);
+  // the caller's stream is rejoined with the side stream on every path, errors included
+  hipError_t e1 = hipEventRecord(D->ev_out, side), e2 = hipStreamWaitEvent(st, D->ev_out, 0);
+  if (rc) return rc;
+  if (e1 != hipSuccess || e2 != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream join failed");
   APtrs A; A.n = d - 1; for (int k = 0; k < 9; k++) A.p[k] = k < d - 1 ? D->A[k] : nullptr;
   hipLaunchKernelGGL(k_combine, dim3(dgrid(D->local)), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, A, V);
   DHIPCHK(hipGetLastError());
   return 0;
 }
 
-// ---- communicator helpers for hosts that do not bring their own ncclComm_t ------------------------------------
-extern "C" int chebhip_rccl_unique_id(void *id128) {
-  if (!id128) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
-  int rc = g_rccl.GetUniqueId(id128); if (rc) return rccl_fail("ncclGetUniqueId", rc);
-  return 0;
-}
-extern "C" int chebhip_rccl_comm_create(int nranks, int rank, const void *id128, void **comm) {
-  if (!id128 || !comm) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
-  Id128 id; memcpy(&id, id128, sizeof id);
-  int rc = g_rccl.CommInitRank(comm, nranks, id, rank); if (rc) return rccl_fail("ncclCommInitRank", rc);
-  return 0;
-}
-extern "C" int chebhip_rccl_comm_destroy(void *comm) {
-  if (!comm) return 0;
-  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
-  int rc = g_rccl.CommDestroy(comm); if (rc) return rccl_fail("ncclCommDestroy", rc);
-  return 0;
-}
-// chebhip_reduce_fn over an RCCL communicator (ctx = the ncclComm_t): the all-reduce of a few doubles per Krylov
-// iteration (rccl.h:611), for chebhip_fgmres_set_reduce / stokes_op_set_inner_reduce
-extern "C" int chebhip_rccl_reduce(void *comm, double *vals_dev, int count, void *stream) {
-  if (!comm || !vals_dev || count < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
-  if (!rccl_ready()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "librccl.so could not be loaded");
-  int rc = g_rccl.AllReduce(vals_dev, vals_dev, (size_t)count, NCCL_DOUBLE, NCCL_SUM, comm, (hipStream_t)stream);
-  if (rc) return rccl_fail("ncclAllReduce", rc);
-  return 0;
-}

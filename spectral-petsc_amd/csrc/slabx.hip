@@ -1,0 +1,203 @@
+// slabx.hip -- the Stokes callbacks and the general-coefficient elliptic callbacks on slabs of planes, host side in C++
+// behind the C ABI (BASELINE config 5; the reference itself is serial: stokes.C:121, elliptic.C:262).
+//
+// Each rank owns a slab-mode operator handle (stokes_op_create_slab / ell_op_create_slab) on its planes [s0[r], s0[r+1])
+// of grid dimension 0 -- the full local grid, boundary planes included: Dirichlet rows and the pressure end points
+// take part in the sweeps.  Gathers, node loops, sweeps along dimensions 1.., the pressure extrapolation along them
+// and the final scatter are the serial launches on the slab.  Whatever runs along dimension 0 (DV[0], DP[0], D_0 and the
+// x-line extrapolation of StokesPressureReduceOrder, stokes.C:1064-1074) comes back here through the handle's callback:
+//
+//   slab fields --pack (one launch), exchange--> pencil fields --pencil launch--> pencil result --exchange, unpack+AXPY--> slab
+//
+// One exchange moves all fields of a call in ONE grouped launch (comm.hip).  The pencil side of the forward exchange and
+// the pencil-row side of the backward one need no (un)packing: a peer's block is a run of whole pencil planes.
+#include "comm.h"
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
+using chebhip::XSeg;
+
+#define XHIPCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+struct Split { int G; long c1[65]; };
+// position inside one field's exchange buffer (peer-major: for peer s the block slab[:, c1[s]:c1[s+1], :]) of slab element e
+__device__ __forceinline__ long xbuf_index(const Split &sp, long m0, long M1, long R, long e) {
+  const long i0 = e / (M1 * R), rem = e - i0 * (M1 * R);
+  const long j = rem / R, r = rem - j * R;
+  int s = 0;
+  while (s + 1 < sp.G && j >= sp.c1[s + 1]) s++;
+  const long w = sp.c1[s + 1] - sp.c1[s];
+  return m0 * sp.c1[s] * R + (i0 * w + (j - sp.c1[s])) * R + r;
+}
+// nf stacked slab fields -> nf stacked exchange buffers, one launch
+__global__ void k_xpack(Split sp, int nf, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf) {
+  const long n = m0 * M1 * R;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long b = xbuf_index(sp, m0, M1, R, e);
+    for (int f = 0; f < nf; f++) buf[f * n + b] = slab[f * n + e];
+  }
+}
+// out = (acc ? acc : 0) + alpha * slab-ordered(buf), nf fields, one launch
+__global__ void k_xunpack(Split sp, int nf, long m0, long M1, long R, const double *__restrict__ buf, const double *acc, double alpha, double *out) {
+  const long n = m0 * M1 * R;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long b = xbuf_index(sp, m0, M1, R, e);
+    for (int f = 0; f < nf; f++) { const double t = alpha * buf[f * n + b]; out[f * n + e] = acc ? acc[f * n + e] + t : t; }
+  }
+}
+inline unsigned xgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+void split_sizes(long n, int parts, std::vector<long> &sz) { sz.resize(parts); for (int i = 0; i < parts; i++) sz[i] = n / parts + (i < n % parts ? 1 : 0); }
+
+// The slab <-> pencil machinery for fields on the full local grid (P0, P1, R): slabs of planes of dimension 0, pencils
+// holding all P0 planes and a share of dimension 1.
+struct SlabX {
+  chebhip_comm *comm = nullptr;
+  int d = 0, G = 1, rank = 0, nf_max = 1;
+  std::vector<int> dims;
+  long P0 = 0, P1 = 0, R = 1;
+  std::vector<long> m0, m1, s0, s1;
+  long Ns = 0, ncol = 0, Np = 0;               // nodes of the slab, lines of the pencil, nodes of the pencil
+  double *sendbuf = nullptr, *recvbuf = nullptr, *pen_in = nullptr, *pen_out = nullptr;
+  Split split;
+  std::vector<XSeg> segs;
+
+  ~SlabX() { double *all[] = {sendbuf, recvbuf, pen_in, pen_out}; for (double *p : all) if (p) (void)hipFree(p); }
+
+  int setup(int d_, const int *dims_, chebhip_comm *c, int nf) {
+    if (!dims_ || d_ < 2 || d_ > 10) return chebhip_fail(CHEBHIP_ERR_DIMS, "slab partitioning needs 2 <= d <= 10");
+    comm = c; d = d_; dims.assign(dims_, dims_ + d_); nf_max = nf;
+    G = chebhip::comm_size(c); rank = chebhip::comm_rank(c);
+    if (G < 1 || G > 64) return chebhip_fail(CHEBHIP_ERR_ARG, "1..64 ranks");
+    P0 = dims[0]; P1 = dims[1]; R = 1; for (int k = 2; k < d; k++) R *= dims[k];
+    if (P0 < G || P1 < G) return chebhip_fail(CHEBHIP_ERR_SIZE, "slab partition over %d ranks: every rank needs a plane along dimensions 0 and 1", G);
+    split_sizes(P0, G, m0); split_sizes(P1, G, m1);
+    s0.assign(G + 1, 0); s1.assign(G + 1, 0);
+    for (int s = 0; s < G; s++) { s0[s + 1] = s0[s] + m0[s]; s1[s + 1] = s1[s] + m1[s]; }
+    Ns = m0[rank] * P1 * R; ncol = m1[rank] * R; Np = P0 * ncol;
+    split.G = G; for (int s = 0; s <= G; s++) split.c1[s] = s1[s];
+    const size_t sb = (size_t)nf * (size_t)(Ns > 0 ? Ns : 1) * sizeof(double), pb = (size_t)nf * (size_t)(Np > 0 ? Np : 1) * sizeof(double);
+    XHIPCHK(hipMalloc((void **)&sendbuf, sb)); XHIPCHK(hipMalloc((void **)&recvbuf, sb));
+    XHIPCHK(hipMalloc((void **)&pen_in, pb)); XHIPCHK(hipMalloc((void **)&pen_out, pb));
+    return 0;
+  }
+
+  // nf slab fields at `in` -> pen_in as (nf, P0, m1, R)
+  int to_pencil(int nf, const double *in, hipStream_t st) {
+    if (nf < 1 || nf > nf_max) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: %d fields, at most %d", nf, nf_max);
+    if (Ns > 0) { hipLaunchKernelGGL(k_xpack, dim3(xgrid(Ns)), dim3(256), 0, st, split, nf, m0[rank], P1, R, in, sendbuf); XHIPCHK(hipGetLastError()); }
+    segs.clear();
+    for (int s = 0; s < G; s++)
+      for (int f = 0; f < nf; f++)
+        segs.push_back(XSeg{s, sendbuf + f * Ns + m0[rank] * s1[s] * R, m0[rank] * m1[s] * R, pen_in + f * Np + s0[s] * ncol, m0[s] * ncol});
+    return chebhip::comm_exchange(comm, segs.data(), (int)segs.size(), st);
+  }
+  // pen_out (nf, P0, m1, R) -> out = (acc ? acc : 0) + alpha * slab fields
+  int to_slab(int nf, const double *acc, double alpha, double *out, hipStream_t st) {
+    if (nf < 1 || nf > nf_max) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: %d fields, at most %d", nf, nf_max);
+    segs.clear();
+    for (int s = 0; s < G; s++)
+      for (int f = 0; f < nf; f++)
+        segs.push_back(XSeg{s, pen_out + f * Np + s0[s] * ncol, m0[s] * ncol, recvbuf + f * Ns + m0[rank] * s1[s] * R, m0[rank] * m1[s] * R});
+    int rc = chebhip::comm_exchange(comm, segs.data(), (int)segs.size(), st); if (rc) return rc;
+    if (Ns > 0) { hipLaunchKernelGGL(k_xunpack, dim3(xgrid(Ns)), dim3(256), 0, st, split, nf, m0[rank], P1, R, (const double *)recvbuf, acc, alpha, out); XHIPCHK(hipGetLastError()); }
+    return 0;
+  }
+
+  // where this rank's pieces sit in the serial vectors (dimension 0 outermost => contiguous): node ranges
+  void ranges(long *r4) const {
+    long inner_int = 1, inner_all = 1;
+    for (int k = 1; k < d; k++) { inner_int *= dims[k] - 2; inner_all *= dims[k]; }
+    const long lo = s0[rank], hi = s0[rank + 1];
+    const long lo1 = lo > 1 ? lo : 1, hi1 = hi < P0 - 1 ? hi : P0 - 1;
+    const long ilo = lo1 - 1, ihi = (hi1 - 1 > ilo) ? hi1 - 1 : ilo;                 // interior planes before / up to this slab
+    auto bnodes = [&](long plane_hi) {                                                // boundary nodes in planes [0, plane_hi)
+      const long full = (plane_hi < 1 ? plane_hi : 1) + (plane_hi - (P0 - 1) > 0 ? plane_hi - (P0 - 1) : 0);
+      return full * inner_all + (plane_hi - full) * (inner_all - inner_int);
+    };
+    r4[0] = ilo * inner_int; r4[1] = ihi * inner_int; r4[2] = bnodes(lo); r4[3] = bnodes(hi);
+  }
+};
+
+}  // namespace
+
+// ---- Stokes ------------------------------------------------------------------------------------------------------
+struct chebhip_dist_stokes { SlabX x; stokes_op *op = nullptr; };
+
+static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const double *acc, double alpha, double *out, void *stream) {
+  chebhip_dist_stokes *D = (chebhip_dist_stokes *)ctx;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = D->x.to_pencil(nf, in, st); if (rc) return rc;
+  if (kind == 0) rc = stokes_op_pencil_sweep(D->op, nf, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);     // DV[0] / DP[0]
+  else rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);                // x-line extrapolation + DP[0]
+  if (rc) return rc;
+  return D->x.to_slab(nf, acc, alpha, out, st);
+}
+
+extern "C" int chebhip_dist_stokes_destroy(chebhip_dist_stokes *D) {
+  if (!D) return 0;
+  if (D->op) stokes_op_destroy(D->op);
+  delete D;
+  return 0;
+}
+extern "C" int chebhip_dist_stokes_create(int d, const int *dims, chebhip_comm *comm, chebhip_dist_stokes **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  chebhip_dist_stokes *D = new (std::nothrow) chebhip_dist_stokes;
+  if (!D) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  int rc = D->x.setup(d, dims, comm, d);
+  if (!rc) rc = stokes_op_create_slab(d, dims, (int)D->x.s0[D->x.rank], (int)D->x.s0[D->x.rank + 1], dstokes_dim0, D, &D->op);
+  if (!rc && D->x.G > 1) rc = stokes_op_set_inner_reduce(D->op, chebhip_comm_reduce, comm);
+  if (rc) { chebhip_dist_stokes_destroy(D); return rc; }
+  *out = D;
+  return 0;
+}
+extern "C" stokes_op *chebhip_dist_stokes_op(chebhip_dist_stokes *D) { return D ? D->op : nullptr; }
+extern "C" int chebhip_dist_stokes_ranges(const chebhip_dist_stokes *D, long *ranges4) {
+  if (!D || !ranges4) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  D->x.ranges(ranges4);
+  return 0;
+}
+
+// ---- general-coefficient elliptic operator -----------------------------------------------------------------------
+struct chebhip_dist_ell { SlabX x; ell_op *op = nullptr; };
+
+static int dell_dim0(void *ctx, int kind, int nf, const double *in, const double *acc, double alpha, double *out, void *stream) {
+  chebhip_dist_ell *D = (chebhip_dist_ell *)ctx;
+  (void)kind;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = D->x.to_pencil(nf, in, st); if (rc) return rc;
+  if ((rc = ell_op_pencil_sweep(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream))) return rc;           // D_0 on the pencil
+  return D->x.to_slab(nf, acc, alpha, out, st);
+}
+
+extern "C" int chebhip_dist_ell_destroy(chebhip_dist_ell *D) {
+  if (!D) return 0;
+  if (D->op) ell_op_destroy(D->op);
+  delete D;
+  return 0;
+}
+extern "C" int chebhip_dist_ell_create(int d, const int *dims, chebhip_comm *comm, chebhip_dist_ell **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  chebhip_dist_ell *D = new (std::nothrow) chebhip_dist_ell;
+  if (!D) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  int rc = D->x.setup(d, dims, comm, 1);
+  if (!rc) rc = ell_op_create_slab(d, dims, (int)D->x.s0[D->x.rank], (int)D->x.s0[D->x.rank + 1], dell_dim0, D, &D->op);
+  if (rc) { chebhip_dist_ell_destroy(D); return rc; }
+  *out = D;
+  return 0;
+}
+extern "C" ell_op *chebhip_dist_ell_op(chebhip_dist_ell *D) { return D ? D->op : nullptr; }
+extern "C" int chebhip_dist_ell_ranges(const chebhip_dist_ell *D, long *ranges4) {
+  if (!D || !ranges4) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  D->x.ranges(ranges4);
+  return 0;
+}

@@ -163,12 +163,15 @@ class DistPoissonC:
     a transport -- an RCCL communicator made from a unique id that rank 0 broadcasts through the process group
     (backend "nccl"), or, for rehearsals on one GPU under gloo, a callback that stages the exchange through the host."""
 
-    def __init__(self, dims, sp, group=None):
+    def __init__(self, dims, sp, group=None, comm=None):
+        """comm: a Comm (e.g. one rank of a LocalGroup) instead of the process group's transport."""
         import ctypes as C
         self.sp, self.group = sp, group
         self.dims = tuple(int(v) for v in dims)
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if comm is not None:
+            self.G, self.rank = comm.G, comm.rank
         L = sp.lib()
         h = C.c_void_p()
         sp._chk(L.chebhip_dist_create(len(self.dims), (C.c_int * len(self.dims))(*self.dims), self.G, self.rank, C.byref(h)))
@@ -179,7 +182,9 @@ class DistPoissonC:
         self._comm = None
         self._cb = None
         forced = dist.is_initialized() and os.environ.get("CHEBHIP_DIST_FORCE_A2A") == "1"
-        if self.G > 1 or forced:
+        if comm is not None:
+            sp._chk(L.chebhip_dist_use_comm(h, comm._h))
+        elif self.G > 1 or forced:
             if dist.get_backend(group) == "nccl":
                 idbuf = C.create_string_buffer(128)
                 if self.rank == 0:
@@ -430,3 +435,190 @@ class DistStokesOp(_SlabPencil):
             self.op.set_inner_reduce(self.group)
             self._inner_reduce = True
         return self.op.mult_schur(p, pout, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Transports and the C++ slab drivers behind the ABI (csrc/comm.hip, csrc/slabx.hip)
+# ---------------------------------------------------------------------------------------------------------------
+class LocalGroup:
+    """G ranks as host threads of ONE process (chebhip_local_group): each thread drives its own handles on its own
+    stream; exchanges are event-ordered device copies between the ranks' buffers.  On one GPU this rehearses an
+    N-rank run at full size; on a multi-GPU node driven from one process each thread sets its own device first."""
+
+    def __init__(self, sp, nranks):
+        import ctypes as C
+        self.sp, self.G = sp, int(nranks)
+        h = C.c_void_p()
+        sp._chk(sp.lib().chebhip_local_group_create(self.G, C.byref(h)))
+        self._h = h
+
+    def comm(self, rank):
+        return Comm(self.sp, local=(self, rank))
+
+    def abort(self):
+        """Called by a rank that failed: the ranks waiting for it get an error instead of the time limit."""
+        self.sp.lib().chebhip_local_group_abort(self._h)
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            self.sp.lib().chebhip_local_group_destroy(self._h)
+            self._h = None
+
+
+EXCHANGEV_FN = None
+
+
+def _exchangev_type():
+    import ctypes as C
+    global EXCHANGEV_FN
+    if EXCHANGEV_FN is None:
+        EXCHANGEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_long),
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.c_void_p)
+    return EXCHANGEV_FN
+
+
+class Comm:
+    """chebhip_comm: from a torch.distributed process group (backend "nccl": an RCCL communicator made from a unique
+    id that rank 0 broadcasts; backend "gloo": the rehearsal transport, staged through the host), or one rank of a
+    LocalGroup."""
+
+    def __init__(self, sp, group=None, local=None):
+        import ctypes as C
+        self.sp = sp
+        L = sp.lib()
+        h = C.c_void_p()
+        self._nccl = None
+        self._cbs = None
+        if local is not None:
+            lg, rank = local
+            self.G, self.rank = lg.G, int(rank)
+            sp._chk(L.chebhip_comm_create_local(lg._h, self.rank, C.byref(h)))
+        else:
+            self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            if self.G > 1 and dist.get_backend(group) == "nccl":
+                idbuf = C.create_string_buffer(128)
+                if self.rank == 0:
+                    sp._chk(L.chebhip_rccl_unique_id(idbuf))
+                box = [bytes(idbuf.raw)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                comm = C.c_void_p()
+                sp._chk(L.chebhip_rccl_comm_create(self.G, self.rank, C.create_string_buffer(box[0], 128), C.byref(comm)))
+                self._nccl = comm
+                sp._chk(L.chebhip_comm_create_rccl(comm, self.G, self.rank, C.byref(h)))
+            else:
+                xfn = _exchangev_type()(self._host_exchangev(group))
+                rfn = sp.allreduce_trampoline(group) if self.G > 1 else None
+                self._cbs = (xfn, rfn)
+                sp._chk(L.chebhip_comm_create_callback(self.G, self.rank, C.cast(xfn, C.c_void_p),
+                                                       C.cast(rfn, C.c_void_p) if rfn is not None else None, None, C.byref(h)))
+        self._h = h
+
+    def _host_exchangev(self, group):
+        """chebhip_exchangev_fn under gloo: device -> host, batched isend / irecv, host -> device, ordered on `stream`."""
+        sp = self.sp
+
+        def xfn(ctx, nseg, peers, sends, scounts, recvs, rcounts, stream):
+            try:
+                ext = torch.cuda.ExternalStream(int(stream or 0))
+                with torch.cuda.stream(ext):
+                    ops, back = [], []
+                    for i in range(nseg):           # receives first, in segment order; matching is by order per peer
+                        if rcounts[i] > 0:
+                            buf = torch.empty(int(rcounts[i]), dtype=torch.float64)
+                            back.append((int(recvs[i]), buf))
+                            ops.append(dist.P2POp(dist.irecv, buf, int(peers[i]), group))
+                    for i in range(nseg):
+                        if scounts[i] > 0:
+                            ops.append(dist.P2POp(dist.isend, sp.device_view(sends[i], int(scounts[i])).cpu(), int(peers[i]), group))
+                    if ops:
+                        for w in dist.batch_isend_irecv(ops):
+                            w.wait()
+                    for ptr, buf in back:
+                        sp.device_view(ptr, buf.numel()).copy_(buf)
+                    ext.synchronize()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 5
+        return xfn
+
+    def reduce_fn(self):
+        """(chebhip_reduce_fn, ctx) for Fgmres.set_reduce-style hooks: chebhip_comm_reduce on this communicator."""
+        import ctypes as C
+        return C.cast(self.sp.lib().chebhip_comm_reduce, C.c_void_p), self._h
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            self.sp.lib().chebhip_comm_destroy(self._h)
+            self._h = None
+        if getattr(self, "_nccl", None):
+            self.sp.lib().chebhip_rccl_comm_destroy(self._nccl)
+            self._nccl = None
+
+
+class _DistC:
+    def _ranges(self, fn):
+        import ctypes as C
+        r = (C.c_long * 4)()
+        self.sp._chk(fn(self._h, r))
+        return (int(r[0]), int(r[1])), (int(r[2]), int(r[3]))
+
+    def serial_ranges(self):
+        """((interior node lo, hi), (boundary node lo, hi)) of this rank's pieces in the serial vectors."""
+        return self._rng
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize()
+            self._destroy(self._h)
+            self._h = None
+        if getattr(self, "_own_comm", None):
+            self._own_comm.destroy()
+            self._own_comm = None
+
+
+class DistStokesC(_DistC):
+    """The Stokes callbacks on slabs with the host in C++ (csrc/slabx.hip: chebhip_dist_stokes_*): partition, pack, the
+    grouped exchanges, pencil launches and the AXPY-fused unpack are behind the ABI; `op` is the slab-mode StokesOp."""
+
+    def __init__(self, dims, sp, comm=None, group=None):
+        import ctypes as C
+        self.sp = sp
+        self.dims = tuple(int(v) for v in dims)
+        self._own_comm = None
+        if comm is None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            comm = self._own_comm = Comm(sp, group=group)
+        self.comm = comm
+        L = sp.lib()
+        h = C.c_void_p()
+        sp._chk(L.chebhip_dist_stokes_create(len(self.dims), (C.c_int * len(self.dims))(*self.dims), comm._h if comm else None, C.byref(h)))
+        self._h, self._destroy = h, L.chebhip_dist_stokes_destroy
+        self.op = sp.StokesOp(self.dims, handle=L.chebhip_dist_stokes_op(h))
+        self._rng = self._ranges(L.chebhip_dist_stokes_ranges)
+        for name in ("global_size", "velocity_size", "pressure_size", "dirichlet_size", "local_nodes", "interior_nodes"):
+            setattr(self, name, getattr(self.op, name))
+        for name in ("mult", "function", "mult_vv", "mult_pv", "mult_vp", "mult_schur"):
+            setattr(self, name, getattr(self.op, name))
+
+
+class DistEllipticC(_DistC):
+    """MatMult_Elliptic / FormFunction for any coefficient state on slabs, host in C++ (chebhip_dist_ell_*)."""
+
+    def __init__(self, dims, sp, comm=None, group=None):
+        import ctypes as C
+        self.sp = sp
+        self.dims = tuple(int(v) for v in dims)
+        self._own_comm = None
+        if comm is None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            comm = self._own_comm = Comm(sp, group=group)
+        self.comm = comm
+        L = sp.lib()
+        h = C.c_void_p()
+        sp._chk(L.chebhip_dist_ell_create(len(self.dims), (C.c_int * len(self.dims))(*self.dims), comm._h if comm else None, C.byref(h)))
+        self._h, self._destroy = h, L.chebhip_dist_ell_destroy
+        self.op = sp.EllipticOp(self.dims, handle=L.chebhip_dist_ell_op(h))
+        self._rng = self._ranges(L.chebhip_dist_ell_ranges)
+        self.global_size, self.dirichlet_size, self.local_size = self.op.global_size, self.op.dirichlet_size, self.op.local_size
+        self.mult, self.function = self.op.mult, self.op.function
