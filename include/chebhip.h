@@ -262,6 +262,8 @@ int chebhip_local_group_destroy(chebhip_local_group *g);
 int chebhip_local_group_abort(chebhip_local_group *g);   /* a failing rank releases the ranks waiting for it: their calls return an error */
 int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebhip_comm **out);          /* call with the rank's device current */
 int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn, chebhip_reduce_fn rfn, void *ctx, chebhip_comm **out);
+/* No wire: own blocks only.  For timing the compute side of one rank of an N-rank partition on one GPU; results are meaningless. */
+int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out);
 int chebhip_comm_destroy(chebhip_comm *c);
 int chebhip_comm_size(const chebhip_comm *c);
 int chebhip_comm_rank(const chebhip_comm *c);
@@ -353,9 +355,13 @@ int stokes_saddle_destroy(stokes_saddle *s);
 /* -pc_saddle_type (stokes.C:177-187): 0 block LU, 1 upper triangular, 2 block diagonal, 3 lower triangular. */
 int stokes_saddle_set_type(stokes_saddle *s, int type);
 /* Inner solves: which = 0 KSPVelocity (-vel_), 1 KSPSchur (-schur_), 2 KSPSchurVelocity (-svel_); max_it GMRES
- * iterations at most (<= 30) to relative tolerance rtol.  For the two velocity solves max_it = 0 means
+ * iterations at most (restart 30) to relative tolerance rtol.  For the two velocity solves max_it = 0 means
  * -ksp_type preonly: one application of the MatVVPC solve.  Defaults (README:43): 4 / 3 / preonly, rtol 1e-5. */
 int stokes_saddle_set_inner(stokes_saddle *s, int which, int max_it, double rtol);
+/* KSPSchur's preconditioner: 1 (default) = PCJACOBI with the diagonal of StokesMatGetDiagonalSchur (stokes.C:330-331,
+ * :538-553: 1/eta at the interior nodes, so residuals are multiplied by the viscosity; left-preconditioned as PETSc's
+ * GMRES is), 0 = none (-schur_pc_type none). */
+int stokes_saddle_set_schur_jacobi(stokes_saddle *s, int on);
 /* Inner GMRES steps on MatVVPC inside its approximate solve (see chebhip_fdpc_set_sweeps); default 0. */
 int stokes_saddle_set_pc_sweeps(stokes_saddle *s, int sweeps);
 /* StokesPCSetUp0 (stokes.C:1160-1241): re-assemble MatVVPC from the operator's current eta. */

@@ -44,14 +44,14 @@ ABI_SYMBOLS = [
     "ell_pc_create", "stokes_pc_create", "chebhip_fdpc_destroy", "chebhip_fdpc_update", "chebhip_fdpc_set_sweeps",
     "chebhip_fdpc_mult", "chebhip_fdpc_apply",
     "stokes_saddle_create", "stokes_saddle_destroy", "stokes_saddle_set_type", "stokes_saddle_set_inner",
-    "stokes_saddle_setup", "stokes_saddle_apply", "stokes_saddle_iterations", "stokes_saddle_set_pc_sweeps",
+    "stokes_saddle_setup", "stokes_saddle_apply", "stokes_saddle_iterations", "stokes_saddle_set_pc_sweeps", "stokes_saddle_set_schur_jacobi",
     "chebhip_timers_enable", "chebhip_timers_reset", "chebhip_timers_read", "chebhip_stage_name",
     "stokes_op_viscosity_range", "stokes_op_write_vtk",
     "chebhip_dist_create", "chebhip_dist_destroy", "chebhip_dist_local_size", "chebhip_dist_slab_offset",
     "chebhip_dist_use_rccl", "chebhip_dist_set_exchange", "chebhip_dist_mult",
     "chebhip_rccl_unique_id", "chebhip_rccl_comm_create", "chebhip_rccl_comm_destroy", "chebhip_rccl_reduce",
     "chebhip_comm_create_rccl", "chebhip_local_group_create", "chebhip_local_group_destroy", "chebhip_local_group_abort",
-    "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
+    "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_create_null", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
     "chebhip_comm_reduce", "chebhip_dist_use_comm",
     "chebhip_dist_stokes_create", "chebhip_dist_stokes_destroy", "chebhip_dist_stokes_op", "chebhip_dist_stokes_ranges",
     "chebhip_dist_ell_create", "chebhip_dist_ell_destroy", "chebhip_dist_ell_op", "chebhip_dist_ell_ranges",
@@ -154,6 +154,7 @@ def lib():
         L.stokes_saddle_apply.argtypes = [vp, vp, vp, vp]
         L.stokes_saddle_iterations.argtypes = [vp, C.c_int]
         L.stokes_saddle_set_pc_sweeps.argtypes = [vp, C.c_int]
+        L.stokes_saddle_set_schur_jacobi.argtypes = [vp, C.c_int]
         L.chebhip_timers_enable.argtypes = [C.c_int]
         L.chebhip_timers_read.argtypes = [C.c_int, dp, C.POINTER(C.c_long)]
         L.chebhip_stage_name.argtypes = [C.c_int]
@@ -179,6 +180,7 @@ def lib():
         L.chebhip_comm_create_local.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.chebhip_comm_create_callback.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)]
         L.chebhip_comm_destroy.argtypes = [vp]
+        L.chebhip_comm_create_null.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
         L.chebhip_comm_size.argtypes = [vp]
         L.chebhip_comm_rank.argtypes = [vp]
         L.chebhip_comm_reduce.argtypes = [vp, vp, C.c_int, vp]
@@ -625,7 +627,8 @@ class StokesSaddlePc:
     saddle-point system, with the inner solves KSPVelocity, KSPSchur, KSPSchurVelocity (stokes.C:328-341).
     Pass the object as the `M` of Fgmres.solve around StokesOp.mult."""
 
-    def __init__(self, op, saddle_type=0, vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0):
+    def __init__(self, op, saddle_type=0, vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, schur_jacobi=True):
+        """schur_jacobi: KSPSchur's PCJACOBI with 1/eta on the diagonal (stokes.C:330-331, 538-553); False = -schur_pc_type none."""
         h = C.c_void_p()
         _chk(lib().stokes_saddle_create(op._h, C.byref(h)))
         self._h = h
@@ -633,6 +636,7 @@ class StokesSaddlePc:
         self.n = op.global_size
         _chk(lib().stokes_saddle_set_type(h, saddle_type))
         _chk(lib().stokes_saddle_set_pc_sweeps(h, pc_sweeps))
+        _chk(lib().stokes_saddle_set_schur_jacobi(h, 1 if schur_jacobi else 0))
         for which, (m, rtol) in enumerate((vel, schur, svel)):
             _chk(lib().stokes_saddle_set_inner(h, which, m, rtol))
 

@@ -73,7 +73,7 @@ int rccl_fail(const char *what, int rc) {
   return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
 }
 
-enum { KIND_RCCL = 1, KIND_LOCAL = 2, KIND_CALLBACK = 3 };
+enum { KIND_RCCL = 1, KIND_LOCAL = 2, KIND_CALLBACK = 3, KIND_NULL = 4 };
 constexpr int MAXR = 64;
 
 // sum of the G posted vectors, taken in rank order on every rank: all ranks get the same bits
@@ -186,6 +186,20 @@ extern "C" int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchan
   return 0;
 }
 
+// No wire at all: a rank's own blocks are copied, nothing else moves, reductions leave the values as they are.  For
+// timing the compute side of ONE rank of an N-rank partition on one GPU (bench.py "dist_rank_compute"); results are
+// meaningless for N > 1.
+extern "C" int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (nranks < 1 || nranks > MAXR || rank < 0 || rank >= nranks) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  chebhip_comm *c = new (std::nothrow) chebhip_comm;
+  if (!c) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  c->kind = KIND_NULL; c->G = nranks; c->rank = rank;
+  *out = c;
+  return 0;
+}
+
 extern "C" int chebhip_comm_destroy(chebhip_comm *c) {
   if (!c) return 0;
   if (c->kind == KIND_LOCAL && c->lg) {
@@ -287,6 +301,7 @@ int comm_exchange(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
     case KIND_RCCL: return exchange_rccl(c, segs, nseg, st);
     case KIND_LOCAL: return exchange_local(c, segs, nseg, st);
     case KIND_CALLBACK: return exchange_callback(c, segs, nseg, st);
+    case KIND_NULL: return self_copies(c, segs, nseg, st);
   }
   return chebhip_fail(CHEBHIP_ERR_ARG, "exchange: bad communicator");
 }
@@ -297,7 +312,7 @@ int comm_exchange(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
 extern "C" int chebhip_comm_reduce(void *comm, double *vals_dev, int count, void *stream) {
   chebhip_comm *c = (chebhip_comm *)comm;
   if (!c || !vals_dev || count < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
-  if (count == 0 || c->G == 1) return 0;
+  if (count == 0 || c->G == 1 || c->kind == KIND_NULL) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (c->kind == KIND_RCCL) {
     int rc = g_rccl.AllReduce(vals_dev, vals_dev, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->nccl, st);

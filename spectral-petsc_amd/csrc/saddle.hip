@@ -3,13 +3,15 @@
 // _schur), the finite-difference velocity matrix MatVVPC (precond.hip) and three inner Krylov solves with the
 // roles the reference gives its KSPs (StokesCreate, stokes.C:328-341):
 //   KSPVelocity       operators (MatVV, MatVVPC), prefix vel_    -> flexible GMRES on MatVV, M = MatVVPC solve
-//   KSPSchur          operator MatSchur, no preconditioner, constant null space removed from every Krylov vector
-//                     (stokes.C:1020-1021), prefix schur_
+//   KSPSchur          operator MatSchur, PCJACOBI with the diagonal StokesMatGetDiagonalSchur supplies -- 1 / eta at the
+//                     interior nodes (stokes.C:330-331, :538-553): every residual is multiplied by the viscosity --,
+//                     constant null space removed from every Krylov vector (stokes.C:1020-1021), prefix schur_
 //   KSPSchurVelocity  operators (MatVV, MatVVPC), prefix svel_   -> inside StokesMatMultSchur (stokes.C:531)
 // Defaults follow the options the reference's README recommends (README:43): -vel_ksp_max_it 4,
 // -schur_ksp_max_it 3, -svel_ksp_type preonly (one application of the MatVVPC solve).
 // Everything here goes through the public C ABI of the operator: vectors never leave HBM.
 #include "../../include/chebhip.h"
+#include "ops.h"
 #include "timers.h"
 #include <hip/hip_runtime.h>
 #include <new>
@@ -40,6 +42,11 @@ __global__ void k_merge(long I, int d, const double *__restrict__ v, int addv, c
 }
 // a = s * a + (b ? b : 0)
 __global__ void k_scale_add(long n, double s, double *__restrict__ a, const double *__restrict__ b) { GS_LOOP(q, n) a[q] = s * a[q] + (b ? b[q] : 0.0); }
+// PCApply of KSPSchur: PCJACOBI divides by the diagonal 1 / eta (StokesMatGetDiagonalSchur, stokes.C:538-553: scatterLP of
+// eta, VecReciprocal), i.e. out = eta .* in at the interior nodes.  in == out allowed.
+__global__ void k_eta_scale(long N, const int *__restrict__ ixL, const double *__restrict__ eta, const double *in, double *out) {
+  GS_LOOP(l, N) { const int n = ixL[l]; if (n >= 0) out[n] = eta[l] * in[n]; }
+}
 // out = in - mean(in): MatNullSpaceRemove with the constant vector, in two launches with a fixed summation order
 // (256 chunk sums, then every block adds the 256 partials in the same order).  The first version summed the vector in ONE
 // workgroup: 1.08 ms per call at 128^3, 39 % of the device time of the config-5 solve (profiles/r02_stokes_power_kernel_summary.txt).
@@ -75,6 +82,8 @@ struct stokes_saddle {
   int m_vel = 4, m_schur = 3, m_svel = 0;
   double rtol_vel = 1e-5, rtol_schur = 1e-5, rtol_svel = 1e-5;
   int its_vel = 0, its_schur = 0;                  // operator applies of the last apply, for monitoring
+  chebhip::FdView view;                            // ixL and eta of the operator (the Jacobi scaling of KSPSchur)
+  bool schur_jacobi = true;
 };
 
 static int vv_apply(void *ctx, const double *x, double *y, void *stream) { return stokes_op_mult_vv(((stokes_saddle *)ctx)->op, x, y, stream); }
@@ -93,9 +102,14 @@ static void remove_mean(stokes_saddle *s, const double *in, double *out, hipStre
   hipLaunchKernelGGL(k_mean_partial, dim3(MEAN_RB), dim3(MEAN_RT), 0, st, s->gp, in, s->red);
   hipLaunchKernelGGL(k_mean_subtract, dim3(g), dim3(MEAN_RT), 0, st, s->gp, (const double *)s->red, in, out);
 }
+static void eta_scale(stokes_saddle *s, const double *in, double *out, hipStream_t st) {
+  if (s->schur_jacobi) hipLaunchKernelGGL(k_eta_scale, dim3(sgrid(s->view.N)), dim3(256), 0, st, s->view.N, s->view.ixL, s->view.eta, in, out);
+}
+// One step of KSPSchur's left-preconditioned GMRES (PETSc's default side): y = P (eta .* (S x))
 static int schur_apply(void *ctx, const double *x, double *y, void *stream) {
   stokes_saddle *s = (stokes_saddle *)ctx;
   int rc = stokes_op_mult_schur(s->op, x, y, svel_solve, s, stream); if (rc) return rc;
+  eta_scale(s, y, y, (hipStream_t)stream);
   remove_mean(s, y, y, (hipStream_t)stream);
   SHIPCHK2(hipGetLastError());
   return 0;
@@ -108,8 +122,10 @@ static int vel_solve(stokes_saddle *s, const double *b, double *x, void *stream)
   s->its_vel += chebhip_fgmres_iterations(s->kvel);
   return rc;
 }
-// KSPSolve(KSPSchur, b, x); b is overwritten by its zero-mean part
+// KSPSolve(KSPSchur, b, x): GMRES on P diag(eta) S x = P diag(eta) b over zero-mean vectors, converged on the
+// preconditioned residual as PETSc's left-preconditioned GMRES is; b is overwritten by its preconditioned zero-mean part
 static int schur_solve(stokes_saddle *s, double *b, double *x, void *stream) {
+  eta_scale(s, b, b, (hipStream_t)stream);
   remove_mean(s, b, b, (hipStream_t)stream);
   int rc = chebhip_fgmres_set_tolerances(s->kschur, s->rtol_schur, 1e-50, s->m_schur > 0 ? s->m_schur : 1); if (rc) return rc;
   rc = chebhip_fgmres_solve(s->kschur, schur_apply, s, nullptr, nullptr, b, x, 0, stream);
@@ -138,6 +154,7 @@ extern "C" int stokes_saddle_create(stokes_op *op, stokes_saddle **out) {
   s->I = stokes_op_size(op, 1); s->gv = stokes_op_size(op, 2); s->gp = stokes_op_size(op, 3); s->g = stokes_op_size(op, 4);
   s->d = s->I > 0 ? (int)(s->gv / s->I) : 2;
   int rc = stokes_pc_create(op, &s->vvpc);
+  if (!rc) rc = stokes_op_fd_view(op, &s->view);
   if (!rc) rc = chebhip_fdpc_set_sweeps(s->vvpc, 0);
   if (!rc) rc = chebhip_fgmres_create(s->gv, 30, &s->kvel);
   if (!rc) rc = chebhip_fgmres_create(s->gp, 30, &s->kschur);
@@ -160,7 +177,7 @@ extern "C" int stokes_saddle_set_type(stokes_saddle *s, int type) {
 // which: 0 KSPVelocity (vel_), 1 KSPSchur (schur_), 2 KSPSchurVelocity (svel_).  max_it = 0 for the two velocity
 // solves means -ksp_type preonly: one application of the MatVVPC solve
 extern "C" int stokes_saddle_set_inner(stokes_saddle *s, int which, int max_it, double rtol) {
-  if (!s || which < 0 || which > 2 || max_it < 0 || max_it > 30 || !(rtol >= 0.0)) return chebhip_fail(CHEBHIP_ERR_ARG, "bad inner-solver setting");
+  if (!s || which < 0 || which > 2 || max_it < 0 || max_it > 100000 || !(rtol >= 0.0)) return chebhip_fail(CHEBHIP_ERR_ARG, "bad inner-solver setting");
   if (which == 0) { s->m_vel = max_it; s->rtol_vel = rtol; }
   else if (which == 1) { s->m_schur = max_it; s->rtol_schur = rtol; }
   else { s->m_svel = max_it; s->rtol_svel = rtol; }
@@ -176,6 +193,12 @@ extern "C" int stokes_saddle_setup(stokes_saddle *s, void *stream) {
 extern "C" int stokes_saddle_set_pc_sweeps(stokes_saddle *s, int sweeps) {
   if (!s) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
   return chebhip_fdpc_set_sweeps(s->vvpc, sweeps);
+}
+// -schur_pc_type: 1 = jacobi (the reference's hard-wired choice, stokes.C:330-331), 0 = none
+extern "C" int stokes_saddle_set_schur_jacobi(stokes_saddle *s, int on) {
+  if (!s) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
+  s->schur_jacobi = on != 0;
+  return 0;
 }
 extern "C" int stokes_saddle_iterations(const stokes_saddle *s, int which) { return !s ? -1 : (which == 0 ? s->its_vel : s->its_schur); }
 

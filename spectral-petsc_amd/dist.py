@@ -482,14 +482,18 @@ class Comm:
     id that rank 0 broadcasts; backend "gloo": the rehearsal transport, staged through the host), or one rank of a
     LocalGroup."""
 
-    def __init__(self, sp, group=None, local=None):
+    def __init__(self, sp, group=None, local=None, null=None):
+        """null = (nranks, rank): no wire at all (chebhip_comm_create_null) -- times one rank's compute side alone."""
         import ctypes as C
         self.sp = sp
         L = sp.lib()
         h = C.c_void_p()
         self._nccl = None
         self._cbs = None
-        if local is not None:
+        if null is not None:
+            self.G, self.rank = int(null[0]), int(null[1])
+            sp._chk(L.chebhip_comm_create_null(self.G, self.rank, C.byref(h)))
+        elif local is not None:
             lg, rank = local
             self.G, self.rank = lg.G, int(rank)
             sp._chk(L.chebhip_comm_create_local(lg._h, self.rank, C.byref(h)))

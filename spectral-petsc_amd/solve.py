@@ -62,7 +62,8 @@ def continuation_schedule(exponent, regularization, cont0=0, cont=1):
 
 def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, saddle_type=0,
                  snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50, ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000,
-                 vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, line_search=True, monitor=None, max_linear_fail=1):
+                 vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, line_search=True, monitor=None, max_linear_fail=1,
+                 schur_jacobi=True, stats=None):
     """The solve phase of stokes.C:213-235 on device vectors: for every continuation stage, SNESSolve = Newton with a
     backtracking line search around StokesFunction (stokes.C:680-758), each step KSPSolve(KSPFGMRES) on the
     Newton-linearised StokesMatMult (stokes.C:499-519) right-preconditioned by StokesPCApply<saddle_type>
@@ -70,12 +71,13 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
     set on `op`; x (device tensor, global_size) holds the initial guess and the result.
     `max_linear_fail`: linear solves that may end on their iteration limit before the Newton iteration gives up
     (-snes_max_linear_solve_fail, PETSc's default 1); the step of such a solve is still tried by the line search.
+    `stats` (a dict) receives "linear_fails": the number of linear solves that ended on their iteration limit.
     Returns a list of (exponent, regularization, newton_its, ksp_its, |F|) per stage."""
     kind, hardness, exponent, regularization, gamma0 = rheology
     n = op.global_size
     F = torch.empty_like(x); dx = torch.empty_like(x)
     ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
-    pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps)
+    pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps, schur_jacobi)
     stages = continuation_schedule(exponent, regularization, cont0, cont) if kind == 1 else [(exponent, regularization)]
     out = []
     fails = 0
@@ -106,4 +108,6 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
             out.append((e_i, r_i, it, total, fn))
     finally:
         ks.destroy(); pc.destroy()
+        if stats is not None:
+            stats["linear_fails"] = fails
     return out

@@ -116,6 +116,22 @@ def elliptic_mult(dims, U, eta=None, deta=None, gradu0=None, mode=FAST, nthreads
     return V
 
 
+def elliptic_mult_timed(dims, U, mode=FAST, nthreads=1, warm=2, reps=5):
+    """The linear MatMult_Elliptic applied warm + reps times (bench.py cpu_baseline, BASELINE.md section 3 protocol);
+    returns (V, [seconds of each timed apply])."""
+    d = len(dims)
+    N, G, _ = sizes(dims)
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    V = np.empty(G)
+    secs = np.zeros(reps)
+    f = lib().orc_elliptic_mult_timed
+    f.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    err = f(d, _ip(dims), _dp(U), _dp(V), mode, nthreads, warm, reps, _dp(secs))
+    if err:
+        raise ValueError("orc_elliptic_mult_timed error %d" % err)
+    return V, [float(v) for v in secs]
+
+
 def elliptic_function(dims, U, b=None, dirichlet=None, gamma=0.0, exponent=2.0, mode=FAST, nthreads=1):
     """FormFunction (elliptic.C:481-533); returns rhs, eta, deta, gradu."""
     d = len(dims)

@@ -2,7 +2,7 @@
 product, the reference an FFT-based one -- this is the comparison of the two algorithms on the device itself, on N(0,1)
 inputs at sizes up to BASELINE config 3.  The recipe's operator-level restatements are written from the reference's formulas,
 not from the CPU oracle (which tests/test_oracle_fft_recipe.py holds to the same recipe on the CPU).  Tolerance 1e-10
-normwise, 1e-9 where the pressure extrapolation enters (observed 1e-15 .. 1e-12)."""
+normwise, the blocks with the pressure extrapolation included (observed 1e-15 .. 1e-12)."""
 import numpy as np
 import pytest
 import torch
@@ -90,10 +90,10 @@ def test_stokes_blocks_equal_the_fft_recipe(dims):
     op.mult_pv(v_in, out_p); torch.cuda.synchronize()
     assert rel(out_p.view(*idims), div) < 1e-10
     op.mult_vp(p_in, out_v); torch.cuda.synchronize()
-    assert rel(out_v.view(*idims, d), torch.stack(gp, dim=-1)) < 1e-9
+    assert rel(out_v.view(*idims, d), torch.stack(gp, dim=-1)) < 1e-10
     y = torch.empty_like(x)
     op.mult(x, y); torch.cuda.synchronize()
-    assert rel(y.view(*idims, d + 1), full) < 1e-9
+    assert rel(y.view(*idims, d + 1), full) < 1e-10
     op.destroy()
 
 
@@ -115,11 +115,11 @@ def test_stokes_power_law_equals_the_fft_recipe(dims):
     s0, gp, div = fr.stokes_fields(dims, x, w)
     eta, deta = fr.power_law(s0, *rheo)
     ref = fr.stokes_assemble(dims, [[eta * s0[j][k] for k in range(d)] for j in range(d)], gp, div)
-    assert rel(y.view(*idims, d + 1), ref) < 1e-9
+    assert rel(y.view(*idims, d + 1), ref) < 1e-10
     z = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
     op.mult(z, y); torch.cuda.synchronize()
     s1, gp1, div1 = fr.stokes_fields(dims, z, w)
     zz = sum(s1[j][k] * s0[j][k] for j in range(d) for k in range(d))
     ref = fr.stokes_assemble(dims, [[eta * s1[j][k] + deta * s0[j][k] * zz for k in range(d)] for j in range(d)], gp1, div1)
-    assert rel(y.view(*idims, d + 1), ref) < 1e-9
+    assert rel(y.view(*idims, d + 1), ref) < 1e-10
     op.destroy()

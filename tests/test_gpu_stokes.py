@@ -1,7 +1,7 @@
 """GPU parity tests of the Stokes callbacks (stokes.C:499-758) through the C ABI, against the golden
-vectors and the CPU oracle.  Tolerance: 1e-10 normwise on N(0,1) inputs (float64); the pressure
-gradient goes through the boundary extrapolation (a dot product here, a Neville table in the
-reference: equal to rounding, amplified by the extrapolation weights) and gets 1e-9."""
+vectors and the CPU oracle.  Tolerance: 1e-10 normwise on N(0,1) inputs (float64) for every block, the pressure
+gradient included (its boundary extrapolation is a dot product here, a Neville table in the reference: observed
+1.8e-14 ... 9.8e-14 at 64^3 ... 136x132x130, profiles/r03_stokes_parity.txt)."""
 import os
 
 import numpy as np
@@ -44,8 +44,8 @@ def test_stokes_golden(g, dims):
     vG, pG = np.ascontiguousarray(X[:, :d]).ravel(), np.ascontiguousarray(X[:, d])
     assert relerr(run(op.mult_vv, vG, op.velocity_size), g["st_%s_vv_lin" % tag]) < 1e-10
     assert relerr(run(op.mult_pv, vG, op.pressure_size), g["st_%s_pv" % tag]) < 1e-10
-    assert relerr(run(op.mult_vp, pG, op.velocity_size), g["st_%s_vp" % tag]) < 1e-9
-    assert relerr(run(op.mult, x, op.global_size), g["st_%s_mult_lin" % tag]) < 1e-9
+    assert relerr(run(op.mult_vp, pG, op.velocity_size), g["st_%s_vp" % tag]) < 1e-10
+    assert relerr(run(op.mult, x, op.global_size), g["st_%s_mult_lin" % tag]) < 1e-10
     # StokesFunction with the power-law rheology, then the Jacobian apply with the state it leaves
     op.set_rheology(*POWER)
     op.set_dirichlet(g["st_%s_fn_dirichlet" % tag])
@@ -55,8 +55,8 @@ def test_stokes_golden(g, dims):
     assert relerr(op.get_state(1), g["st_%s_fn_deta" % tag]) < 1e-10
     for j in range(d):
         assert relerr(op.get_state(2 + j), g["st_%s_fn_strain" % tag][j]) < 1e-10
-    assert relerr(y, g["st_%s_fn_y" % tag]) < 1e-9
-    assert relerr(run(op.mult, x, op.global_size), g["st_%s_mult_nl" % tag]) < 1e-9
+    assert relerr(y, g["st_%s_fn_y" % tag]) < 1e-10
+    assert relerr(run(op.mult, x, op.global_size), g["st_%s_mult_nl" % tag]) < 1e-10
     op.destroy()
 
 
@@ -73,8 +73,8 @@ def test_stokes_mult_vs_oracle(dims):
     nt = 16
     assert relerr(run(op.mult_vv, vG, op.velocity_size), orc.stokes_mult_vv(dims, vG, nthreads=nt)) < 1e-10
     assert relerr(run(op.mult_pv, vG, op.pressure_size), orc.stokes_divergence(dims, vG, nthreads=nt)) < 1e-10
-    assert relerr(run(op.mult_vp, pG, op.velocity_size), orc.stokes_mult_vp(dims, pG, nthreads=nt)) < 1e-9
-    assert relerr(run(op.mult, x, op.global_size), orc.stokes_mult(dims, x, nthreads=nt)) < 1e-9
+    assert relerr(run(op.mult_vp, pG, op.velocity_size), orc.stokes_mult_vp(dims, pG, nthreads=nt)) < 1e-10
+    assert relerr(run(op.mult, x, op.global_size), orc.stokes_mult(dims, x, nthreads=nt)) < 1e-10
     op.destroy()
 
 
@@ -94,9 +94,9 @@ def test_stokes_function_power_law_vs_oracle(dims):
     yo, eta, deta, strain = orc.stokes_function(dims, xs, dv, U2, POWER, nthreads=16)
     assert relerr(op.get_state(0), eta) < 1e-10
     assert relerr(op.get_state(1), deta) < 1e-10
-    assert relerr(y, yo) < 1e-9
+    assert relerr(y, yo) < 1e-10
     x = rng.standard_normal(op.global_size)
-    assert relerr(run(op.mult, x, op.global_size), orc.stokes_mult(dims, x, eta, deta, strain, nthreads=16)) < 1e-9
+    assert relerr(run(op.mult, x, op.global_size), orc.stokes_mult(dims, x, eta, deta, strain, nthreads=16)) < 1e-10
     op.destroy()
 
 
@@ -108,7 +108,7 @@ def test_constant_pressure_null_space(dims):
     x = np.zeros((op.interior_nodes, d + 1))
     x[:, d] = 1.0
     y = run(op.mult, x.ravel(), op.global_size)
-    assert np.abs(y).max() < 1e-9
+    assert np.abs(y).max() < 1e-9          # absolute, on an input of norm sqrt(I)
     op.destroy()
 
 
@@ -121,7 +121,7 @@ def test_exact2_residual():
     op.set_force(U2)
     r = run(op.function, U, op.global_size)
     ro, *_ = orc.stokes_function(dims, U, dv, U2, nthreads=4)
-    assert np.abs(r - ro).max() < 1e-9
+    assert np.abs(r - ro).max() < 1e-9     # absolute difference of two residuals of size ~1e-10 .. 1e-6
     assert np.abs(r).max() < 1e-6
     op.destroy()
 
@@ -155,7 +155,7 @@ def _power_state_test(dims, nthreads):
     op.destroy()
     ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=orc.FAST, nthreads=nthreads)
     ref_m = orc.stokes_mult(dims, v, eta, deta, strain, mode=orc.FAST, nthreads=nthreads)
-    assert relerr(yf, ref_f) < 1e-9 and relerr(ym, ref_m) < 1e-9
+    assert relerr(yf, ref_f) < 1e-10 and relerr(ym, ref_m) < 1e-10
 
 
 def test_stokes_power_law_config5_size_vs_oracle():
@@ -178,6 +178,6 @@ def test_stokes_blocks_large_vs_oracle(dims):
     op.set_dirichlet(np.zeros(ndv)); op.set_force(np.zeros(g))
     assert relerr(run(op.mult_vv, v, gv), orc.stokes_mult_vv(dims, v, mode=orc.FAST, nthreads=16)) < 1e-10
     assert relerr(run(op.mult_pv, v, gp), orc.stokes_divergence(dims, v, mode=orc.FAST, nthreads=16)) < 1e-10
-    assert relerr(run(op.mult_vp, p, gv), orc.stokes_mult_vp(dims, p, mode=orc.FAST, nthreads=16)) < 1e-9
-    assert relerr(run(op.mult, x, g), orc.stokes_mult(dims, x, mode=orc.FAST, nthreads=16)) < 1e-9
+    assert relerr(run(op.mult_vp, p, gv), orc.stokes_mult_vp(dims, p, mode=orc.FAST, nthreads=16)) < 1e-10
+    assert relerr(run(op.mult, x, g), orc.stokes_mult(dims, x, mode=orc.FAST, nthreads=16)) < 1e-10
     op.destroy()

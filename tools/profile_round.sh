@@ -3,13 +3,15 @@
 # traffic record bench.py reads (profiles/traffic.json, tied to the kernel sources by their hash).
 # usage (on the GPU box): tools/profile_round.sh r02      -> writes gpurun_out/<tag>_*; copy what is to be judged into profiles/
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT; out=gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_trace -o t -- python3 $R/bench.py --no-cpu-baseline > $R/$out/${tag}_bench_under_rocprof.json 2> $R/$out/${tag}_trace.log
+# the traced run is the metric alone (no CPU baseline, no extras): spin-up 100 + warm-up 20 are dropped from the summary,
+# which then covers exactly the 200 timed steps (3 launches each) that ms_per_step of the same run is taken over
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_trace -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras > $R/$out/${tag}_bench_under_rocprof.json 2> $R/$out/${tag}_trace.log
 cd $R
 f=$(find $out/${tag}_trace -name '*kernel_trace.csv' | head -1)
-python3 tools/prof_summary.py $f > $out/${tag}_bench_kernel_summary.txt
+python3 tools/prof_summary.py $f --skip 120 > $out/${tag}_bench_kernel_summary.txt
 tools/pmc_passes.sh $out/${tag}_pmc 256 0 > $out/${tag}_pmc.log 2>&1
 python3 - <<PY
 import json, re, sys
