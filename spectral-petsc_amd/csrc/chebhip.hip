@@ -408,6 +408,21 @@ __global__ void k_axpy(long N, double alpha, const double *__restrict__ x, doubl
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
 
+// eta = 1 + gamma w0^2, deta = 2 gamma w0 (elliptic.C:508-509 with the default exponent 2) from the stored state w0
+__global__ void k_coeff_sq(long N, const double *__restrict__ w0, double gamma, double *__restrict__ eta, double *__restrict__ deta) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const double v = w0[i];
+    eta[i] = 1.0 + gamma * (v * v); deta[i] = 2.0 * gamma * v;
+  }
+}
+// the coefficient pairs of the Jacobian apply straight from w0: {1 + gamma w0^2, (2 gamma w0) du0_k / 2}
+__global__ void k_cprod_sq(long N, const double *__restrict__ w0, double gamma, const double *__restrict__ du, double2 *__restrict__ ec) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const double v = w0[i];
+    ec[i] = make_double2(1.0 + gamma * (v * v), 0.5 * ((2.0 * gamma * v) * du[i]));
+  }
+}
+
 static inline unsigned pw_grid(long N) { long g = (N + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,13 +456,18 @@ struct ell_op {
   std::vector<double *> cprod;          // pairs {eta, deta * gradu[k] / 2} (2N doubles): what the Jacobian apply reads, refreshed when the state changes
   bool cdirty = true;
   double *eta = nullptr, *deta = nullptr, *dirloc = nullptr;
+  bool dir_nonzero = false;             // some Dirichlet value != 0 (set_dirichlet): the interior-line FormFunction path does not apply
+  // FormFunction on the interior line space (ell_fused4_function_trim) leaves w0 and gradu current but NOT eta / deta:
+  // they are 1 + gamma w0^2 and 2 gamma w0 (exponent 2) and are formed when something asks for them (ell_sync_coeffs)
+  bool coef_stale = false; double coef_gamma = 0.0;
+  bool bdy_lines_dirty = false;         // w0 / gradu hold non-zero values on lines inside the boundary (left by the general path)
   CoeffMode mode = COEFF_UNIT;
   double *hU = nullptr, *hV = nullptr, *hB = nullptr;  // staging for host-pointer calls
 };
 
 static int ell_alloc_state(ell_op *op) {
   const size_t bytes = (size_t)op->N * sizeof(double);
-  if (!op->w0) HIPCHK(hipMalloc((void **)&op->w0, bytes));
+  if (!op->w0) { HIPCHK(hipMalloc((void **)&op->w0, bytes)); HIPCHK(hipMemset(op->w0, 0, bytes)); }   // boundary nodes read as zero until a pass writes them
   if (!op->eta) {
     HIPCHK(hipMalloc((void **)&op->eta, bytes));
     HIPCHK(hipMalloc((void **)&op->deta, bytes));
@@ -465,6 +485,16 @@ static int ell_alloc_state(ell_op *op) {
   }
   return 0;
 }
+
+// eta / deta as the reference would hold them after the last FormFunction (elliptic.C:508-509), for whoever reads the arrays
+static int ell_sync_coeffs(ell_op *op, hipStream_t st) {
+  if (!op->coef_stale) return 0;
+  hipLaunchKernelGGL(k_coeff_sq, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->w0, op->coef_gamma, op->eta, op->deta);
+  HIPCHK(hipGetLastError());
+  op->coef_stale = false;
+  return 0;
+}
+int ell_op_sync_coeffs(ell_op *op, void *stream) { return op ? ell_sync_coeffs(op, (hipStream_t)stream) : 0; }   // precond.hip, before it reads the view
 
 int ell_op_fd_view(ell_op *op, chebhip::FdView *v) {
   if (!op || !v) return fail(CHEBHIP_ERR_ARG, "NULL argument");
@@ -747,6 +777,44 @@ static int ell_fused4_function(ell_op *op, int k, double gamma, double exponent,
   return 0;
 }
 
+// FormFunction, direction k, on the INTERIOR line space (homogeneous Dirichlet rows, exponent 2): the launch reads U in
+// the interior layout of the MatShell vector as the Jacobian mode does (end points of a line are implicit zeros, lines
+// inside the boundary are identically zero and are not visited), forms eta = 1 + gamma u^2 on chip, stores gradu[k] (and,
+// in the first direction, w0) through a base shifted to the first interior line of the local layout, keeps W in its padded
+// interior layout and, in the last direction, writes rhs = W - D_k f - b.  No gather pass: 104 B/point per residual
+// against 132 with it (SURVEY 8d model: 160).
+static int ell_fused4_function_trim(ell_op *op, int k, double gamma, const double *U, const double *b, double *rhs, hipStream_t st) {
+  const int d = op->d;
+  const unsigned n1 = d == 3 ? op->dims[1] : 0, nlast = op->dims[d - 1];
+  const unsigned nl = nlast - 2, nm = d == 3 ? n1 - 2 : 1u, n0i = op->dims[0] - 2, wp = op->wpad;
+  const unsigned s0 = d == 3 ? n1 * nlast : nlast;                       // local stride of dimension 0
+  Fused4Params q = {};
+  q.alpha = -1.0; q.trimf = 1; q.eta_square = 1; q.gamma4 = 0.25 * gamma;
+  q.in = U; q.in_bytes = (unsigned)((size_t)op->G * 8);
+  size_t shift;                                                          // first interior line in the local layout
+  const size_t wbytes = (size_t)(d == 3 ? n0i * nm : n0i) * wp * 8;
+  const bool last = k == d - 1;
+  if (!last) {
+    const bool first = d == 3 && k == 0;
+    q.qmax = nl;
+    if (d == 2) { q.nouter = 1; q.gi = {0, 1, nl}; q.gc = {0, 1, nlast}; q.go = {0, 1, wp}; shift = 1; }
+    else if (first) { q.nouter = nm; q.gi = {nl, 1, nm * nl}; q.gc = {nlast, 1, s0}; q.go = {wp, 1, nm * wp}; shift = nlast + 1; }
+    else { q.nouter = n0i; q.gi = {nm * nl, 1, nl}; q.gc = {s0, 1, nlast}; q.go = {nm * wp, 1, wp}; shift = s0 + 1; }
+    q.ga = q.go; q.out = op->W; q.out_bytes = (unsigned)wbytes;
+    if (k > 0) { q.acc = op->W; q.acc_bytes = (unsigned)wbytes; }
+  } else {
+    q.nouter = d == 3 ? n0i : 1u; q.qmax = d == 3 ? nm : n0i;
+    q.gi = {nm * nl, nl, 1}; q.gc = {s0, nlast, 1}; q.ga = {nm * wp, wp, 1}; q.go = q.gi;
+    shift = d == 3 ? s0 + nlast : nlast;
+    q.acc = op->W; q.acc_bytes = (unsigned)wbytes; q.out = rhs; q.out_bytes = (unsigned)((size_t)op->G * 8);
+    q.sub = b; q.sub_bytes = b ? (unsigned)((size_t)op->G * 8) : 0u;
+  }
+  q.gout = op->gradu[k] + shift; q.gout_bytes = (unsigned)(((size_t)op->N - shift) * 8);
+  if (k == 0) { q.w0out = op->w0 + shift; q.w0_bytes = q.gout_bytes; }
+  HIPCHK(fused4_launch(op->mats[op->dims[k]], q, last, false, k > 0, false, st));
+  return 0;
+}
+
 // Where the k-th term -D_k f_k of the divergence goes: W = -t0; W -= t_k; out_global = scatter(W - t_{d-1}).
 static void ell_out_chain(ell_op *op, int k, double *out_global, SweepParams *sp) {
   const int d = op->d;
@@ -918,13 +986,20 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   // General coefficients: w0 = gather(U) on the fly (VecScatter GL + dirichlet0, elliptic.C:305-308),
   // V = scatter( -sum_k D_k( eta D_k w0 + deta w0 du0_k ) ); the gradient and the flux
   // (elliptic.C:309-323) never leave the chip.
+  const bool f4 = op->wpad && ell_fused4_ok(op) && aligned16(U) && aligned16(V);
+  if (!f4) { int rc = ell_sync_coeffs(op, st); if (rc) return rc; }      // the other kernels read eta / deta themselves
   if (op->cdirty) {
-    for (int k = 0; k < op->d; k++)
-      hipLaunchKernelGGL(k_cprod, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta, (const double *)op->deta,
-                         (const double *)op->gradu[k], (double2 *)op->cprod[k]);
+    for (int k = 0; k < op->d; k++) {
+      if (op->coef_stale)     // state left by the interior-line FormFunction: the pairs come straight from w0
+        hipLaunchKernelGGL(k_cprod_sq, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->w0, op->coef_gamma,
+                           (const double *)op->gradu[k], (double2 *)op->cprod[k]);
+      else
+        hipLaunchKernelGGL(k_cprod, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta, (const double *)op->deta,
+                           (const double *)op->gradu[k], (double2 *)op->cprod[k]);
+    }
     op->cdirty = false;
   }
-  if (op->wpad && ell_fused4_ok(op) && aligned16(U) && aligned16(V)) {
+  if (f4) {
     for (int k = 0; k < op->d; k++) { int rc = ell_fused4_jacobian(op, k, U, V, st); if (rc) return rc; }
     return 0;
   }
@@ -949,6 +1024,25 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
   if (rc) return rc;
   const int d = op->d;
   const int iexp = (exponent == std::floor(exponent) && exponent >= 1.0 && exponent <= 8.0) ? (int)exponent : 0;
+  {
+    // Homogeneous Dirichlet rows and the reference's default exponent 2 (elliptic.C:141, :468-476) on the straight-line
+    // kernel: three launches on the interior lines, no gather pass; eta / deta are formed from w0 when somebody reads them
+    static int notrim = -1;
+    if (notrim < 0) { const char *e = getenv("CHEBHIP_NO_ETASQ"), *f = getenv("CHEBHIP_NO_TRIMF"); notrim = ((e && e[0] == '1') || (f && f[0] == '1')) ? 1 : 0; }
+    if (!notrim && exponent == 2.0 && !op->dir_nonzero && op->wpad && op->G > 0 && !use_unfused() && ell_fused4_ok(op) && aligned16(U) && aligned16(rhs)) {
+      if (op->bdy_lines_dirty) {                             // lines inside the boundary: zero in this state, not visited by the launches
+        HIPCHK(hipMemsetAsync(op->w0, 0, (size_t)op->N * sizeof(double), st));
+        for (int k = 0; k < d; k++) HIPCHK(hipMemsetAsync(op->gradu[k], 0, (size_t)op->N * sizeof(double), st));
+        op->bdy_lines_dirty = false;
+      }
+      for (int k = 0; k < d; k++) if ((rc = ell_fused4_function_trim(op, k, gamma, U, b, rhs, st))) return rc;
+      op->cdirty = true; op->coef_stale = true; op->coef_gamma = gamma;
+      op->mode = (gamma == 0.0) ? COEFF_UNIT : COEFF_FULL;
+      return 0;
+    }
+  }
+  op->coef_stale = false;                                    // the pass below writes w0, eta and deta
+  if (op->dir_nonzero) op->bdy_lines_dirty = true;
   if ((op->N & 1) == 0)
     hipLaunchKernelGGL(k_gather_coeff2, dim3(pw_grid(op->N >> 1) * 2), dim3(256), 0, st, op->N, (const int *)op->ixL, U,
                        (const double *)op->dirloc, gamma, exponent, iexp, op->w0, op->eta, op->deta);   // elliptic.C:486-493, 508-509
@@ -1054,6 +1148,8 @@ extern "C" int ell_op_set_dirichlet(ell_op *op, const double *values) {
   }
   if (!op->dirloc) HIPCHK(hipMalloc((void **)&op->dirloc, (size_t)op->N * sizeof(double)));
   HIPCHK(hipMemcpy(op->dirloc, loc.data(), (size_t)op->N * sizeof(double), hipMemcpyHostToDevice));
+  op->dir_nonzero = false;
+  for (long i = 0; i < dd && !op->dir_nonzero; i++) op->dir_nonzero = values[i] != 0.0;
   return 0;
 }
 
@@ -1070,6 +1166,7 @@ static int ell_state_ptr(ell_op *op, int which, double **p) {
 extern "C" int ell_op_get_state(ell_op *op, int which, double *dst) {
   if (!op || !dst) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
+  if (which < 2 && (rc = ell_sync_coeffs(op, nullptr))) return rc;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(dst, p, (size_t)op->N * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
@@ -1078,7 +1175,10 @@ extern "C" int ell_op_get_state(ell_op *op, int which, double *dst) {
 extern "C" int ell_op_set_state(ell_op *op, int which, const double *src) {
   if (!op || !src) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
+  if ((rc = ell_sync_coeffs(op, nullptr))) return rc;           // the untouched one of eta / deta must be current
+  HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(p, src, (size_t)op->N * sizeof(double), hipMemcpyHostToDevice));
+  if (which >= 2) op->bdy_lines_dirty = true;
   op->mode = COEFF_FULL; op->cdirty = true;
   return 0;
 }

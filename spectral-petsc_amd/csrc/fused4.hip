@@ -45,7 +45,7 @@ constexpr int f4_lds_doubles() {
 
 #define AO4(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
 
-template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ>
+template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ, bool TRIMF>
 __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) {
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
@@ -62,13 +62,15 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
   constexpr int KR = KS - NFL;
   constexpr u32 INVALID = 0x80000000u, T_INVALID = 0x40000000u;     // see sweep_vec.hip: arrays stay below 0x38000000 bytes
-  constexpr int IT = FULL ? 1 : 0;                    // input / accumulator hold interior points only
-  constexpr int OT = (FULL || WIN) ? 1 : 0;           // so does the output
+  constexpr int IT = (FULL || TRIMF) ? 1 : 0;         // input / accumulator hold interior points only
+  constexpr int OT = (FULL || WIN || TRIMF) ? 1 : 0;  // so does the output
+  constexpr bool SUB = WIN || (TRIMF && JFAST);       // the last launch of FormFunction: rhs -= b
   constexpr u32 CE = FULL ? 16u : 8u;                 // bytes of one coefficient element
   static_assert(KS >= 16 && CH >= 1, "two sub-tiles per tile");
   static_assert(!WIN || (JFAST && ACC && !FULL), "the window mode is the last launch of FormFunction");
   static_assert(!JFAST || ACC, "the contiguous direction is never the first one");
   static_assert(!ETASQ || !FULL, "eta = 1 + gamma u^2 formed on chip: FormFunction only (the line being differentiated is u)");
+  static_assert(!TRIMF || (ETASQ && !WIN && !FULL), "FormFunction on the interior line space: eta on chip, homogeneous Dirichlet rows");
 
   __shared__ double smem[f4_lds_doubles<KS, JFAST>()];
   double *inE = smem, *inO = smem + LDS_ELEMS, *fE_ = smem + 2 * LDS_ELEMS, *fO_ = smem + 3 * LDS_ELEMS;
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   const __amdgpu_buffer_rsrc_t r_gout = __builtin_amdgcn_make_buffer_rsrc((void *)(FULL ? (void *)p.in : (void *)p.gout), 0, FULL ? 0u : p.gout_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC ? p.acc : p.in), 0, ACC ? p.acc_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_sub = __builtin_amdgcn_make_buffer_rsrc((void *)((WIN && p.sub) ? p.sub : p.in), 0, (WIN && p.sub) ? p.sub_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_sub = __builtin_amdgcn_make_buffer_rsrc((void *)((SUB && p.sub) ? p.sub : p.in), 0, (SUB && p.sub) ? p.sub_bytes : 0u, 0x00020000);
+  // TRIMF, first direction: the local copy w0 of the state (scatter GL, elliptic.C:486-493) is stored on the way, same geometry as gout
+  const __amdgpu_buffer_rsrc_t r_w0 = __builtin_amdgcn_make_buffer_rsrc((void *)((TRIMF && p.w0out) ? (void *)p.w0out : (void *)p.in), 0, (TRIMF && p.w0out) ? p.w0_bytes : 0u, 0x00020000);
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
   auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { if (!(F4_ABLATE & 8) || v.x == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
   auto ld8 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); };
@@ -224,6 +228,10 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
           // 2 u_{n-i} = e - o): two multiply-adds instead of 8 bytes from HBM per value -- a byte costs the package about
           // twenty times what a flop does
           const double si = ue[r] + uo[r], sm = ue[r] - uo[r];
+          if constexpr (TRIMF) {                                           // w0 = the line itself (2 u_i = e + o); dropped when w0out is null
+            st8(r_w0, k_hi[r] + tv1[JFAST ? r : 0], 0.5 * si);
+            st8(r_w0, k_lo[r] + tv1[JFAST ? r : 0], 0.5 * sm);
+          }
           fi = __builtin_fma(p.gamma4 * si, si, 1.0) * gi; fm = __builtin_fma(p.gamma4 * sm, sm, 1.0) * gm;
         } else { fi = cv_hi[r] * gi; fm = cv_lo[r] * gm; }              // eta * g, elliptic.C:511
       }
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   const bool win_o = WIN && p.nouter > 1;
 
   d2 acc_hi[2], acc_lo[2];                             // COLFAST: 2 x 16 B each; JFAST: the same registers as 4 + 4 doubles
-  d2 sub_hi[WIN ? 2 : 1], sub_lo[WIN ? 2 : 1];
+  d2 sub_hi[SUB ? 2 : 1], sub_lo[SUB ? 2 : 1];
   u32 tv2[JFAST ? 4 : 1];                              // masked tile offsets of `out`
   auto acc_issue = [&](u32 tl, int sub) {
     const u32 o = tile_o(tl), q0 = (tl - o * tpo) * NT;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
         tv2[r] = (q < qmax - 2u * qt) ? to + (u32)(4 * r) * o_ls8 : T_INVALID;
         const double ah = (F4_ABLATE & 2) ? 1.0 : ld8(r_acc, c_hi[0] + ta + (u32)(4 * r) * a_ls8), al = (F4_ABLATE & 2) ? 2.0 : ld8(r_acc, c_lo[0] + ta + (u32)(4 * r) * a_ls8);
         if (r & 1) { acc_hi[r >> 1].y = ah; acc_lo[r >> 1].y = al; } else { acc_hi[r >> 1].x = ah; acc_lo[r >> 1].x = al; }
-        if constexpr (WIN) {
+        if constexpr (SUB) {
           const double sh = ld8(r_sub, o_hi[0] + tv2[r]), sl = ld8(r_sub, o_lo[0] + tv2[r]);
           if (r & 1) { sub_hi[r >> 1].y = sh; sub_lo[r >> 1].y = sl; } else { sub_hi[r >> 1].x = sh; sub_lo[r >> 1].x = sl; }
         }
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
       for (int r = 0; r < 4; r++) {
         double vh = ((r & 1) ? acc_hi[r >> 1].y : acc_hi[r >> 1].x) + alpha * hi[r];
         double vl = ((r & 1) ? acc_lo[r >> 1].y : acc_lo[r >> 1].x) + alpha_lo * lo[r];
-        if constexpr (WIN) {                                            // rhs -= b, elliptic.C:530
+        if constexpr (SUB) {                                            // rhs -= b, elliptic.C:530
           vh -= (r & 1) ? sub_hi[r >> 1].y : sub_hi[r >> 1].x;
           vl -= (r & 1) ? sub_lo[r >> 1].y : sub_lo[r >> 1].x;
         }
@@ -432,9 +440,9 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
 
 bool fused4_eligible(const DiffMat &m) { return (m.KS == 16 || m.KS == 32) && (m.P & 1) == 0 && m.fragE2 && m.sym == 0; }
 
-template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ = false>
+template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ = false, bool TRIMF = false>
 static hipError_t launch4(const Fused4Params &p, unsigned grid, hipStream_t stream) {
-  hipLaunchKernelGGL((cheb_fused4_kernel<KS, JFAST, FULL, ACC, WIN, ETASQ>), dim3(grid), dim3(512), 0, stream, p);
+  hipLaunchKernelGGL((cheb_fused4_kernel<KS, JFAST, FULL, ACC, WIN, ETASQ, TRIMF>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
 }
@@ -452,6 +460,11 @@ static hipError_t launch4_ks(Fused4Params &p, bool jfast, bool full, bool acc, b
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
   const bool sq = p.eta_square != 0;                      // FormFunction with exponent 2: eta formed on chip
   if (full && sq) return hipErrorInvalidValue;
+  if (p.trimf) {                                          // FormFunction on the interior line space (homogeneous Dirichlet rows, eta on chip)
+    if (!sq || full || win) return hipErrorInvalidValue;
+    if (jfast) return acc ? launch4<KS, true, false, true, false, true, true>(p, grid, stream) : hipErrorInvalidValue;
+    return acc ? launch4<KS, false, false, true, false, true, true>(p, grid, stream) : launch4<KS, false, false, false, false, true, true>(p, grid, stream);
+  }
   if (jfast) {
     if (!acc) return hipErrorInvalidValue;
     if (win) {
@@ -472,7 +485,7 @@ hipError_t fused4_launch(const DiffMat &m, Fused4Params p, bool jfast, bool full
   p.P = m.P; p.H = m.H; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2;
   // every offset the kernel forms must stay 16-B aligned where it moves 16 bytes, and below the T_INVALID marks
   const unsigned lim = 0x38000000u;
-  if (p.in_bytes >= lim || p.coef_bytes >= lim || p.gout_bytes >= lim || p.acc_bytes >= lim || p.out_bytes >= lim || p.sub_bytes >= lim)
+  if (p.in_bytes >= lim || p.coef_bytes >= lim || p.gout_bytes >= lim || p.acc_bytes >= lim || p.out_bytes >= lim || p.sub_bytes >= lim || p.w0_bytes >= lim)
     return hipErrorInvalidValue;
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
   if (!al(p.in) || (!p.eta_square && !al(p.coef)) || !al(p.out) || (acc && !al(p.acc))) return hipErrorInvalidValue;

@@ -17,6 +17,7 @@ struct FdView {
 
 }  // namespace chebhip
 
+int ell_op_sync_coeffs(ell_op *op, void *stream);            // chebhip.hip: makes eta / deta current before the view's arrays are read
 int ell_op_fd_view(ell_op *op, chebhip::FdView *v);          // chebhip.hip (allocates the coefficient state if needed)
 int stokes_op_fd_view(stokes_op *op, chebhip::FdView *v);    // stokes.hip
 int chebhip_fail(int code, const char *fmt, ...);            // chebhip.hip

@@ -242,6 +242,7 @@ static int fdpc_create(const FdView &v, int nf, bool interleaved, chebhip_fdpc *
 static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
   FdView v;
   int rc = pc->eop ? ell_op_fd_view(pc->eop, &v) : stokes_op_fd_view(pc->sop, &v);
+  if (!rc && pc->eop) rc = ell_op_sync_coeffs(pc->eop, (void *)st);
   if (rc) return rc;
   if (pc->G == 0) { pc->assembled = true; return 0; }
   GradPtrs gu; CoordPtrs xs;

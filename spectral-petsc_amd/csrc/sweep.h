@@ -116,7 +116,10 @@ struct Fused4Params {
   double *gout; unsigned gout_bytes;                           // eta mode: g = D u is stored here, geometry gc
   const double *acc; F4Geom ga; unsigned acc_bytes;            // trimmed in the Jacobian mode
   double *out; F4Geom go; unsigned out_bytes;                  // trimmed in the Jacobian mode and in the window mode
-  const double *sub; unsigned sub_bytes;                       // window mode: out -= sub (geometry go), may be null
+  const double *sub; unsigned sub_bytes;                       // window mode / last trimf launch: out -= sub (geometry go), may be null
+  int trimf;                                                   // FormFunction on the interior line space: `in`, `acc`, `out` trimmed as in the Jacobian mode, eta on chip
+                                                               //   (eta_square), gout through a base shifted to the first interior line (geometry gc); homogeneous Dirichlet rows only
+  double *w0out; unsigned w0_bytes;                            // trimf: if non-null the line itself is stored here (geometry gc): the local copy w0 of the state
   double alpha;
   int eta_square; double gamma4;                               // eta mode: eta = 1 + 4 gamma4 u^2 is formed from the line itself (coef is not read)
   const double *fragE2, *fragO2;

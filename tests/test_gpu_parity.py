@@ -356,6 +356,52 @@ def test_elliptic_nonlinear_straight_line_kernel(dims, exponent):
     op.destroy()
 
 
+@pytest.mark.parametrize("dims", [(136, 200), (68, 70, 72), (66, 128, 254), (256, 66, 68)], ids=lambda v: "x".join(map(str, v)))
+def test_elliptic_formfunction_interior_line_path(dims):
+    """FormFunction with homogeneous Dirichlet rows and the default exponent 2 (elliptic.C:141, 468-476): three launches on
+    the interior lines, no gather pass, eta / deta formed from w0 only when somebody reads them.  Residual with and
+    without b, the stored state (eta, deta, grad u on EVERY node, zero lines inside the boundary included), the Jacobian
+    apply from that state (coefficient pairs straight from w0), the preconditioner matrix from it, and the hand-over
+    between this path and the general one (non-zero Dirichlet rows) in both directions -- against the oracle."""
+    d = len(dims)
+    op = sp.EllipticOp(dims)
+    rng = np.random.default_rng(SEED + 11)
+    u = rng.random(op.global_size) + 0.5
+    b = rng.standard_normal(op.global_size)
+    zero = np.zeros(op.dirichlet_size)
+
+    def check(dv, gamma):
+        rhs0 = op.function_host(u, None, gamma, 2.0)
+        rhs = op.function_host(u, b, gamma, 2.0)
+        rhs_o, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, gamma, 2.0, mode=orc.FAST, nthreads=16)
+        assert relerr(rhs, rhs_o) < TOL and relerr(rhs0, rhs_o + b) < TOL
+        U = np.random.default_rng(SEED + 12).standard_normal(op.global_size)
+        V = op.mult_host(U)                                   # the Jacobian apply BEFORE anything has asked for eta / deta
+        assert relerr(V, orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST, nthreads=16)) < TOL
+        for k in range(d):
+            g = op.get_state(2 + k)
+            assert relerr(g, gradu[k]) < TOL
+            assert np.abs(g - gradu[k]).max() <= 1e-10 * np.abs(gradu[k]).max()          # lines inside the boundary too
+        assert relerr(op.get_state(0), eta) < 1e-14 and relerr(op.get_state(1), deta) < 1e-14
+        return eta, deta, gradu
+    check(zero, 1.5)                                          # never set: homogeneous
+    dv = rng.random(op.dirichlet_size) + 0.5
+    op.set_dirichlet(dv)
+    check(dv, 1.5)                                            # general path: gather pass, non-zero lines inside the boundary
+    op.set_dirichlet(zero)
+    eta, deta, gradu = check(zero, 0.75)                      # back: the boundary lines must read zero again
+    if d == 2:                                                # the preconditioner matrix right after a FormFunction on this path
+        op.function_host(u, b, 0.75, 2.0)
+        pc = sp.FdPc(op, sweeps=0)
+        P = orc.fd_matrix(dims, eta, deta, gradu)
+        x = rng.standard_normal(op.global_size)
+        y = torch.empty(op.global_size, dtype=torch.float64, device="cuda")
+        pc.mult(torch.from_numpy(x).cuda(), y)
+        assert relerr(y.cpu().numpy(), P @ x) < 1e-12
+        pc.destroy()
+    op.destroy()
+
+
 def test_elliptic_exact_residual():
     """elliptic.C:193-209 with -exact 2: the residual of the polynomial exact solution is ~0."""
     dims = (12, 11, 10)
