@@ -51,6 +51,35 @@ __global__ void k_st_local(long N, int gs, int go, const int *__restrict__ ixL, 
     if (pL) pL[l] = n >= 0 ? s[go] : 0.0;
   }
 }
+// The same for the full 3-D vector (node stride 4, pressure last, 16-byte aligned): the 32 bytes of a node come as two
+// 16-byte loads, and a thread keeps UN nodes in flight (index loads first, then the node loads, then the stores) -- the
+// one-node version is a chain of two dependent memory round trips per node and ran at 3.7 TB/s at 128^3.
+template <int UN>
+__global__ __launch_bounds__(256) void k_st_local4(long N, const int *__restrict__ ixL, const double *__restrict__ src,
+                                                   const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL) {
+  const long T = (long)gridDim.x * blockDim.x;
+  for (long l0 = blockIdx.x * (long)blockDim.x + threadIdx.x; l0 < N; l0 += UN * T) {
+    int n[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { const long l = l0 + u * T; n[u] = l < N ? ixL[l] : -1; }
+    double2 a[UN], b[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const double2 *s2 = (const double2 *)(src + 4L * (n[u] >= 0 ? n[u] : 0));
+      a[u] = s2[0]; b[u] = s2[1];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long l = l0 + u * T;
+      if (l >= N) continue;
+      const bool in = n[u] >= 0;
+      xL[l] = in ? a[u].x : (dirloc ? dirloc[l] : 0.0);
+      xL[N + l] = in ? a[u].y : (dirloc ? dirloc[N + l] : 0.0);
+      xL[2 * N + l] = in ? b[u].x : (dirloc ? dirloc[2 * N + l] : 0.0);
+      pL[l] = in ? b[u].y : 0.0;
+    }
+  }
+}
 
 // Boundary pressure of one family of grid lines (StokesPressureReduceOrder, stokes.C:1029-1080): the two
 // end values of a line become the degree-(len-3) polynomial through its interior values evaluated at the
@@ -178,6 +207,95 @@ __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict
   }
 }
 
+// The two node loops for d = 3 on node PAIRS (N even; every array is an allocation of the handle, 16-byte aligned): each
+// field is read and written 16 bytes at a time.  Same arithmetic per node as k_st_node_vv / k_st_node_fn.
+__device__ __forceinline__ double &comp(double2 &v, int q) { return q ? v.y : v.x; }
+template <bool DETA>
+__global__ __launch_bounds__(256) void k_st_node_vv_pair(long N, double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
+                                                         const double *__restrict__ S0, const double *__restrict__ S1, const double *__restrict__ S2,
+                                                         const double *__restrict__ eta, const double *__restrict__ deta, double *__restrict__ div) {
+  double *V[3] = {V0, V1, V2};
+  const double *S[3] = {S0, S1, S2};
+  const long half = N >> 1;
+  GS_LOOP(t, half) {
+    double2 g[3][3], s0[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) g[j][k] = ((const double2 *)(V[j] + k * N))[t];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = j; k < 3; k++) { s0[j][k] = DETA ? ((const double2 *)(S[j] + k * N))[t] : make_double2(0.0, 0.0); s0[k][j] = s0[j][k]; }
+    double2 e = ((const double2 *)eta)[t], de = DETA ? ((const double2 *)deta)[t] : make_double2(0.0, 0.0);
+    double2 out[3][3], dv;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      double strain[3][3], z = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { strain[j][k] = 0.5 * (comp(g[j][k], q) + comp(g[k][j], q)); z += strain[j][k] * comp(s0[j][k], q); }
+      const double eq = comp(e, q), deq = comp(de, q);
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) comp(out[j][k], q) = DETA ? eq * strain[j][k] + deq * comp(s0[j][k], q) * z : eq * strain[j][k];
+      double tr = comp(g[0][0], q) + comp(g[1][1], q); tr += comp(g[2][2], q);
+      comp(dv, q) = tr;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) ((double2 *)(V[j] + k * N))[t] = out[j][k];
+    if (div) ((double2 *)div)[t] = dv;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_st_node_fn_pair(long N, double *__restrict__ S0, double *__restrict__ S1, double *__restrict__ S2,
+                                                         double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
+                                                         double *__restrict__ eta, double *__restrict__ deta, double *__restrict__ div,
+                                                         int kind, double hardness, double expo, double eps, double gamma0) {
+  double *V[3] = {V0, V1, V2};
+  double *S[3] = {S0, S1, S2};
+  const long half = N >> 1;
+  GS_LOOP(t, half) {
+    double2 g[3][3], sv[3][3], tv[3][3], e2, de2, dv;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) g[j][k] = ((const double2 *)(S[j] + k * N))[t];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      double s[3][3], gamma = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s[j][k] = 0.5 * (comp(g[j][k], q) + comp(g[k][j], q)); gamma += 0.5 * (s[j][k] * s[j][k]); }
+      double e = 1.0, de = 0.0;
+      if (kind == 1) {
+        const double p = (1.0 - expo) / (2.0 * expo);
+        const double qq = eps + gamma / gamma0, qp = pow(qq, p);
+        e = hardness * qp;
+        de = (fabs(expo) > 1.0e-5) ? hardness * p / gamma0 * (qp / qq) : 0.0;
+      }
+      comp(e2, q) = e; comp(de2, q) = de;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { comp(tv[j][k], q) = e * s[j][k]; comp(sv[j][k], q) = s[j][k]; }
+      double tr = comp(g[0][0], q) + comp(g[1][1], q); tr += comp(g[2][2], q);
+      comp(dv, q) = tr;
+    }
+    ((double2 *)eta)[t] = e2; ((double2 *)deta)[t] = de2;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { ((double2 *)(V[j] + k * N))[t] = tv[j][k]; ((double2 *)(S[j] + k * N))[t] = sv[j][k]; }
+    if (div) ((double2 *)div)[t] = dv;
+  }
+}
+
 // Final scatter: velocity rows = yL (+ grad p), pressure rows = div v, minus force
 // (scatterLV/VG, VecAXPY stokes.C:513-517,750-756).  Any of yL / gp0 / p2 may be null.
 template <int D>
@@ -208,6 +326,45 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
       for (int k = 0; k < D; k++) { if (force) v[k] += -1.0 * force[o + k]; out[o + k] = v[k]; }
     }
     if (p2) { double w = p2[l]; if (force) w += -1.0 * force[o + po]; out[o + po] = w; }
+  }
+}
+
+// The final scatter of StokesMatMult / StokesFunction in 3-D (all terms present, 16-byte aligned output): UN nodes in
+// flight per thread, the node's four values leave as two 16-byte stores.  Same sums in the same order as k_st_out.
+template <int UN>
+__global__ __launch_bounds__(256) void k_st_out4(long N, const int *__restrict__ ixL, const double *__restrict__ yL,
+                                                 const double *__restrict__ yL1, const double *__restrict__ yL2,
+                                                 const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
+                                                 const double *__restrict__ p2, const double *__restrict__ force, double *__restrict__ out) {
+  const long T = (long)gridDim.x * blockDim.x;
+  for (long l0 = blockIdx.x * (long)blockDim.x + threadIdx.x; l0 < N; l0 += UN * T) {
+    int n[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { const long l = l0 + u * T; n[u] = l < N ? ixL[l] : -1; }
+    double v[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long l = (l0 + u * T < N) ? l0 + u * T : 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        double t = yL[k * N + l];
+        t = t + yL1[k * N + l];
+        t = t + yL2[k * N + l];
+        v[u][k] = t;
+      }
+      v[u][0] += 1.0 * gp0[l]; v[u][1] += 1.0 * gp1[l]; v[u][2] += 1.0 * gp2[l];
+      v[u][3] = p2[l];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      if (n[u] < 0) continue;
+      double2 *o2 = (double2 *)(out + 4L * n[u]);
+      if (force) {
+        const double2 f0 = ((const double2 *)(force + 4L * n[u]))[0], f1 = ((const double2 *)(force + 4L * n[u]))[1];
+        v[u][0] += -1.0 * f0.x; v[u][1] += -1.0 * f0.y; v[u][2] += -1.0 * f1.x; v[u][3] += -1.0 * f1.y;
+      }
+      o2[0] = make_double2(v[u][0], v[u][1]); o2[1] = make_double2(v[u][2], v[u][3]);
+    }
   }
 }
 
@@ -444,9 +601,27 @@ static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *
                                else hipLaunchKernelGGL((KERNEL<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); } while (0)
 
 // xL / pL <- global vector (either may be null)
+static inline unsigned ugrid(long n, int un) { long g = (n + 256L * un - 1) / (256L * un); return (unsigned)(g < 1 ? 1 : g); }
+static inline bool st_al16(const void *q) { return ((size_t)q & 15) == 0; }
 static void st_local(stokes_op *op, int gs, int go, const double *src, const double *dirloc, double *xL, double *pL, hipStream_t st) {
   const int d = op->d;
+  if (d == 3 && gs == 4 && go == 3 && xL && pL && st_al16(src)) {
+    hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
+    return;
+  }
   ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL);
+}
+// final scatter with every term present (StokesMatMult, StokesFunction)
+static void st_out_full(stokes_op *op, const double *force, double *out, hipStream_t st) {
+  const int d = op->d;
+  if (d == 3 && op->yLx[1] && op->yLx[2] && st_al16(out) && (!force || st_al16(force))) {
+    hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, (const double *)op->yL,
+                       (const double *)op->yLx[1], (const double *)op->yLx[2], (const double *)op->gp[0], (const double *)op->gp[1],
+                       (const double *)op->gp[2], (const double *)op->p2, force, out);
+    return;
+  }
+  ST_D(k_st_out, d + 1, (const int *)op->ixL, (const double *)op->yL, (const double *)op->yLx[1], (const double *)op->yLx[2],
+       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, force, out);
 }
 
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
@@ -496,8 +671,12 @@ static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st) {
   { int rc = st_gradient(op, op->V, st); if (rc) return rc; }                                                                   // :639
 #define NODE_VV(D_, DETA_) hipLaunchKernelGGL((k_st_node_vv<D_, DETA_>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
     (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
+#define NODE_VV_PAIR(DETA_) hipLaunchKernelGGL((k_st_node_vv_pair<DETA_>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
+    (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
   if (d == 2) { if (op->deta_nonzero) NODE_VV(2, true); else NODE_VV(2, false); }
+  else if ((op->N & 1) == 0) { if (op->deta_nonzero) NODE_VV_PAIR(true); else NODE_VV_PAIR(false); }
   else        { if (op->deta_nonzero) NODE_VV(3, true); else NODE_VV(3, false); }
+#undef NODE_VV_PAIR
 #undef NODE_VV
   return st_div_stress(op, st);
 }
@@ -614,7 +793,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   int rc = st_pressure_gradient_forked(op, st); if (rc) return rc;                                                               // MatVP (:512)
   if ((rc = st_viscous_jacobian(op, op->p2, st))) return rc;
   if ((rc = st_join(op, st))) return rc;
-  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(nullptr), yG);
+  st_out_full(op, nullptr, yG, st);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -628,12 +807,16 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
   { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                           // :747
   { int rc = st_gradient(op, op->strain, st); if (rc) return rc; }                                                                // :701
-  ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
-       op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  if (d == 3 && (op->N & 1) == 0)
+    hipLaunchKernelGGL(k_st_node_fn_pair, dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
+                       op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  else
+    ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
+         op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
   op->deta_nonzero = (op->rh_kind == 1);
   int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
   if ((rc = st_join(op, st))) return rc;
-  ST_OUT(d + 1, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(op->p2), d, CDP(op->force), yG);   // :750-756
+  st_out_full(op, op->force, yG, st);                                                                                              // :750-756
   SHIPCHK(hipGetLastError());
   return 0;
 }

@@ -348,3 +348,78 @@ def test_dist_c_ranks_match_oracle(world, dims, backend):
     assert all(r[4] == 2 for r in res)
     assert np.linalg.norm(b - orc.elliptic_mult(dims, x, mode=orc.DIRECT)) <= 1e-9 * np.linalg.norm(b)
 
+
+
+# ---- the C-side Stokes / general-elliptic slab drivers (csrc/slabx.hip) over a process group ---------------------------
+def _slabx_worker(rank, world, port, dims, q, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        os.environ["CHEBHIP_DIST_SELF_RCCL"] = "1"            # one rank on the real transport: its own block through ncclSend / ncclRecv
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = ge.load(); dsp = ge.load_dist()
+        d = len(dims)
+        comm = dsp.Comm(sp) if world > 1 else None
+        if backend == "nccl":                                  # world == 1: make the RCCL communicator by hand
+            import ctypes as C
+            L = sp.lib()
+            idbuf = C.create_string_buffer(128); sp._chk(L.chebhip_rccl_unique_id(idbuf))
+            nccl = C.c_void_p(); sp._chk(L.chebhip_rccl_comm_create(1, 0, idbuf, C.byref(nccl)))
+            comm = dsp.Comm.__new__(dsp.Comm); comm.sp = sp; comm.G, comm.rank = 1, 0; comm._nccl = nccl; comm._cbs = None
+            h = C.c_void_p(); sp._chk(L.chebhip_comm_create_rccl(nccl, 1, 0, C.byref(h))); comm._h = h
+        D = dsp.DistStokesC(dims, sp, comm=comm)
+        (n0, n1), (b0, b1) = D.serial_ranges()
+        rng = np.random.default_rng(SEED)
+        N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
+        x = rng.standard_normal(g); dv = rng.standard_normal(ndv); force = rng.standard_normal(g); w = rng.standard_normal(g)
+        D.op.set_rheology(*POWER)
+        D.op.set_dirichlet(dv[b0 * d:b1 * d]); D.op.set_force(force[n0 * (d + 1):n1 * (d + 1)])
+        xl = torch.from_numpy(x[n0 * (d + 1):n1 * (d + 1)].copy()).cuda(); wl = torch.from_numpy(w[n0 * (d + 1):n1 * (d + 1)].copy()).cuda()
+        yf, ym = torch.empty_like(xl), torch.empty_like(xl)
+        D.function(xl, yf); D.mult(wl, ym)
+        E = dsp.DistEllipticC(dims, sp, comm=comm)
+        (e0, e1), (c0, c1) = E.serial_ranges()
+        n, ge_, nd = orc.sizes(dims)
+        U = rng.random(ge_) + 0.5; b = rng.standard_normal(ge_); dirv = rng.standard_normal(nd); X = rng.standard_normal(ge_)
+        E.op.set_dirichlet(dirv[c0:c1])
+        Ul, bl, Xl = (torch.from_numpy(a[e0:e1].copy()).cuda() for a in (U, b, X))
+        R, V = torch.empty_like(Ul), torch.empty_like(Ul)
+        E.function(Ul, bl, R, gamma=4.0, exponent=2.0); E.mult(Xl, V)
+        torch.cuda.synchronize()
+        q.put((rank, n0, yf.cpu().numpy(), ym.cpu().numpy(), R.cpu().numpy(), V.cpu().numpy()))
+        E.destroy(); D.destroy()
+        if comm is not None:
+            comm.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (1, (10, 9, 8), "nccl")], ids=str)
+def test_slabx_c_drivers_over_process_group(world, dims, backend):
+    """chebhip_dist_stokes_* / chebhip_dist_ell_* with the transports a multi-process run uses: the callback transport
+    staged through gloo (2-3 ranks sharing the box's GPU), and ONE rank on the real RCCL transport (grouped ncclSend /
+    ncclRecv of its own blocks, every field of a call in one group) -- against the oracle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slabx_worker, args=(r, world, port, dims, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[1])
+    yf, ym, R, V = (np.concatenate([r[i] for r in res]) for i in (2, 3, 4, 5))
+    rng = np.random.default_rng(SEED)
+    N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
+    x = rng.standard_normal(g); dv = rng.standard_normal(ndv); force = rng.standard_normal(g); w = rng.standard_normal(g)
+    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=orc.DIRECT)
+    assert relerr(yf, ref_f) < TOL and relerr(ym, orc.stokes_mult(dims, w, eta, deta, strain, mode=orc.DIRECT)) < TOL
+    n, ge_, nd = orc.sizes(dims)
+    U = rng.random(ge_) + 0.5; b = rng.standard_normal(ge_); dirv = rng.standard_normal(nd); X = rng.standard_normal(ge_)
+    ref_r, eta, deta, gradu = orc.elliptic_function(dims, U, b, dirv, gamma=4.0, exponent=2.0, mode=orc.DIRECT)
+    assert relerr(R, ref_r) < TOL and relerr(V, orc.elliptic_mult(dims, X, eta, deta, gradu, mode=orc.DIRECT)) < TOL
