@@ -453,7 +453,7 @@ def main():
         launch_s = (dev_ms * 1e-3) / (args.steps * launches_per_step)
         alg_bytes_launch = BYTES_PER_POINT * npts / launches_per_step / world
         achieved = alg_bytes_launch / launch_s
-        two_stage = os.environ.get("CHEBHIP_TWO_STAGE") == "1"
+        two_stage = False                                   # (the two-stage A/B path of rounds 1-2 is gone: one kernel per state)
         # HBM bytes per launch from the committed PMC profile -- only if it was taken on the very kernel sources
         # being timed (hash of csrc/), otherwise null
         traffic = None

@@ -375,6 +375,23 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
 /* ------------------------------------------------------------------------- */
 /* Instrumentation (the reference has none: SURVEY 5.1).                      */
 /* ------------------------------------------------------------------------- */
+/* Run-time options: named integer switches, process-wide, read where they apply (the library never reads the
+ * environment).  Unknown names are an error.  Set them before creating the handles they concern.
+ *   general_kernels       1: every sweep runs the general 8-byte kernel (A/B against the 16-byte kernels)
+ *   separate_launches     1: the d sweeps of a Stokes gradient / divergence are d launches instead of one
+ *   no_rocblas            1: lines of more than 256 points use the library's own kernel, never rocBLAS (first use decides)
+ *   no_raw_transforms     1: the preconditioner's line transforms take two launches instead of one
+ *   equal_shares          1: multi-job launches give every job min(tiles, CUs) workgroups instead of proportional shares
+ *   force_gemm            1: every extent >= 4 takes the long-line (library DGEMM) route (read at operator create)
+ *   stokes_single_stream  1: StokesMatMult / StokesFunction keep the pressure chain on the caller's stream (read at create)
+ *   eta_from_memory       1: FormFunction reads eta instead of forming 1 + gamma u^2 on chip (exponent 2)
+ *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
+ *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
+ *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120) */
+int chebhip_set_option(const char *name, int value);
+int chebhip_get_option(const char *name, int *value);
+const char *chebhip_option_name(int index);     /* "" past the last option: enumerate from 0 */
+
 /* Number of sweep-kernel launches issued by this process so far. */
 long chebhip_launch_count(void);
 

@@ -29,6 +29,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 # every symbol include/chebhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "chebhip_last_error", "chebhip_version", "chebhip_arch", "chebhip_launch_count",
+    "chebhip_set_option", "chebhip_get_option", "chebhip_option_name",
     "cheb_plan_create", "cheb_apply", "cheb_apply_host", "cheb_plan_destroy", "cheb_plan_size",
     "cheb_plan_create_trimmed", "cheb_apply_lap1d", "cheb_slab_pack", "cheb_slab_unpack_add",
     "ell_op_create", "ell_op_destroy", "ell_op_local_size", "ell_op_global_size",
@@ -87,6 +88,10 @@ def lib():
         L.chebhip_last_error.restype = C.c_char_p
         L.chebhip_arch.restype = C.c_char_p
         L.chebhip_launch_count.restype = C.c_long
+        L.chebhip_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.chebhip_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        L.chebhip_option_name.argtypes = [C.c_int]
+        L.chebhip_option_name.restype = C.c_char_p
         L.cheb_plan_create.argtypes = [C.c_int, C.c_int, ip, C.POINTER(vp)]
         L.cheb_apply.argtypes = [vp, vp, vp, vp]
         L.cheb_plan_create_trimmed.argtypes = [C.c_int, C.c_int, ip, C.POINTER(vp)]
@@ -193,6 +198,27 @@ def lib():
             getattr(L, "chebhip_dist_%s_ranges" % nm).argtypes = [vp, lp]
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """chebhip_set_option: the library's run-time switches (include/chebhip.h lists them); the environment is never read."""
+    _chk(lib().chebhip_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int()
+    _chk(lib().chebhip_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def options():
+    out, i = {}, 0
+    while True:
+        n = lib().chebhip_option_name(i).decode()
+        if not n:
+            return out
+        out[n] = get_option(n)
+        i += 1
 
 
 def _chk(rc):

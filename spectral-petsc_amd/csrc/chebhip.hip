@@ -4,6 +4,7 @@
 #include "sweep.h"
 #include "ops.h"
 #include "timers.h"
+#include <atomic>
 #include <mutex>
 #include <cmath>
 #include <cstdarg>
@@ -44,10 +45,34 @@ extern "C" const char *chebhip_last_error(void) { return g_err.c_str(); }
 extern "C" int chebhip_version(void) { return 100; }
 extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
-// Undocumented profiling hook (not in chebhip.h): disables parts of the sweep kernel to price them.
-extern "C" void chebhip_debug_ablate(int bits) { sweep_set_ablate(bits); }
-// Undocumented profiling hook: schedule switches of the 16-byte kernels (4 = dense accumulator W, 8 = flat-address kernel v3 instead of v4, 16 = fused.hip instead of fused4.hip)
-extern "C" void chebhip_debug_variant(int bits) { sweep_set_variant(bits); }
+
+// ---------------------------------------------------------------------------------------------
+// run-time options (include/chebhip.h): the only switches of the library; the environment is never read
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct OptDesc { const char *name; int def; };
+const OptDesc g_opt_desc[OPT_COUNT] = {
+  {"general_kernels", 0}, {"separate_launches", 0}, {"no_rocblas", 0}, {"no_raw_transforms", 0}, {"equal_shares", 0}, {"force_gemm", 0},
+  {"stokes_single_stream", 0}, {"eta_from_memory", 0}, {"gather_pass", 0}, {"rccl_self_messages", 0}, {"local_timeout_s", 120},
+};
+std::atomic<int> g_opt_val[OPT_COUNT];
+std::once_flag g_opt_once;
+void opt_init() { std::call_once(g_opt_once, [] { for (int i = 0; i < OPT_COUNT; i++) g_opt_val[i].store(g_opt_desc[i].def); }); }
+}  // namespace
+int chebhip::opt(int id) { opt_init(); return (id >= 0 && id < OPT_COUNT) ? g_opt_val[id].load(std::memory_order_relaxed) : 0; }
+extern "C" int chebhip_set_option(const char *name, int value) {
+  if (!name) return fail(CHEBHIP_ERR_ARG, "NULL option name");
+  opt_init();
+  for (int i = 0; i < OPT_COUNT; i++) if (!strcmp(name, g_opt_desc[i].name)) { g_opt_val[i].store(value); return 0; }
+  return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
+}
+extern "C" int chebhip_get_option(const char *name, int *value) {
+  if (!name || !value) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  opt_init();
+  for (int i = 0; i < OPT_COUNT; i++) if (!strcmp(name, g_opt_desc[i].name)) { *value = g_opt_val[i].load(); return 0; }
+  return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
+}
+extern "C" const char *chebhip_option_name(int index) { return (index >= 0 && index < OPT_COUNT) ? g_opt_desc[index].name : ""; }
 // Diagnostic builds (-DCHEB_STAMPS) only: device buffer of 256*8*4 uint64 receiving per-wave phase cycle sums.
 static const double *g_stamp_buf = nullptr;
 static int g_stamp_cnt = 0;
@@ -104,8 +129,6 @@ extern "C" int chebhip_timers_read(int stage, double *total_ms, long *calls) {
   return 0;
 }
 extern "C" const char *chebhip_stage_name(int stage) { return (stage >= 0 && stage < CHEBHIP_NSTAGES) ? g_tm_names[stage] : ""; }
-
-static bool use_two_stage();
 
 static int require_device() {
   int n = 0;
@@ -206,8 +229,7 @@ extern "C" int cheb_apply_lap1d(cheb_plan *p, const double *x, const double *acc
   sp.in0 = x; sp.in_mode = IN_PLAIN;
   sp.alpha = alpha; sp.out = y;
   if (acc) { sp.out_mode = OUT_ACC; sp.acc = acc; } else sp.out_mode = OUT_STORE;
-  if (use_two_stage()) { sp.trim = 1; sp.coef_mode = COEF_UNIT; HIPCHK(fused_launch(p->mat, sp, (hipStream_t)stream)); }
-  else HIPCHK(sweep_launch(p->lap, sp, (hipStream_t)stream));
+  HIPCHK(sweep_launch(p->lap, sp, (hipStream_t)stream));
   return 0;
 }
 
@@ -662,43 +684,6 @@ extern "C" long ell_op_local_size(const ell_op *op) { return op ? op->N : -1; }
 extern "C" long ell_op_global_size(const ell_op *op) { return op ? op->G : -1; }
 extern "C" long ell_op_dirichlet_size(const ell_op *op) { return op ? op->N - op->G : -1; }
 
-// Divergence half of the UNFUSED path (kept for A/B measurements, CHEBHIP_UNFUSED=1):
-// out_global = -sum_k D_k f_k, f_k formed from src[k] on load.
-static int ell_divergence(ell_op *op, int in_mode, double *const *src, double *out_global, hipStream_t st) {
-  const int d = op->d;
-  for (int k = 0; k < d; k++) {
-    SweepParams sp = {};
-    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
-    sp.in0 = src[k]; sp.in1 = op->eta; sp.in2 = op->deta; sp.in3 = op->w0;
-    sp.in4 = op->gradu.empty() ? nullptr : op->gradu[k];
-    sp.in_mode = in_mode; sp.alpha = -1.0;                       // VecAXPY(w0,-1,.) elliptic.C:333
-    if (k == d - 1) {                                            // last term also does VecScatter LG (:336)
-      sp.out_mode = OUT_ACC_SCATTER; sp.out = out_global; sp.acc = (d > 1) ? op->W : nullptr;
-      sp.gcol = op->gcol[k]; sp.gstride = op->gstride[k];
-    } else if (k == 0) {                                         // 0 + (-1) t0
-      sp.out_mode = OUT_STORE; sp.out = op->W;
-    } else {
-      sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W;
-    }
-    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
-  }
-  return 0;
-}
-
-static int g_two_stage = -1;
-static bool use_two_stage() {
-  if (g_two_stage < 0) { const char *e = getenv("CHEBHIP_TWO_STAGE"); g_two_stage = (e && e[0] == '1') ? 1 : 0; }
-  return g_two_stage == 1;
-}
-// Undocumented profiling hook (not in chebhip.h): select the two-stage kernel for the linear state.
-extern "C" void chebhip_debug_two_stage(int on) { g_two_stage = on ? 1 : 0; }
-
-static bool use_unfused() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("CHEBHIP_UNFUSED"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-
 // the 16-byte kernels with per-array geometry need 16-B aligned MatShell vectors (hipMalloc and PETSc give them); a vector that
 // is not goes through the general kernels
 static inline bool aligned16(const void *q) { return ((size_t)q & 15) == 0; }
@@ -706,9 +691,6 @@ static inline bool aligned16(const void *q) { return ((size_t)q & 15) == 0; }
 // ---- the straight-line fused kernel (fused4.hip): d = 2, 3, every extent even and 66..256, no slab ----
 static bool ell_fused4_ok(ell_op *op) {
   if (op->slab || op->has_long || (op->d != 2 && op->d != 3) || op->G == 0) return false;
-  static int legacy = -1;
-  if (legacy < 0) { const char *e = getenv("CHEBHIP_FUSED_LEGACY"); legacy = (e && e[0] == '1') ? 1 : 0; }
-  if (legacy || (sweep_get_variant() & 16)) return false;
   for (int k = 0; k < op->d; k++) if (!fused4_eligible(op->mats[op->dims[k]])) return false;
   return (size_t)op->N * 16 < 0x38000000ull;
 }
@@ -756,9 +738,7 @@ static int ell_fused4_function(ell_op *op, int k, double gamma, double exponent,
   q.alpha = -1.0;
   q.in = op->w0; q.in_bytes = nbytes; q.coef = op->eta; q.coef_bytes = nbytes; q.gout = op->gradu[k]; q.gout_bytes = nbytes;
   // the reference's default exponent (elliptic.C:141): eta = 1 + gamma w0^2 is formed from the line in LDS instead of being read
-  static int noetasq = -1;
-  if (noetasq < 0) { const char *e = getenv("CHEBHIP_NO_ETASQ"); noetasq = (e && e[0] == '1') ? 1 : 0; }
-  if (exponent == 2.0 && !noetasq) { q.eta_square = 1; q.gamma4 = 0.25 * gamma; }
+  if (exponent == 2.0 && !opt(OPT_ETA_FROM_MEMORY)) { q.eta_square = 1; q.gamma4 = 0.25 * gamma; }
   const bool last = k == d - 1;
   if (!last) {
     if (k == 0) { q.nouter = 1; q.qmax = s0; q.gi = {0, 1, s0}; }         // lines along dimension 0: every (i1, i2)
@@ -823,29 +803,6 @@ static void ell_out_chain(ell_op *op, int k, double *out_global, SweepParams *sp
   if (k == d - 1) { sp->out_mode = OUT_ACC_SCATTER; sp->out = out_global; sp->acc = (d > 1) ? op->W : nullptr; }  // + VecScatter LG (:336)
   else if (k == 0) { sp->out_mode = OUT_STORE; sp->out = op->W; }
   else { sp->out_mode = OUT_ACC; sp->out = op->W; sp->acc = op->W; }
-}
-
-static int ell_mult_unfused(ell_op *op, const double *U, double *V, hipStream_t st) {
-  const int d = op->d;
-  if (op->mode == COEFF_UNIT) {
-    for (int k = 0; k < d; k++) {
-      SweepParams sp = {};
-      sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
-      sp.in0 = U; sp.in_mode = IN_GATHER; sp.gcol = op->gcol[k]; sp.gstride = op->gstride[k];
-      sp.out = op->g[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
-      HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
-    }
-    return ell_divergence(op, IN_PLAIN, op->g.data(), V, st);
-  }
-  hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U,
-                     (const double *)nullptr, op->w0);                          // dirichlet0 == 0
-  for (int k = 0; k < d; k++) {
-    SweepParams sp = {};
-    sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
-    sp.in0 = op->w0; sp.in_mode = IN_PLAIN; sp.out = op->g[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
-    HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
-  }
-  return ell_divergence(op, IN_FLUX_FULL, op->g.data(), V, st);
 }
 
 // One sweep D_k of the slab mode: along dimension 0 through the driver, otherwise a local launch
@@ -931,17 +888,14 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
   if (op->G == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (op->has_long) return ell_mult_plain(op, U, V, st);
-  if (use_unfused()) return ell_mult_unfused(op, U, V, st);
   if (op->mode == COEFF_UNIT) {
     // Linear state (eta == 1, deta == 0; homogeneous Dirichlet rows, elliptic.C:305-308): every
     // array of the apply lives in the interior layout of the global vectors, so there is no
     // gather/scatter at all -- lines through boundary nodes carry zeros in and are not read out.
     // V = -sum_k D_k D_k w0 restricted to the interior, one launch per direction.
-    //  default : the two sweeps of a direction collapse into one product with the interior block
-    //            of D D (constant coefficient), cheb_sweep_kernel, half the MFMA work;
-    //  two-stage (CHEBHIP_TWO_STAGE=1 / chebhip_debug_two_stage): the same fused gradient ->
-    //            flux -> divergence kernel the variable-coefficient path uses.
-    if (op->wpad && !use_two_stage() && !(sweep_get_variant() & 4) && aligned16(U) && aligned16(V)) {
+    // The two sweeps of a direction collapse into one product with the interior block of D D (constant coefficient):
+    // half the MFMA work of the fused gradient -> flux -> divergence launch the variable-coefficient path needs.
+    if (op->wpad && aligned16(U) && aligned16(V)) {
       // d = 2, 3 with lines of more than 64 points: the accumulator W keeps its rows padded to a multiple of
       // 128 B (pitch wpad), so that the strided launches read and write whole cache lines of it; U and V stay
       // dense.  Tiles of the strided directions are (outer index, 32 neighbouring points of the last dimension).
@@ -978,8 +932,7 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
       else if (k == 0) { sp.out_mode = OUT_STORE; sp.out = V; }
       else if (k == op->d - 1) { sp.out_mode = OUT_ACC; sp.out = V; sp.acc = op->W; }
       else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
-      if (use_two_stage()) { sp.trim = 1; sp.coef_mode = COEF_UNIT; HIPCHK(fused_launch(op->mats[op->dims[k]], sp, st)); }
-      else HIPCHK(sweep_launch(op->laps[op->dims[k]], sp, st));
+      HIPCHK(sweep_launch(op->laps[op->dims[k]], sp, st));
     }
     return 0;
   }
@@ -1027,9 +980,8 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
   {
     // Homogeneous Dirichlet rows and the reference's default exponent 2 (elliptic.C:141, :468-476) on the straight-line
     // kernel: three launches on the interior lines, no gather pass; eta / deta are formed from w0 when somebody reads them
-    static int notrim = -1;
-    if (notrim < 0) { const char *e = getenv("CHEBHIP_NO_ETASQ"), *f = getenv("CHEBHIP_NO_TRIMF"); notrim = ((e && e[0] == '1') || (f && f[0] == '1')) ? 1 : 0; }
-    if (!notrim && exponent == 2.0 && !op->dir_nonzero && op->wpad && op->G > 0 && !use_unfused() && ell_fused4_ok(op) && aligned16(U) && aligned16(rhs)) {
+    const bool notrim = opt(OPT_ETA_FROM_MEMORY) || opt(OPT_GATHER_PASS);
+    if (!notrim && exponent == 2.0 && !op->dir_nonzero && op->wpad && op->G > 0 && ell_fused4_ok(op) && aligned16(U) && aligned16(rhs)) {
       if (op->bdy_lines_dirty) {                             // lines inside the boundary: zero in this state, not visited by the launches
         HIPCHK(hipMemsetAsync(op->w0, 0, (size_t)op->N * sizeof(double), st));
         for (int k = 0; k < d; k++) HIPCHK(hipMemsetAsync(op->gradu[k], 0, (size_t)op->N * sizeof(double), st));
@@ -1076,17 +1028,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     HIPCHK(hipGetLastError());
     return 0;
   }
-  if (use_unfused()) {
-    for (int k = 0; k < d; k++) {                                               // gradu[k] = D_k w0 (:497-499)
-      SweepParams sp = {};
-      sp.ncols = op->ncols[k]; sp.inner = op->inner[k];
-      sp.in0 = op->w0; sp.in_mode = IN_PLAIN; sp.out = op->gradu[k]; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
-      HIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
-    }
-    if (op->G == 0) return 0;
-    rc = ell_divergence(op, IN_FLUX_ETA, op->gradu.data(), rhs, st);             // w = eta*gradu (:511), :521-528
-    if (rc) return rc;
-  } else if (ell_fused4_ok(op) && aligned16(rhs)) {
+  if (ell_fused4_ok(op) && aligned16(rhs)) {
     for (int k = 0; k < d; k++) if ((rc = ell_fused4_function(op, k, gamma, exponent, b, rhs, st))) return rc;   // includes rhs -= b (:530)
     return 0;
   } else {

@@ -11,6 +11,7 @@
 //             full-size rehearsal of an N-rank run (tests/test_gpu_dist_emul.py).
 //   CALLBACK  anything else (the gloo staging of the tests).
 #include "comm.h"
+#include "sweep.h"
 #include <dlfcn.h>
 #include <chrono>
 #include <condition_variable>
@@ -126,7 +127,7 @@ extern "C" int chebhip_local_group_create(int nranks, chebhip_local_group **out)
   chebhip_local_group *g = new (std::nothrow) chebhip_local_group;
   if (!g) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
   g->G = nranks;
-  if (const char *e = getenv("CHEBHIP_LOCAL_TIMEOUT")) { double t = atof(e); if (t > 0.0) g->timeout_s = t; }
+  { const int t = chebhip::opt(chebhip::OPT_LOCAL_TIMEOUT_S); if (t > 0) g->timeout_s = (double)t; }   // "local_timeout_s"
   *out = g;
   return 0;
 }
@@ -230,8 +231,8 @@ static int self_copies(const chebhip_comm *c, const XSeg *segs, int nseg, hipStr
 
 static int exchange_rccl(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
   // the own blocks first: nothing that can fail sits between ncclGroupStart and ncclGroupEnd except RCCL itself.
-  // CHEBHIP_DIST_SELF_RCCL=1 (one-rank smoke runs): the own block goes through ncclSend / ncclRecv as well.
-  static const bool self_rccl = [] { const char *e = getenv("CHEBHIP_DIST_SELF_RCCL"); return e && e[0] == '1'; }();
+  // option "rccl_self_messages" (one-rank smoke runs): the own block goes through ncclSend / ncclRecv as well.
+  const bool self_rccl = chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES) != 0;
   if (!self_rccl) { int rc = self_copies(c, segs, nseg, st); if (rc) return rc; }
   bool any = false;
   for (int i = 0; i < nseg; i++) if ((segs[i].peer != c->rank || self_rccl) && (segs[i].nsend > 0 || segs[i].nrecv > 0)) any = true;

@@ -80,9 +80,8 @@ static hipError_t diffmat_create_long(int P, DiffMat *out) {
 }
 
 hipError_t diffmat_create(int P, DiffMat *out) {
-  // CHEBHIP_FORCE_GEMM=1 (A/B measurements only): every extent takes the long-line route, i.e. a library DGEMM
-  static int force = -1;
-  if (force < 0) { const char *e = getenv("CHEBHIP_FORCE_GEMM"); force = (e && e[0] == '1') ? 1 : 0; }
+  // option "force_gemm" (A/B measurements only): every extent takes the long-line route, i.e. a library DGEMM
+  const int force = opt(OPT_FORCE_GEMM);
   if (P > 256 || (force && P >= 4)) return diffmat_create_long(P, out);
   const int n = P - 1;
   const int H = (P + 1) / 2;

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
   const u32 joff = trim ? inner : 0u;
   const int jlo = trim ? 1 : 0;
   const bool need_g = (p.in_mode == IN_GATHER) || (p.out_mode == OUT_ACC_SCATTER);
-  const int ablate = p.ablate;
 
   double ae[KS], ao[KS];
 #pragma unroll
@@ -80,7 +79,6 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
     ao[s] = p.fragO[((long)(mt * KS + s)) * 64 + lane];
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see sweep.hip
-  if (p.variant & 1) { if (w < 4) __builtin_amdgcn_s_setprio(2); }
 
   const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
   // XCD-aware tile walk: workgroups b and b+8 share an XCD (and its L2).  Give each XCD one
@@ -135,11 +133,6 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
     }
   };
   auto issue_loads_any = [&](u32 tile, int chunk, double (&xj_)[CH], double (&xm_)[CH]) {
-    if (ablate & 1) {
-#pragma unroll
-      for (int s = 0; s < CH; s++) { xj_[s] = 1.0 + s; xm_[s] = 0.5; }
-      return;
-    }
     if (p.in_mode == IN_GATHER) issue_loads(mode_c<IN_GATHER>{}, tile, chunk, xj_, xm_);
     else issue_loads(mode_c<IN_PLAIN>{}, tile, chunk, xj_, xm_);
   };
@@ -159,7 +152,6 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
     const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
     const double *fE = sE + frag, *fO = sO + frag;
     ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
-    if (ablate & 4) { ce[0] = fE[0]; co[0] = fO[0]; return; }
     double fb[2][4];
     fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
 #pragma unroll
@@ -301,7 +293,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
         park_chunk(sub, rj, rm);
         if (sub + 1 < NSUB) issue_loads_any(nxt, sub + 1, rj, rm);
       }
-      if (!(ablate & 2) || ce[0] == 12345.678) {
+      {
         const double alpha = p.alpha;
         if (p.out_mode == OUT_STORE) {
 #pragma unroll
@@ -359,8 +351,7 @@ static hipError_t launch_f(const SweepParams &p0, hipStream_t stream) {
 
 hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   if (p.in_mode != IN_PLAIN && p.in_mode != IN_GATHER) return hipErrorInvalidValue;
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero; p.ablate = sweep_get_ablate();
-  p.variant = sweep_get_variant();
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.zero = m.zero;
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_f<4, true>(p, stream) : launch_f<4, false>(p, stream);

@@ -507,8 +507,7 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     OPCHK(hipMemcpy(op->w1[k], b.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
   }
   {
-    const char *e = getenv("CHEBHIP_STOKES_SERIAL");
-    if (!(e && e[0] == '1') && !slab) {
+    if (!opt(OPT_STOKES_SINGLE_STREAM) && !slab) {          // "stokes_single_stream": read when the handle is created
       OPCHK(hipStreamCreateWithFlags(&op->aux, hipStreamNonBlocking));
       OPCHK(hipEventCreateWithFlags(&op->ev_fork, hipEventDisableTiming));
       OPCHK(hipEventCreateWithFlags(&op->ev_join, hipEventDisableTiming));

@@ -63,8 +63,6 @@ struct SweepParams {
   unsigned nouter, qmax;
   unsigned in_os, in_rs, acc_os, acc_rs, out_os, out_rs;
   unsigned in_bytes, acc_bytes, out_bytes;   // set by the launcher: exact sizes for the buffer descriptors of v4
-  int variant;        // profiling only: experimental schedule switches (CHEBHIP_VARIANT)
-  int ablate;         // profiling only (see sweep_set_ablate); 0 in production
 };
 
 // Host description of the even/odd split differentiation matrices for P points.
@@ -100,7 +98,6 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
 // Launches one fused pair: out (+)= alpha * D( coef( D in ) ) along the plan's dimension.
 // in_mode must be IN_PLAIN or IN_GATHER.
 hipError_t fused_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
-int sweep_get_ablate();
 void sweep_note_launch();
 
 // Straight-line fused kernel (fused4.hip).  The launch walks a line space of nouter blocks x qmax lines; element
@@ -141,9 +138,12 @@ hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams 
 long sweep_launch_count();
 // compute units of the CURRENT device (cached per device id); 0 on error with *err set
 int sweep_num_cus(hipError_t *err);
-void sweep_set_ablate(int bits);
-void sweep_set_variant(int bits);
-int sweep_get_variant();
+
+// Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
+// Nothing in the library reads the environment.
+enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_NO_ROCBLAS, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_COUNT };
+int opt(int id);
 
 // Fast diagonalisation of the 1-D three-point operator of the finite-difference preconditioners (diffmat.cpp)
 // Modes are ordered by parity: position p < ceil(M/2) holds the p-th even mode, position M-1-q the q-th odd one

@@ -37,7 +37,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef unsigned u32;
 
 static std::atomic<long> g_launches{0};
-static int g_ablate = 0;   // profiling only: bit0 no global loads, bit1 no stores, bit2 no MFMA, bit3 no LDS park
 long sweep_launch_count() { return g_launches.load(); }
 int sweep_num_cus(hipError_t *err) {
   static std::atomic<int> cache[64];
@@ -52,14 +51,6 @@ int sweep_num_cus(hipError_t *err) {
   if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
   *err = hipSuccess;
   return n;
-}
-void sweep_set_ablate(int bits) { g_ablate = bits; }
-int sweep_get_ablate() { return g_ablate; }
-static int g_variant = -1;  // profiling only: schedule switches of the 16-byte kernels (CHEBHIP_VARIANT / chebhip_debug_variant)
-void sweep_set_variant(int bits) { g_variant = bits; }
-int sweep_get_variant() {
-  if (g_variant < 0) { const char *e = getenv("CHEBHIP_VARIANT"); g_variant = e ? atoi(e) : 0; }
-  return g_variant;
 }
 void sweep_note_launch() { g_launches.fetch_add(1); }
 
@@ -111,7 +102,6 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
   const u32 inner = p.inner, ncols = p.ncols;
   const u32 lineLen = (u32)p.P * inner;
   const bool need_g = (p.in_mode == IN_GATHER) || (p.out_mode == OUT_ACC_SCATTER);
-  const int ablate = p.ablate;
 
   // Matrix fragments -> registers (coalesced 512 B per wave load).
   double ae[KS], ao[KS];
@@ -185,11 +175,6 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
     }
   };
   auto issue_loads_any = [&](u32 tile, int chunk) {
-    if (ablate & 1) {
-#pragma unroll
-      for (int s = 0; s < CH; s++) { rj[s] = 1.0 + s; rm[s] = 0.5; }
-      return;
-    }
     switch (p.in_mode) {
       case IN_PLAIN: issue_loads(mode_c<IN_PLAIN>{}, tile, chunk); break;
       case IN_GATHER: issue_loads(mode_c<IN_GATHER>{}, tile, chunk); break;
@@ -269,8 +254,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
       const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
       const double *fE = sE + frag, *fO = sO + frag;
       constexpr int KSTR = JFAST ? 4 : 4 * NT;             // LDS stride of one k-step
-      if (ablate & 4) { ce[0] = fE[0]; co[0] = fO[0]; }
-      else {
+      {
         double fb[2][4];
         fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
 #pragma unroll
@@ -297,13 +281,10 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
       // Park the prefetched chunk BEFORE issuing this sub-tile's stores: the wait in front of the
       // parity split then covers loads only (vmcnt retires in order; after the stores it would
       // also wait for them to reach memory).
-      if (has_next) {
-        if (!(ablate & 8)) park_chunk(cur ^ 1, sub);
-        else { double t = 0; for (int s = 0; s < CH; s++) t += rj[s] + rm[s]; if (t == 12345.678) park_chunk(cur ^ 1, sub); }
-      }
+      if (has_next) park_chunk(cur ^ 1, sub);
       // ---- stores: accumulator element r of a lane is row 4r + (lane >> 4), col lane & 15 ----
       if (p.sym) { const v4d t = ce; ce = co; co = t; }   // centro-symmetric matrix: y_{n-i} = a - b, i.e. the roles of a and b swap in (b - a)
-      if (!(ablate & 2) || ce[0] == 12345.678) {
+      {
         const double alpha = p.alpha;
         if (p.out_mode == OUT_STORE) {
 #pragma unroll
@@ -432,8 +413,7 @@ RocblasApi g_rb;
 
 bool rocblas_ready() {
   std::call_once(g_rb.once, [] {
-    const char *off = getenv("CHEBHIP_NO_ROCBLAS");
-    if (off && off[0] == '1') return;
+    if (opt(OPT_NO_ROCBLAS)) return;                     // "no_rocblas": set before the first long-line launch
     const char *names[] = {"librocblas.so.5", "librocblas.so.4", "librocblas.so"};
     for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // already in the process?
     for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -506,13 +486,11 @@ static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
-  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym; p.ablate = g_ablate; p.variant = sweep_get_variant();
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym;
   p.longDT = m.longDT; p.longD = m.longD;
   if (m.KS == 0) return m.longDT ? launch_long(p, stream) : hipErrorInvalidValue;
   {
-    static int novec = -1;
-    if (novec < 0) { const char *e = getenv("CHEBHIP_NOVEC"); novec = (e && e[0] == '1') ? 1 : 0; }
-    if (!novec && sweep_vec_eligible(m, p)) {
+    if (!opt(OPT_GENERAL_KERNELS) && sweep_vec_eligible(m, p)) {
       // diagnostic builds: three stamp areas of 256 x 8 x 8 words, used round-robin (one per launch of a 3-D matvec)
       if (chebhip_stamp_buf()) p.in4 = chebhip_stamp_buf() + (size_t)(chebhip_stamp_next() % 3) * (256 * 8 * 8);
       return sweep_vec_launch(m, p, stream);
@@ -531,13 +509,11 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
 
 static void sweep_fill(const DiffMat &m, SweepParams &p) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink;
-  p.sym = m.sym; p.ablate = g_ablate; p.variant = sweep_get_variant(); p.longDT = m.longDT; p.longD = m.longD;
+  p.sym = m.sym; p.longDT = m.longDT; p.longD = m.longD;
 }
 
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {
-  static int nomulti = -1;
-  if (nomulti < 0) { const char *e = getenv("CHEBHIP_NOMULTI"); nomulti = (e && e[0] == '1') ? 1 : 0; }
-  if (n >= 2 && n <= 3 && !nomulti) {
+  if (n >= 2 && n <= 3 && !opt(OPT_SEPARATE_LAUNCHES)) {
     SweepParams jobs[3];
     bool ok = true;
     for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); ok = ok && m[j]->KS != 0; }

@@ -101,14 +101,8 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
   d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
   const d2 *zero2 = (const d2 *)p.zero;
 
-  const int ablate = p.ablate;   // profiling only (sweep.h)
   const bool raw_in = p.raw == 2, raw_out = p.raw == 1;   // the line transforms of precond.hip (sweep.h)
   auto issue_loads = [&](u32 tile, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
-    if (ablate & 1) {
-#pragma unroll
-      for (int s = 0; s < CH; s++) { rj[s] = d2{1.0 + s, 2.0}; rm[s] = d2{0.5, 0.25}; }
-      return;
-    }
     if (!JFAST) {
       const u32 o = tile / tpo, q0 = (tile - o * tpo) * NT;
       const u32 q = q0 + 2 * ld_a;
@@ -232,7 +226,7 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
       }
       // the VecAXPY operand of this sub-tile: fetched early in the chain (staggered like the loads)
       auto acc_fn = [&] {
-        if (acc_on && !(ablate & 1)) {
+        if (acc_on) {
 #pragma unroll
           for (int rp = 0; rp < 2; rp++) {
             acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
@@ -246,8 +240,7 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
       STAMP(st_t1); st_pre += st_t1 - st_t0;
 #endif
       v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
-      if (ablate & 4) { ce[0] = sE[l16]; co[0] = sO[l16]; }
-      else {
+      {
         const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
         const double *fE = sE + frag, *fO = sO + frag;
         double fb[2][4];
@@ -307,7 +300,6 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
         if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};   // (y_ie, y_{n-ie}) : adjacent when H is odd
         vh = acc_hi[rp] + alpha * vh;
         vl = acc_lo[rp] + alpha * vl;
-        if ((ablate & 2) && vh.x != 12345.678) continue;
         if (ok_hi[rp]) *(d2 *)(p.out + a_hi[rp]) = vh;
         if (ok_lo[rp]) *(d2 *)(p.out + a_lo[rp]) = vl;
       }
@@ -363,281 +355,24 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// v3: the kernel with a STRAIGHT-LINE tile loop (KS >= 16, i.e. lines of more than 64 points), flat addressing.
-// Since round 2 it is the fallback of v4 for arrays of 1 GiB and more (v4's 32-bit buffer offsets do not reach).
+// cheb_sweep_vec4_kernel: the kernel for lines of more than 64 points (KS >= 16) -- a STRAIGHT-LINE tile loop with as few
+// VALU instructions as the algorithm allows.
 //
-// gfx950 retires loads and stores through one in-order counter (vmcnt).  hipcc places the waits,
-// and it can only count exactly through straight-line code: a branch around a load or store (a
-// "has next tile" test, an exec-masked store, the two in-chain positions of the wave groups) makes
-// it fall back to vmcnt(0), which waits for EVERYTHING in flight -- including the prefetch issued a
-// few hundred cycles earlier.  Here the loop body has no branch around any memory instruction:
-//   * the loop is instantiated once per wave group (GRPB), so the in-chain placement is static;
-//   * masked-off loads (tiles past the workgroup's last, lanes outside the tile) read a zero word,
-//     masked-off stores go to a per-lane sink word;
-//   * STORE and ACC are separate instantiations.
-// With exact counts the operand pipeline can be deep: line chunks ride under two MFMA chains, the
-// VecAXPY operand is requested one sub-tile ahead into its own register set (X / Y), and the wait
-// for it does not cover the stores issued in between.  Per-array geometry (sweep.h): input, VecAXPY
-// operand and output may have different row pitches.
-// Tried and dropped here (measured, round 2): deferring the second epilogue of waves 4-7 by one tile so that
-// one wave of a SIMD stores while the other is in its chain (MI355X_MICROARCH.md "Two waves per SIMD", item 9):
-// 257 us per 256^3 matvec against 255 without, 264 with s_setprio 1 on those waves.
-template <int KS, bool JFAST, bool ACC>
-__global__ __launch_bounds__(512) void cheb_sweep_vec3_kernel(const SweepParams p) {
-  constexpr int MTP = KS / 4;
-  constexpr int NG = 8 / MTP;
-  constexpr int HP = 4 * KS;
-  constexpr int NSUB = 2;
-  constexpr int NT = 16 * NG * NSUB;
-  constexpr int LDJ = HP + 2;
-  constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
-  constexpr int ITEMS = HP * NT / 2 / 512;
-  constexpr int CH = ITEMS / NSUB;
-  constexpr int QSTEP = JFAST ? 512 / (HP / 2) : 512 / (NT / 2);
-  constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
-  constexpr int KSTR = JFAST ? 4 : 4 * NT;
-  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
-  constexpr int KR = KS - NFL;
-  static_assert(KS >= 16 && CH >= 1, "v3 needs two sub-tiles per tile");
-  __shared__ double smem[4 * LDS_ELEMS + 8 * NFL * 64];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int mt = w % MTP, ng = w / MTP;
-  const int kq = lane >> 4, l16 = lane & 15;
-  const int odd = l16 & 1, l16e = l16 & ~1;
-  const int nn = p.P - 1, H = p.H;
-  const u32 qmax = p.qmax, ncols = p.ncols;
-  const u32 in_os = p.in_os, in_rs = p.in_rs;
-
-  double ae[KS], ao[KR > 0 ? KR : 1];
-  double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
-
-  const u32 tpo = JFAST ? 1u : (qmax + NT - 1) / NT;
-  const u32 nxcd = (gridDim.x % 8 == 0) ? 8u : 1u;
-  const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
-  const u32 t_lo = (blockIdx.x % nxcd) * t_per;
-  const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
-  const u32 t_step = gridDim.x / nxcd;
-
-  const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
-  const int ld_b = JFAST ? tid / (HP / 2) : tid / (NT / 2);
-  const int ld_lds0 = JFAST ? ld_b * LDJ + 2 * ld_a : ld_b * NT + ((2 * ld_a) ^ ((ld_b & 1) << 4));
-  const d2 *zero2 = (const d2 *)p.zero;
-  d2 *sink2 = (d2 *)p.sink + tid;
-  const int i0 = mt * 16 + (JFAST ? l16 : kq);
-  const double alpha = p.alpha;
-
-  d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
-  d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];
-
-  // `valid` false (a tile past the workgroup's last): every slot reads the zero word
-  auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
-    if (!JFAST) {
-      const u32 o = tl / tpo, q0 = (tl - o * tpo) * NT;
-      const u32 q = q0 + 2 * ld_a;
-      const bool cv = valid & (q < qmax);                    // qmax is even: the pair is in or out together
-      const u32 base = o * in_os + q;
-      int jp = ld_b + chunk * CH * QSTEP;
-      u32 rel = (u32)jp * in_rs;
-      const u32 top = base + (u32)nn * in_rs;
-      asm volatile("" : "+v"(rel), "+v"(jp));
-#pragma unroll
-      for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * in_rs) {
-        const bool ok = cv & (jp < H);
-        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
-        rm[s] = *((ok & (nn - jp != jp)) ? (const d2 *)(p.in0 + (top - rel)) : zero2);
-      }
-    } else {
-      const int j = 2 * ld_a;
-#pragma unroll
-      for (int s = 0; s < CH; s++) {
-        const u32 c = tl * NT + ld_b + (chunk * CH + s) * QSTEP;
-        const bool ok = valid & (c < ncols) & (j < H);
-        const u32 base = (ok ? c : 0u) * in_os;
-        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
-        rm[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
-      }
-    }
-  };
-  auto park_chunk = [&](int buf, int chunk, const d2 (&rj)[CH], const d2 (&rm)[CH]) {
-    double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
-#pragma unroll
-    for (int s = 0; s < CH; s++) {
-      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
-      d2 e, o;
-      if (!JFAST) {
-        const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn;
-        e = rj[s] + rm[s];
-        o = rj[s] - rm[s];
-        if (mid) o = d2{0.0, 0.0};
-      } else {
-        const bool v1 = 2 * ld_a + 1 < H;
-        e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
-        o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
-      }
-      *(d2 *)(dE + idx) = e;
-      *(d2 *)(dO + idx) = o;
-    }
-  };
-  // offsets of the two 16-B pieces (row i / mirror row n-i) of pair rp in an array of geometry (os, rs)
-  auto geom = [&](u32 tl, bool valid, int sub, u32 os, u32 rs, u32 (&a_hi)[2], u32 (&a_lo)[2], bool (&ok_hi)[2], bool (&ok_lo)[2], bool (&fold)[2]) {
-    const int nb = (ng * NSUB + sub) * 16;
-    const u32 g_o = tl / tpo, g_q0 = (tl - g_o * tpo) * NT;
-    int i0o = i0;
-    asm volatile("" : "+v"(i0o));
-#pragma unroll
-    for (int rp = 0; rp < 2; rp++) {
-      const int r = 2 * rp + odd;
-      if (!JFAST) {
-        const u32 q = g_q0 + nb + l16e;
-        const int i = i0o + 4 * r;
-        const u32 b = g_o * os + q;
-        ok_hi[rp] = valid & (q < qmax) & (i < H);
-        ok_lo[rp] = ok_hi[rp] & (nn - i != i);
-        fold[rp] = false;
-        a_hi[rp] = b + (u32)i * rs;
-        a_lo[rp] = b + (u32)(nn - i) * rs;
-      } else {
-        const u32 c = tl * NT + nb + 4 * r + kq;
-        const int ie = mt * 16 + l16e;
-        const u32 b = (c < ncols ? c : 0u) * os;
-        ok_hi[rp] = valid & (c < ncols) & (ie < H);
-        fold[rp] = ok_hi[rp] & (ie + 1 >= H);
-        ok_lo[rp] = ok_hi[rp] & !fold[rp];
-        a_hi[rp] = b + (u32)ie;
-        a_lo[rp] = b + (u32)(nn - ie - 1);
-      }
-    }
-  };
-  auto acc_issue = [&](u32 tl, bool valid, int sub, d2 (&ah)[2], d2 (&al)[2]) {
-    if (!ACC) return;
-    u32 a_hi[2], a_lo[2]; bool ok_hi[2], ok_lo[2], fold[2];
-    geom(tl, valid, sub, p.acc_os, p.acc_rs, a_hi, a_lo, ok_hi, ok_lo, fold);
-#pragma unroll
-    for (int rp = 0; rp < 2; rp++) {
-      ah[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
-      al[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
-    }
-  };
-
-  u32 tile = t_lo + blockIdx.x / nxcd;
-  if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
-  // the first tile's lines are requested BEFORE the matrix fragments: one memory round trip instead of two
-  issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
-    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
-    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see sweep.hip
-  park_chunk(0, 0, rjA, rmA); park_chunk(0, 1, rjB, rmB);
-
-  // one MFMA chain over sub-tile `sub` of the LDS buffer at sE/sO; issue_fn / park_fn sit inside it
-  auto chain = [&](const double *sE, const double *sO, int sub, int g_issue, int g_park, v4d &ce, v4d &co, auto &&issue_fn, auto &&park_fn) {
-    const int nb = (ng * NSUB + sub) * 16;
-    ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
-    const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
-    const double *fE = sE + frag, *fO = sO + frag;
-    double fb[2][4];
-    fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
-#pragma unroll
-    for (int g = 0; g < KS / 2; g++) {
-      const int cb = g & 1, nbuf = cb ^ 1;
-      if (g + 1 < KS / 2) {
-        fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
-        fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
-      }
-      __builtin_amdgcn_sched_barrier(0);               // fragment reads stay one group ahead of their MFMAs
-      if (g == g_issue) issue_fn();
-      if (g == g_park) park_fn();
-      if (!JFAST) {
-        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
-        co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g), fb[cb][2], co, 0, 0, 0);
-        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
-        co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g + 1), fb[cb][3], co, 0, 0, 0);
-      } else {
-        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
-        co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], AO(2 * g), co, 0, 0, 0);
-        ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
-        co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], AO(2 * g + 1), co, 0, 0, 0);
-      }
-    }
-  };
-  // out = (acc +) alpha * (sums) for sub-tile `sub` of tile tl; !valid: every store hits the sink
-  auto epilogue = [&](u32 tl, bool valid, int sub, const v4d &ce, const v4d &co, const d2 (&acc_hi)[2], const d2 (&acc_lo)[2]) {
-    u32 a_hi[2], a_lo[2];
-    bool ok_hi[2], ok_lo[2], fold[2];
-    geom(tl, valid, sub, p.out_os, p.out_rs, a_hi, a_lo, ok_hi, ok_lo, fold);
-    double hi[4], lo[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
-#pragma unroll
-    for (int rp = 0; rp < 2; rp++) {
-      const double own_hi = odd ? hi[2 * rp + 1] : hi[2 * rp], snd_hi = odd ? hi[2 * rp] : hi[2 * rp + 1];
-      const double own_lo = odd ? lo[2 * rp + 1] : lo[2 * rp], snd_lo = odd ? lo[2 * rp] : lo[2 * rp + 1];
-      const double rcv_hi = swap1(snd_hi), rcv_lo = swap1(snd_lo);
-      d2 vh = odd ? d2{rcv_hi, own_hi} : d2{own_hi, rcv_hi};
-      d2 vl;
-      if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
-      else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};
-      if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};
-      if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha * vl; }
-      else { vh = alpha * vh; vl = alpha * vl; }
-      *(ok_hi[rp] ? (d2 *)(p.out + a_hi[rp]) : sink2) = vh;     // unconditional: masked-off lanes hit the sink
-      *(ok_lo[rp] ? (d2 *)(p.out + a_lo[rp]) : sink2) = vl;
-    }
-  };
-
-  auto run_plain = [&](auto GRPB_) {
-    constexpr bool GRPB = decltype(GRPB_)::value;
-    constexpr int G_ISSUE = GRPB ? 0 : KS / 8, G_PARK = GRPB ? KS / 4 : 3 * KS / 8;
-    {
-      // reproduce the in-flight state of the loop's back edge (operand X, chunk A, four stores) so
-      // that the wait counts of the loop hold from iteration 0
-      const u32 nx = tile + t_step;
-      acc_issue(tile, true, 0, accX_hi, accX_lo);
-      issue_loads(nx, nx < t_hi, 0, rjA, rmA);
-#pragma unroll
-      for (int q = 0; q < 4; q++) *sink2 = d2{0.0, 0.0};
-    }
-    lds_barrier_v();
-    int cur = 0;
-    for (; tile < t_hi; tile += t_step) {
-      const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
-      const bool v1 = nxt < t_hi, v2 = nxt2 < t_hi;
-      const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
-      v4d ce, co;
-      chain(sE, sO, 0, G_ISSUE, G_PARK, ce, co,
-            [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
-            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
-      epilogue(tile, true, 0, ce, co, accX_hi, accX_lo);
-      chain(sE, sO, 1, G_ISSUE, G_PARK, ce, co,
-            [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
-            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
-      epilogue(tile, true, 1, ce, co, accY_hi, accY_lo);
-      lds_barrier_v();
-      cur ^= 1;
-    }
-  };
-  if (w >= 4) run_plain(std::true_type{}); else run_plain(std::false_type{});
-}
-
-template <int KS, bool JFAST>
-static hipError_t launch_v3(const SweepParams &p, unsigned grid, hipStream_t stream) {
-  if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec3_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((cheb_sweep_vec3_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
-  sweep_note_launch();
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// v4: the straight-line kernel with as few VALU instructions as the algorithm allows.
+// gfx950 retires loads and stores through one in-order counter (vmcnt).  hipcc places the waits, and it can only count
+// exactly through straight-line code: a branch around a load or store (a "has next tile" test, an exec-masked store,
+// the two in-chain positions of the wave groups) makes it fall back to vmcnt(0), which waits for EVERYTHING in flight --
+// including the prefetch issued a few hundred cycles earlier.  Here the loop body has no branch around any memory
+// instruction: the loop is instantiated once per wave group (GRPB), so the in-chain placement is static; STORE and ACC
+// are separate instantiations; masking is done by the buffer range check.  With exact counts the operand pipeline can be
+// deep: line chunks ride under two MFMA chains, the VecAXPY operand is requested one sub-tile ahead into its own register
+// set (X / Y), and the wait for it does not cover the stores issued in between.  Per-array geometry (sweep.h): input,
+// VecAXPY operand and output may have different row pitches.
 //
 // On gfx950 the FP64 MFMA and the VALU do not co-execute (SQ_VALU_MFMA_COEXEC_CYCLES reads 0 for every launch
 // of this kernel, profiles/r02_*; the FP64 matrix rate equals the FP64 vector rate): every vector instruction
-// of a wave is paid in matrix-pipe time, ~6 cycles each, and v3 issued 300-450 of them per tile and wave next
-// to 128 MFMAs (in-kernel stamps: an epilogue beside the partner wave's chain took 4,400 cycles).  Here
+// of a wave is paid in matrix-pipe time, ~6 cycles each, and the flat-address predecessor of this kernel (round 1-2,
+// deleted) issued 300-450 of them per tile and wave next to 128 MFMAs (in-kernel stamps: an epilogue beside the partner
+// wave's chain took 4,400 cycles).  Here
 //   * every global access is a raw BUFFER access: 32-bit byte offset = per-lane constant + one scalar per
 //     tile (one v_add), the hardware range check replaces every `ok ? address : dummy` select (out-of-range
 //     loads return 0, out-of-range stores are dropped; a masked lane gets offset 0x80000000);
@@ -1000,12 +735,14 @@ static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t str
   return hipGetLastError();
 }
 
-// Geometry defaults, tile count and (v4) the byte sizes of the buffer descriptors.  Returns 4 / 3 / 1: which kernel
-// generation can run the launch, 0: none (per-array geometry on short lines).
+// Geometry defaults, tile count and (KS >= 16) the byte sizes of the buffer descriptors.  Returns 4: cheb_sweep_vec4_kernel
+// runs the launch; 1: cheb_sweep_vec_kernel (lines of at most 64 points, dense geometry); 0: neither (per-array geometry
+// on short lines, or an array of 0.94 GB and more -- the 32-bit buffer offsets of the long-line kernel do not reach;
+// the general kernel of sweep.hip runs those).
 template <int KS, bool JFAST>
 static int prepare_v(SweepParams &p) {
   constexpr int MTP = KS / 4, NG = 8 / MTP, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB;
-  const bool custom = p.qmax != 0 || p.in_os != 0;         // per-array geometry given by the caller (v3 / v4 only)
+  const bool custom = p.qmax != 0 || p.in_os != 0;         // per-array geometry given by the caller (KS >= 16 only)
   if (JFAST) {
     if (!p.in_os) p.in_os = (unsigned)p.P;
     if (!p.acc_os) p.acc_os = (unsigned)p.P;
@@ -1020,50 +757,53 @@ static int prepare_v(SweepParams &p) {
     p.ntiles = p.nouter * ((p.qmax + NT - 1) / NT);
   }
   if constexpr (KS >= 16) {
-    static int v1 = -1;
-    if (v1 < 0) { const char *e = getenv("CHEBHIP_VEC_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
-    if (!v1 && !p.ablate && p.sink) {
-      // byte sizes of the three arrays for the buffer descriptors of v4 (exact: the range check is the mask)
-      const unsigned long long P_ = (unsigned long long)p.P;
-      auto span = [&](unsigned os, unsigned rs) -> unsigned long long {
-        if (JFAST) return ((unsigned long long)(p.ncols - 1) * os + P_) * 8ull;
-        return ((unsigned long long)(p.nouter - 1) * os + (p.qmax - 1) + (P_ - 1) * rs + 1) * 8ull;
-      };
-      const unsigned long long bi = span(p.in_os, p.in_rs), ba = span(p.acc_os, p.acc_rs), bo = span(p.out_os, p.out_rs);
-      const bool fits = bi < 0x38000000ull && ba < 0x38000000ull && bo < 0x38000000ull;   // < 1 GiB minus slack: see T_INVALID
-      if (fits && !(p.variant & 8)) {
-        p.in_bytes = (unsigned)bi; p.acc_bytes = (unsigned)ba; p.out_bytes = (unsigned)bo;
-        return 4;
-      }
-      return 3;
-    }
+    if (!p.sink) return 0;
+    // byte sizes of the three arrays for the buffer descriptors (exact: the range check is the mask)
+    const unsigned long long P_ = (unsigned long long)p.P;
+    auto span = [&](unsigned os, unsigned rs) -> unsigned long long {
+      if (JFAST) return ((unsigned long long)(p.ncols - 1) * os + P_) * 8ull;
+      return ((unsigned long long)(p.nouter - 1) * os + (p.qmax - 1) + (P_ - 1) * rs + 1) * 8ull;
+    };
+    const unsigned long long bi = span(p.in_os, p.in_rs), ba = span(p.acc_os, p.acc_rs), bo = span(p.out_os, p.out_rs);
+    if (!(bi < 0x38000000ull && ba < 0x38000000ull && bo < 0x38000000ull)) return 0;   // < 1 GiB minus slack: see T_INVALID
+    p.in_bytes = (unsigned)bi; p.acc_bytes = (unsigned)ba; p.out_bytes = (unsigned)bo;
+    return 4;
   }
-  return custom ? 0 : 1;                                   // per-array geometry exists in the v3 / v4 kernels only
+  return custom ? 0 : 1;
 }
+
+// Workgroups of a persistent launch per CU.  Lines of at most 64 points (KS <= 8) need 64-70 KiB of LDS and at most 124
+// VGPRs per workgroup: two fit on a CU, and at such sizes (64^3: a few tiles per workgroup) one workgroup's memory round
+// trips then overlap the other's MFMA chains, and the tiles divide more evenly over the walkers.
+template <int KS> constexpr int wgs_per_cu() { return KS <= 8 ? 2 : 1; }
 
 template <int KS, bool JFAST>
 static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   SweepParams p = p0;
   const int gen = prepare_v<KS, JFAST>(p);
-  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (gen == 0) return hipErrorInvalidValue;             // sweep_vec_eligible said otherwise
+  hipError_t cu_err; int ncu = sweep_num_cus(&cu_err);
   if (cu_err != hipSuccess) return cu_err;
+  ncu *= wgs_per_cu<KS>();
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
   if (grid == 0) return hipSuccess;
-  if constexpr (KS >= 16) {
-    if (gen == 4) return launch_v4<KS, JFAST>(p, grid, stream);
-    if (p.raw) return hipErrorInvalidValue;              // see sweep_vec_raw_eligible
-    if (gen == 3) return launch_v3<KS, JFAST>(p, grid, stream);
+  if constexpr (KS >= 16) return launch_v4<KS, JFAST>(p, grid, stream);
+  else {
+    if (p.raw && p.out_mode != OUT_STORE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
+    sweep_note_launch();
+    return hipGetLastError();
   }
-  if (gen == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
-  sweep_note_launch();
-  return hipGetLastError();
 }
 
-bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p) {
+template <int KS>
+static bool prepare_ok_t(SweepParams p, bool jfast) { return (jfast ? prepare_v<KS, true>(p) : prepare_v<KS, false>(p)) != 0; }
+
+bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
+  const SweepParams &p = p0;
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
   const bool jfast = p.inner < 16;
-  if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: v3 / v4 only, every offset must stay 16-B aligned
+  if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: the long-line kernel only, every offset must stay 16-B aligned
     if (m.KS < 16) return false;
     const unsigned all = p.qmax | p.in_os | p.in_rs | p.acc_os | p.acc_rs | p.out_os | p.out_rs;
     if (jfast ? ((p.in_os | p.acc_os | p.out_os) & 1) : (all & 1)) return false;
@@ -1072,29 +812,21 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p) {
   if (!jfast && (p.inner & 1)) return false;
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
   if (!al(p.in0) || !al(p.out) || (p.out_mode == OUT_ACC && !al(p.acc))) return false;
-  return m.KS == 4 || m.KS == 8 || m.KS == 16 || m.KS == 32;
-}
-
-template <int KS>
-static bool raw_ok_t(SweepParams p, bool jfast) {
-  const int gen = jfast ? prepare_v<KS, true>(p) : prepare_v<KS, false>(p);
-  return KS >= 16 ? gen == 4 : gen == 1;
-}
-bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p0) {
-  if (p0.out_mode != OUT_STORE || !sweep_vec_eligible(m, p0)) return false;
-  static int noraw = -1;
-  if (noraw < 0) { const char *e = getenv("CHEBHIP_NORAW"); noraw = (e && e[0] == '1') ? 1 : 0; }
-  if (noraw) return false;
-  SweepParams p = p0;
-  p.P = m.P; p.H = m.H; p.sink = m.sink; p.ablate = sweep_get_ablate(); p.variant = sweep_get_variant();
-  const bool jfast = p.inner < 16;
+  SweepParams q = p0;                                    // sizes: the buffer offsets must reach (prepare_v)
+  q.P = m.P; q.H = m.H; q.sink = m.sink;
   switch (m.KS) {
-    case 4: return raw_ok_t<4>(p, jfast);
-    case 8: return raw_ok_t<8>(p, jfast);
-    case 16: return raw_ok_t<16>(p, jfast);
-    case 32: return raw_ok_t<32>(p, jfast);
+    case 4: return prepare_ok_t<4>(q, jfast);
+    case 8: return prepare_ok_t<8>(q, jfast);
+    case 16: return prepare_ok_t<16>(q, jfast);
+    case 32: return prepare_ok_t<32>(q, jfast);
     default: return false;
   }
+}
+
+// ... and may carry p.raw != 0: the raw modes (sweep.h) are STORE-only
+bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p0) {
+  if (p0.out_mode != OUT_STORE || opt(OPT_NO_RAW_TRANSFORMS)) return false;
+  return sweep_vec_eligible(m, p0);
 }
 
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
@@ -1115,20 +847,20 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
   for (int j = 0; j < n; j++) if (jobs[j].raw) { *done = false; return hipSuccess; }
   MultiParams mp = {};
   mp.njobs = n;
-  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  hipError_t cu_err; int ncu = sweep_num_cus(&cu_err);
   if (cu_err != hipSuccess) return cu_err;
+  ncu *= wgs_per_cu<KS>();
   unsigned long long total = 0;
   for (int j = 0; j < n; j++) {
     SweepParams &p = jobs[j];
     const bool jfast = p.inner < 16;
     const int gen = jfast ? prepare_v<KS, true>(p) : prepare_v<KS, false>(p);
-    if (gen != (KS >= 16 ? 4 : 1)) return hipSuccess;      // not for this launch: done stays false
+    if (gen == 0) return hipSuccess;                       // not for this launch: done stays false
     total += p.ntiles;
   }
   // One workgroup per CU in all, shared out in proportion to the jobs' tiles: every workgroup walks several tiles with
   // its prefetch pipeline running (one fill, one drain per launch) instead of the jobs taking the chip one after another.
-  static int split = -1;
-  if (split < 0) { const char *e = getenv("CHEBHIP_MULTI_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+  const int split = opt(OPT_EQUAL_SHARES) ? 0 : 1;
   unsigned gs[MULTI_MAX];
   for (int j = 0; j < n; j++) {
     const unsigned nt = jobs[j].ntiles;
@@ -1167,7 +899,7 @@ hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *j
   *done = false;
   if (n < 1 || n > MULTI_MAX) return hipSuccess;
   for (int j = 0; j < n; j++) {
-    if (m[j]->KS != m[0]->KS || jobs[j].out_mode != OUT_STORE || !sweep_vec_eligible(*m[j], jobs[j]) || jobs[j].ablate) return hipSuccess;
+    if (m[j]->KS != m[0]->KS || jobs[j].out_mode != OUT_STORE || !sweep_vec_eligible(*m[j], jobs[j])) return hipSuccess;
   }
   switch (m[0]->KS) {
     case 4: return launch_multi_t<4>(n, jobs, stream, done);

@@ -65,7 +65,9 @@ class HipBackend:
 
 
 class DistPoissonOp:
-    def __init__(self, dims, backend, group=None):
+    def __init__(self, dims, backend, group=None, force_a2a=False, serial=False):
+        """force_a2a: run the collectives even with one rank (rehearsals of the real backend); serial: everything on the
+        caller's stream (no overlap of the local sweeps with the exchanges, but no cross-stream dependencies either)."""
         assert len(dims) >= 2, "slab partitioning needs at least two dimensions"
         self.dims = tuple(int(d) for d in dims)
         self.M = tuple(d - 2 for d in self.dims)
@@ -99,10 +101,7 @@ class DistPoissonOp:
         self.sendbuf = torch.empty(self.local_size, dtype=torch.float64, device=dev)
         self.UT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
         self.TT = torch.empty(self.pencil_size, dtype=torch.float64, device=dev)
-        forced = dist.is_initialized() and os.environ.get("CHEBHIP_DIST_FORCE_A2A") == "1"
-        # CHEBHIP_DIST_SERIAL=1: everything on the caller's stream (no overlap of the local sweeps with the exchanges,
-        # but no cross-stream dependencies either)
-        serial = os.environ.get("CHEBHIP_DIST_SERIAL") == "1"
+        forced = self.force_a2a = bool(force_a2a) and dist.is_initialized()
         self.comm_stream = backend.side_stream() if ((G > 1 or forced) and not serial) else None
         self.A = []
 
@@ -115,7 +114,7 @@ class DistPoissonOp:
         return full[self.s0[r]:self.s0[r + 1]].reshape(-1).contiguous().to(self.backend.device)
 
     def _a2a(self, out, inp, out_split, in_split):
-        if self.G == 1 and not (dist.is_initialized() and os.environ.get("CHEBHIP_DIST_FORCE_A2A") == "1"):
+        if self.G == 1 and not self.force_a2a:
             out.copy_(inp)
         elif inp.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal only (several ranks sharing one GPU, BENCH_DIST_BACKEND=gloo): stage through the host
@@ -163,8 +162,9 @@ class DistPoissonC:
     a transport -- an RCCL communicator made from a unique id that rank 0 broadcasts through the process group
     (backend "nccl"), or, for rehearsals on one GPU under gloo, a callback that stages the exchange through the host."""
 
-    def __init__(self, dims, sp, group=None, comm=None):
-        """comm: a Comm (e.g. one rank of a LocalGroup) instead of the process group's transport."""
+    def __init__(self, dims, sp, group=None, comm=None, force_a2a=False):
+        """comm: a Comm (e.g. one rank of a LocalGroup) instead of the process group's transport; force_a2a: go through
+        the transport even with one rank (one-rank rehearsals of the real backend)."""
         import ctypes as C
         self.sp, self.group = sp, group
         self.dims = tuple(int(v) for v in dims)
@@ -181,7 +181,7 @@ class DistPoissonC:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._comm = None
         self._cb = None
-        forced = dist.is_initialized() and os.environ.get("CHEBHIP_DIST_FORCE_A2A") == "1"
+        forced = bool(force_a2a) and dist.is_initialized()
         if comm is not None:
             sp._chk(L.chebhip_dist_use_comm(h, comm._h))
         elif self.G > 1 or forced:

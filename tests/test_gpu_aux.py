@@ -207,3 +207,72 @@ def test_two_host_threads_with_their_own_handles():
     for tag in ("a", "b"):
         U, V, dims = results[tag]
         assert relerr(V, orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=8)) < 1e-10
+
+
+def test_options_and_kernel_families_agree():
+    """chebhip_set_option (the library's only switches; it never reads the environment): unknown names fail, values read
+    back, and the kernel families an option selects give the same operator: the general 8-byte sweep kernel against the
+    16-byte kernels at 96^3, separate launches against the multi-job launch of the Stokes sweeps, FormFunction with and
+    without its gather pass."""
+    import ctypes as C
+    import numpy as np
+    L = sp.lib()
+    assert L.chebhip_set_option(b"no_such_option", 1) == 4 and b"unknown option" in L.chebhip_last_error()
+    names = sp.options()
+    assert {"general_kernels", "separate_launches", "gather_pass", "local_timeout_s"} <= set(names) and names["local_timeout_s"] == 120
+    sp.set_option("equal_shares", 1); assert sp.get_option("equal_shares") == 1; sp.set_option("equal_shares", 0)
+    dims = (96, 96, 96)
+    op = sp.EllipticOp(dims)
+    U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
+    b = torch.randn_like(U); us = torch.rand_like(U) + 0.5
+    V0, V1, R0, R1 = (torch.empty_like(U) for _ in range(4))
+    op.mult(U, V0)                                       # linear state: the D D kernels
+    try:
+        sp.set_option("general_kernels", 1)
+        op.mult(U, V1)
+    finally:
+        sp.set_option("general_kernels", 0)
+    op.function(us, b, R0, 1.5, 2.0)                     # interior-line path, eta on chip
+    J0, J1 = torch.empty_like(U), torch.empty_like(U)
+    op.mult(U, J0)                                       # Jacobian apply from that state
+    try:
+        sp.set_option("gather_pass", 1); sp.set_option("eta_from_memory", 1)
+        op.function(us, b, R1, 1.5, 2.0)
+        op.mult(U, J1)
+    finally:
+        sp.set_option("gather_pass", 0); sp.set_option("eta_from_memory", 0)
+    torch.cuda.synchronize()
+    assert float((V1 - V0).norm() / V0.norm()) < 1e-12 and float((R1 - R0).norm() / R0.norm()) < 1e-12
+    assert float((J1 - J0).norm() / J0.norm()) < 1e-12
+    op.destroy()
+    st = sp.StokesOp((48, 40, 36))
+    x = torch.randn(st.global_size, dtype=torch.float64, device="cuda"); y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    st.mult(x, y0)
+    try:
+        sp.set_option("separate_launches", 1)
+        st.mult(x, y1)
+    finally:
+        sp.set_option("separate_launches", 0)
+    torch.cuda.synchronize()
+    assert float((y1 - y0).norm() / y0.norm()) < 1e-13
+    st.destroy()
+
+
+def test_cheb_apply_on_an_array_of_a_gigabyte():
+    """Arrays of 0.94 GB and more are beyond the 32-bit buffer offsets of the long-line kernel: the general kernel takes
+    them (sweep_vec_eligible).  Checked against the same plan applied to the two halves of the tensor (dimension 0 is not
+    the transform dimension, so the halves are independent problems below the limit)."""
+    dims = (4, 256, 130048)            # 4 * 256 * 130048 * 8 B = 1.07 GB, lines of 256 points at stride 130048
+    n = dims[0] * dims[1] * dims[2]
+    x = torch.randn(n, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)
+    big = sp.ChebPlan(dims, 1)
+    big.mult(x, y)
+    half = sp.ChebPlan((2, dims[1], dims[2]), 1)
+    yh = torch.empty(n // 2, dtype=torch.float64, device="cuda")
+    for h in range(2):
+        half.mult(x[h * (n // 2):(h + 1) * (n // 2)], yh)
+        torch.cuda.synchronize()
+        ref = yh
+        got = y[h * (n // 2):(h + 1) * (n // 2)]
+        assert float((got - ref).norm() / ref.norm()) < 1e-13
+    big.destroy(); half.destroy()

@@ -296,13 +296,14 @@ def _distc_worker(rank, world, port, dims, q, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     if backend == "nccl":
-        os.environ["CHEBHIP_DIST_FORCE_A2A"] = "1"; os.environ["CHEBHIP_DIST_SELF_RCCL"] = "1"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sp = ge.load(); dsp = ge.load_dist()
-        op = dsp.DistPoissonC(dims, sp)
+        if backend == "nccl":
+            sp.set_option("rccl_self_messages", 1)              # one rank on the real transport: its own block through ncclSend / ncclRecv
+        op = dsp.DistPoissonC(dims, sp, force_a2a=(backend == "nccl"))
         G = int(np.prod([v - 2 for v in dims]))
         U = np.random.default_rng(SEED).standard_normal(G)
         lo, n = op.slab_offset, op.local_size
@@ -355,12 +356,13 @@ def _slabx_worker(rank, world, port, dims, q, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     if backend == "nccl":
-        os.environ["CHEBHIP_DIST_SELF_RCCL"] = "1"            # one rank on the real transport: its own block through ncclSend / ncclRecv
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sp = ge.load(); dsp = ge.load_dist()
+        if backend == "nccl":
+            sp.set_option("rccl_self_messages", 1)              # one rank on the real transport: its own block through ncclSend / ncclRecv
         d = len(dims)
         comm = dsp.Comm(sp) if world > 1 else None
         if backend == "nccl":                                  # world == 1: make the RCCL communicator by hand

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run the matvec in a loop for a few seconds per ablation setting and sample rocm-smi (sclk, power)."""
+"""Run the matvec in a loop for a few seconds and sample rocm-smi (sclk, power) beside it.  The stream-ablated
+builds of tools/v4_ablate.sh are selected with CHEBHIP_LIB_PATH (one process per build)."""
 import os, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +13,6 @@ P = 256
 op = sp.EllipticOp((P, P, P))
 U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
 V = torch.empty_like(U)
-L = sp.lib()
 def smi():
     try:
         out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True, timeout=20).stdout
@@ -20,15 +20,17 @@ def smi():
         return " | ".join(keep)
     except Exception as e:
         return "smi failed: %r" % e
-settings = ((0, "full"),) if os.environ.get("CHEBHIP_LIB_PATH") else ((0, "full"), (3, "compute only"), (4, "memory only"))
-for ab, name in settings:
-    L.chebhip_debug_ablate(ab)
+for name in (os.path.basename(os.environ.get("CHEBHIP_LIB_PATH", "shipped build")),):
     stop = False
     res = []
     def sampler():
         time.sleep(1.0)
         while not stop:
-            res.append(smi()); time.sleep(0.7)
+            try:
+                res.append(smi())
+            except Exception as e:          # a sampling failure must not end the record
+                res.append("sample failed: %r" % (e,))
+            time.sleep(0.7)
     th = threading.Thread(target=sampler); th.start()
     t0 = time.time(); n = 0
     while time.time() - t0 < 5.0:
@@ -37,7 +39,6 @@ for ab, name in settings:
         torch.cuda.synchronize(); n += 200
     dt = time.time() - t0
     stop = True; th.join()
-    print("%-14s %.1f us/matvec" % (name, dt / n * 1e6))
+    print("%-28s %.1f us/matvec" % (name, dt / n * 1e6))
     for r in res[:4]:
         print("    ", r)
-L.chebhip_debug_ablate(0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sustained-loop timing of the variable-coefficient elliptic callbacks (SURVEY 8d byte models):
 FormFunction (160 B/point) and the Jacobian apply MatMult_Elliptic with eta, eta' from the last residual
-(208 B/point), -gamma 4 -exponent 2 as in tests.sh:10.  usage: elliptic_bench.py [P ...]"""
+(208 B/point), -gamma 4 -exponent 2 as in tests.sh:10.  usage: elliptic_bench.py [P ...] [option=value ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +25,9 @@ def timeit(fn, reps):
         best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
     return best
 
-for P in [int(a) for a in sys.argv[1:]] or [128, 256]:
+for a in [a for a in sys.argv[1:] if "=" in a]:
+    k, v = a.split("="); sp.set_option(k, int(v))
+for P in [int(a) for a in sys.argv[1:] if "=" not in a] or [128, 256]:
     op = sp.EllipticOp((P, P, P))
     U = torch.rand(op.global_size, dtype=torch.float64, device="cuda") + 0.5     # positive state: eta = 1 + 4 u^2
     X = torch.randn(op.global_size, dtype=torch.float64, device="cuda")

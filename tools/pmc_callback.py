@@ -8,9 +8,12 @@ import numpy as np
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
-what = sys.argv[1]
-P = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-n = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+for a in [a for a in sys.argv[1:] if "=" in a]:
+    k, v = a.split("="); sp.set_option(k, int(v))
+argv = [a for a in sys.argv if "=" not in a]
+what = argv[1]
+P = int(argv[2]) if len(argv) > 2 else 128
+n = int(argv[3]) if len(argv) > 3 else 6
 dims = (P, P, P)
 if what.startswith("stokes"):
     op = sp.StokesOp(dims)

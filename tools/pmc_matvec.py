@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A short loop of Poisson matvecs for rocprofv3 counter passes: usage pmc_matvec.py [P] [n] [variant]"""
+"""A short loop of Poisson matvecs for rocprofv3 counter passes: usage pmc_matvec.py [P] [n]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,8 +8,6 @@ import __graft_entry__ as ge
 sp = ge.load()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-if len(sys.argv) > 3:
-    sp.lib().chebhip_debug_variant(int(sys.argv[3]))
 op = sp.EllipticOp((P, P, P))
 U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
 V = torch.empty_like(U)

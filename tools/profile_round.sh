@@ -12,7 +12,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$ou
 cd $R
 f=$(find $out/${tag}_trace -name '*kernel_trace.csv' | head -1)
 python3 tools/prof_summary.py $f --skip 120 > $out/${tag}_bench_kernel_summary.txt
-tools/pmc_passes.sh $out/${tag}_pmc 256 0 > $out/${tag}_pmc.log 2>&1
+tools/pmc_passes.sh $out/${tag}_pmc 256 > $out/${tag}_pmc.log 2>&1
 python3 - <<PY
 import json, re, sys
 sys.path.insert(0, "$R")

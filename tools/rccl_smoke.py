@@ -7,14 +7,13 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-os.environ["CHEBHIP_DIST_FORCE_A2A"] = "1"
 import numpy as np, torch, torch.distributed as dist
 import __graft_entry__ as ge
 sp = ge.load(); dsp = ge.load_dist()
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 dims = (66, 64, 40)
-op = dsp.DistPoissonOp(dims, backend=dsp.HipBackend(sp))
+op = dsp.DistPoissonOp(dims, backend=dsp.HipBackend(sp), force_a2a=True)
 assert op.comm_stream is None or True
 ser = sp.EllipticOp(dims)
 U = op.random_input(7); V = torch.empty_like(U); W = torch.empty_like(U)
@@ -41,12 +40,10 @@ assert its == ks2.iterations
 # for the per-call overhead, not a bandwidth figure
 import time
 for serial in ("0", "1"):
-    os.environ["CHEBHIP_DIST_SERIAL"] = serial
-    os.environ["CHEBHIP_DIST_FORCE_A2A"] = "1"
-    big = dsp.DistPoissonOp((34, 256, 256), backend=dsp.HipBackend(sp))
+  for forced in ("1", "0"):
+    big = dsp.DistPoissonOp((34, 256, 256), backend=dsp.HipBackend(sp), force_a2a=(forced == "1"), serial=(serial == "1"))
     Ub = big.random_input(3); Vb = torch.empty_like(Ub)
-    for forced in ("1", "0"):
-        os.environ["CHEBHIP_DIST_FORCE_A2A"] = forced
+    if True:
         for _ in range(20):
             big.mult(Ub, Vb)
         torch.cuda.synchronize(); t0 = time.perf_counter()

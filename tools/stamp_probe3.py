@@ -2,7 +2,7 @@
 """Diagnostic only: the Poisson matvec with tools/libchebhip_diag.so (`make -C spectral-petsc_amd/csrc diag`:
 sweep_vec.hip with -DCHEB_STAMPS) -- where a wave of cheb_sweep_vec3_kernel spends its cycles, per launch
 (direction) and wave group: chain 0, epilogue 0, chain 1, epilogue 1, barrier; prologue; spans.
-usage: stamp_probe3.py [P] [variant ...]"""
+usage: stamp_probe3.py [P]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,14 +12,13 @@ sp = ge.load()
 sp.LIB_PATH = os.path.join(ROOT, "tools", "libchebhip_diag.so")
 L = sp.lib()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-variants = [int(v) for v in sys.argv[2:]] or [1]
+variants = [0]
 op = sp.EllipticOp((P, P, P))
 U = torch.randn(op.global_size, dtype=torch.float64, device="cuda")
 V = torch.empty_like(U)
 buf = torch.zeros(3 * 256 * 8 * 8, dtype=torch.int64, device="cuda")
 names = ("chain0", "epi0", "chain1", "epi1/top", "barrier")
 for var in variants:
-    L.chebhip_debug_variant(var)
     for _ in range(60):
         op.mult(U, V)
     torch.cuda.synchronize()
