@@ -47,32 +47,23 @@ extern "C" const char *chebhip_arch(void) { return "gfx950"; }
 extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 
 // ---------------------------------------------------------------------------------------------
-// run-time options (include/chebhip.h): the only switches of the library; the environment is never read
+// run-time options (include/chebhip.h; registry in options.cpp): the only switches of the library; the environment is never read
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct OptDesc { const char *name; int def; };
-const OptDesc g_opt_desc[OPT_COUNT] = {
-  {"general_kernels", 0}, {"separate_launches", 0}, {"no_rocblas", 0}, {"no_raw_transforms", 0}, {"equal_shares", 0}, {"force_gemm", 0},
-  {"stokes_single_stream", 0}, {"eta_from_memory", 0}, {"gather_pass", 0}, {"rccl_self_messages", 0}, {"local_timeout_s", 120},
-};
-std::atomic<int> g_opt_val[OPT_COUNT];
-std::once_flag g_opt_once;
-void opt_init() { std::call_once(g_opt_once, [] { for (int i = 0; i < OPT_COUNT; i++) g_opt_val[i].store(g_opt_desc[i].def); }); }
-}  // namespace
-int chebhip::opt(int id) { opt_init(); return (id >= 0 && id < OPT_COUNT) ? g_opt_val[id].load(std::memory_order_relaxed) : 0; }
 extern "C" int chebhip_set_option(const char *name, int value) {
   if (!name) return fail(CHEBHIP_ERR_ARG, "NULL option name");
-  opt_init();
-  for (int i = 0; i < OPT_COUNT; i++) if (!strcmp(name, g_opt_desc[i].name)) { g_opt_val[i].store(value); return 0; }
-  return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
+  const int id = opt_find(name);
+  if (id < 0) return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
+  opt_set(id, value);
+  return 0;
 }
 extern "C" int chebhip_get_option(const char *name, int *value) {
   if (!name || !value) return fail(CHEBHIP_ERR_ARG, "NULL argument");
-  opt_init();
-  for (int i = 0; i < OPT_COUNT; i++) if (!strcmp(name, g_opt_desc[i].name)) { *value = g_opt_val[i].load(); return 0; }
-  return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
+  const int id = opt_find(name);
+  if (id < 0) return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
+  *value = opt(id);
+  return 0;
 }
-extern "C" const char *chebhip_option_name(int index) { return (index >= 0 && index < OPT_COUNT) ? g_opt_desc[index].name : ""; }
+extern "C" const char *chebhip_option_name(int index) { return opt_name(index); }
 // Diagnostic builds (-DCHEB_STAMPS) only: device buffer of 256*8*4 uint64 receiving per-wave phase cycle sums.
 static const double *g_stamp_buf = nullptr;
 static int g_stamp_cnt = 0;

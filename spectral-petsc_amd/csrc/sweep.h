@@ -144,6 +144,9 @@ int sweep_num_cus(hipError_t *err);
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_NO_ROCBLAS, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
              OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_COUNT };
 int opt(int id);
+void opt_set(int id, int value);
+const char *opt_name(int id);
+int opt_find(const char *name);      // -1: no such option
 
 // Fast diagonalisation of the 1-D three-point operator of the finite-difference preconditioners (diffmat.cpp)
 // Modes are ordered by parity: position p < ceil(M/2) holds the p-th even mode, position M-1-q the q-th odd one

@@ -15,7 +15,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def test_fdm_line_decomposition(tmp_path):
     csrc = os.path.join(ROOT, "spectral-petsc_amd", "csrc")
     objs = []
-    for src, extra in ((os.path.join(csrc, "diffmat.cpp"), ["-x", "hip"]), (os.path.join(ROOT, "tests", "host", "fdm_check.cpp"), [])):
+    for src, extra in ((os.path.join(csrc, "diffmat.cpp"), ["-x", "hip"]), (os.path.join(csrc, "options.cpp"), ["-x", "hip"]),
+                       (os.path.join(ROOT, "tests", "host", "fdm_check.cpp"), [])):
         o = str(tmp_path / (os.path.basename(src) + ".o"))
         subprocess.run([HIPCC, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", csrc] + extra + ["-c", src, "-o", o], check=True, timeout=600)
         objs.append(o)
