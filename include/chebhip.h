@@ -387,7 +387,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   eta_from_memory       1: FormFunction reads eta instead of forming 1 + gamma u^2 on chip (exponent 2)
  *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
  *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
- *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120) */
+ *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120)
+ *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);
 const char *chebhip_option_name(int index);     /* "" past the last option: enumerate from 0 */

@@ -210,10 +210,12 @@ __global__ void k_st_node_fn(long N, double *__restrict__ S0, double *__restrict
 // The two node loops for d = 3 on node PAIRS (N even; every array is an allocation of the handle, 16-byte aligned): each
 // field is read and written 16 bytes at a time.  Same arithmetic per node as k_st_node_vv / k_st_node_fn.
 __device__ __forceinline__ double &comp(double2 &v, int q) { return q ? v.y : v.x; }
-template <bool DETA>
+// SYM: the stress goes to the 6 slots of T (stokes_op::T) instead of overwriting the 9 gradient fields.
+template <bool DETA, bool SYM>
 __global__ __launch_bounds__(256) void k_st_node_vv_pair(long N, double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
                                                          const double *__restrict__ S0, const double *__restrict__ S1, const double *__restrict__ S2,
-                                                         const double *__restrict__ eta, const double *__restrict__ deta, double *__restrict__ div) {
+                                                         const double *__restrict__ eta, const double *__restrict__ deta, double *__restrict__ div,
+                                                         double *__restrict__ T) {
   double *V[3] = {V0, V1, V2};
   const double *S[3] = {S0, S1, S2};
   const long half = N >> 1;
@@ -247,15 +249,19 @@ __global__ __launch_bounds__(256) void k_st_node_vv_pair(long N, double *__restr
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) ((double2 *)(V[j] + k * N))[t] = out[j][k];
+      for (int k = 0; k < 3; k++) {
+        if (SYM) { if (j <= k) ((double2 *)(T + (long)(j + k + j * k) * N))[t] = out[j][k]; }
+        else ((double2 *)(V[j] + k * N))[t] = out[j][k];
+      }
     if (div) ((double2 *)div)[t] = dv;
   }
 }
 
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_st_node_fn_pair(long N, double *__restrict__ S0, double *__restrict__ S1, double *__restrict__ S2,
                                                          double *__restrict__ V0, double *__restrict__ V1, double *__restrict__ V2,
                                                          double *__restrict__ eta, double *__restrict__ deta, double *__restrict__ div,
-                                                         int kind, double hardness, double expo, double eps, double gamma0) {
+                                                         int kind, double hardness, double expo, double eps, double gamma0, double *__restrict__ T) {
   double *V[3] = {V0, V1, V2};
   double *S[3] = {S0, S1, S2};
   const long half = N >> 1;
@@ -291,7 +297,10 @@ __global__ __launch_bounds__(256) void k_st_node_fn_pair(long N, double *__restr
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) { ((double2 *)(V[j] + k * N))[t] = tv[j][k]; ((double2 *)(S[j] + k * N))[t] = sv[j][k]; }
+      for (int k = 0; k < 3; k++) {
+        if (SYM) { if (j <= k) { ((double2 *)(T + (long)(j + k + j * k) * N))[t] = tv[j][k]; ((double2 *)(S[j] + k * N))[t] = sv[j][k]; } }
+        else { ((double2 *)(V[j] + k * N))[t] = tv[j][k]; ((double2 *)(S[j] + k * N))[t] = sv[j][k]; }
+      }
     if (div) ((double2 *)div)[t] = dv;
   }
 }
@@ -381,6 +390,16 @@ struct stokes_op {
   double *xL = nullptr, *yL = nullptr;                       // workV[0], workV[1]
   double *yLx[3] = {nullptr, nullptr, nullptr};              // serial handles: terms 1, 2 of the stress divergence (summed in the final scatter)
   double *V[3] = {nullptr, nullptr, nullptr};                // workV[2..]
+  // d = 3 serial handles on lines of more than 64 points: the stress is symmetric, so the node loops write its 6 distinct
+  // components only, into slots {0, 1, 2, 3, 5, 8} of T (9 N doubles): tau_jk = tau_kj sits at slot j + k + j k, chosen so
+  // that the three fields the divergence sweep of direction j reads -- (j,0), (j,1), (j,2) -- are slots j, 2j+1, 3j+2: an
+  // arithmetic progression of stride j + 1, which the sweep kernel takes as spaced-out input fields (sweep.h).  Likewise
+  // the node loop of StokesFunction symmetrises c->strain in its upper triangle only (entries j <= k); the state
+  // accessors rebuild the full tensor.  48 B/node less written per StokesFunction (128^3: 325 -> 306 us).  StokesMatMult
+  // keeps its in-place node loop over all 9 fields: writing the 6 components elsewhere measured 13 us SLOWER there (the
+  // gradient fields it has just read are the lines the Infinity Cache still holds; tools/stokes_ab.py).
+  bool sym = false;
+  double *T = nullptr;
   double *strain[3] = {nullptr, nullptr, nullptr};           // c->strain[]
   double *eta = nullptr, *deta = nullptr;
   double *pL = nullptr, *p2 = nullptr, *gp[3] = {nullptr, nullptr, nullptr};   // workP[]
@@ -413,7 +432,7 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
-                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2]};
+                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T};
   for (double *p : all) if (p) (void)hipFree(p);
   if (op->sv0) (void)hipFree(op->sv0);
   if (op->sv1) (void)hipFree(op->sv1);
@@ -487,6 +506,13 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
   if (!slab) for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
   for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
   OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
+  if (!slab && d == 3 && (N & 1) == 0 && (size_t)N * 9 * 8 < 0x38000000ull && !opt(OPT_FULL_STRESS)) {
+    bool ok = true;
+    for (int k = 0; k < d; k++) ok = ok && op->mats[dims[k]].KS >= 16 && (dims[k] & 1) == 0;       // the long-line 16-byte kernel, both tilings
+    const int nt_last = op->mats[dims[d - 1]].KS == 16 ? 64 : 32;                                   // lines per tile of the contiguous direction
+    ok = ok && ((N / dims[d - 1]) % nt_last) == 0;
+    if (ok) { OPRC(st_alloc(&op->T, (size_t)N * 9)); op->sym = true; }
+  }
   OPRC(st_alloc(&op->pL, (size_t)N)); OPRC(st_alloc(&op->p2, (size_t)N));
   hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
   // Lagrange weights of the interior nodes x_1..x_{P-2} at x_0 and x_{P-1} (the polyInterp functional)
@@ -625,12 +651,16 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
 
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
 // kernels allow it (sweep_launch_multi), else one launch each.  Serial handles only.
-static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st) {
+static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st, bool spaced = false) {
   const DiffMat *m[3]; SweepParams sp[3];
   int n = 0;
   for (int k = k0; k < op->d; k++, n++) {
     sp[n] = SweepParams{};
     sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
+    if (spaced && k > 0) {                                  // job k: its d fields are k N doubles further apart than dense stacking (stokes_op::T)
+      sp[n].in_fblocks = (unsigned)(op->innerP[k] >= 16 ? op->N / ((long)op->dims[k] * op->innerP[k]) : op->N / op->dims[k]);
+      sp[n].in_fskip = (unsigned)((long)k * op->N);
+    }
     sp[n].in0 = x[k]; sp[n].in_mode = IN_PLAIN; sp[n].out = y[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = alpha;
     m[n] = &op->mats[op->dims[k]];
   }
@@ -640,7 +670,7 @@ static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x,
 
 // yL (+ yLx[1] + yLx[2]) = -sum_j DV[j] V[j]   (stokes.C:668-671, 737-740): one launch, the sum is taken by the final scatter
 // in the order j = 0, 1, 2; slab mode keeps the accumulating chain (the sweep along dimension 0 is the driver's)
-static int st_div_stress(stokes_op *op, hipStream_t st) {
+static int st_div_stress(stokes_op *op, hipStream_t st, bool from_T = false) {
   if (op->slab) {
     for (int j = 0; j < op->d; j++) {
       int rc = sweep_plain(op, true, j, op->V[j], op->yL, j == 0 ? OUT_STORE : OUT_ACC, op->yL, -1.0, st);
@@ -648,8 +678,12 @@ static int st_div_stress(stokes_op *op, hipStream_t st) {
     }
     return 0;
   }
-  const double *x[3] = {op->V[0], op->V[1], op->V[2]};
   double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
+  if (from_T) {         // the fields (j,0), (j,1), (j,2) of direction j are slots j, 2j+1, 3j+2 of T: base j N, one field every (j+1) N
+    const double *x[3] = {op->T, op->T + op->N, op->T + 2 * op->N};
+    return sweeps_multi(op, true, 0, x, y, -1.0, st, true);
+  }
+  const double *x[3] = {op->V[0], op->V[1], op->V[2]};
   return sweeps_multi(op, true, 0, x, y, -1.0, st);
 }
 
@@ -670,10 +704,10 @@ static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st) {
   { int rc = st_gradient(op, op->V, st); if (rc) return rc; }                                                                   // :639
 #define NODE_VV(D_, DETA_) hipLaunchKernelGGL((k_st_node_vv<D_, DETA_>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
     (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
-#define NODE_VV_PAIR(DETA_) hipLaunchKernelGGL((k_st_node_vv_pair<DETA_>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
-    (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
+#define NODE_VV_PAIR(DETA_, SYM_) hipLaunchKernelGGL((k_st_node_vv_pair<DETA_, SYM_>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
+    (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div, op->T)
   if (d == 2) { if (op->deta_nonzero) NODE_VV(2, true); else NODE_VV(2, false); }
-  else if ((op->N & 1) == 0) { if (op->deta_nonzero) NODE_VV_PAIR(true); else NODE_VV_PAIR(false); }
+  else if ((op->N & 1) == 0) { if (op->deta_nonzero) NODE_VV_PAIR(true, false); else NODE_VV_PAIR(false, false); }
   else        { if (op->deta_nonzero) NODE_VV(3, true); else NODE_VV(3, false); }
 #undef NODE_VV_PAIR
 #undef NODE_VV
@@ -806,14 +840,17 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
   { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                           // :747
   { int rc = st_gradient(op, op->strain, st); if (rc) return rc; }                                                                // :701
-  if (d == 3 && (op->N & 1) == 0)
-    hipLaunchKernelGGL(k_st_node_fn_pair, dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
-                       op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
+  if (op->sym)
+    hipLaunchKernelGGL((k_st_node_fn_pair<true>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
+                       op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0, op->T);
+  else if (d == 3 && (op->N & 1) == 0)
+    hipLaunchKernelGGL((k_st_node_fn_pair<false>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
+                       op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0, op->T);
   else
     ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
          op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
   op->deta_nonzero = (op->rh_kind == 1);
-  int rc = st_div_stress(op, st); if (rc) return rc;                                                                             // :737-740
+  int rc = st_div_stress(op, st, op->sym); if (rc) return rc;                                                                    // :737-740
   if ((rc = st_join(op, st))) return rc;
   st_out_full(op, op->force, yG, st);                                                                                              // :750-756
   SHIPCHK(hipGetLastError());
@@ -903,8 +940,13 @@ extern "C" int stokes_op_get_state(stokes_op *op, int which, double *dst) {
   SHIPCHK(hipDeviceSynchronize());
   if (!soa) { SHIPCHK(hipMemcpy(dst, p, n * sizeof(double), hipMemcpyDeviceToHost)); return 0; }
   std::vector<double> tmp(n);
-  SHIPCHK(hipMemcpy(tmp.data(), p, n * sizeof(double), hipMemcpyDeviceToHost));
   const size_t N = (size_t)op->N; const int d = op->d;
+  const int j = which - 2;
+  for (int k = 0; k < d; k++) {
+    // symmetric storage (stokes_op::sym): only the entries with first index <= second are the symmetrised strain
+    const double *src = (op->sym && k < j) ? op->strain[k] + (size_t)j * N : p + (size_t)k * N;
+    SHIPCHK(hipMemcpy(tmp.data() + (size_t)k * N, src, N * sizeof(double), hipMemcpyDeviceToHost));
+  }
   for (size_t l = 0; l < N; l++) for (int k = 0; k < d; k++) dst[l * d + k] = tmp[k * N + l];
   return 0;
 }
@@ -978,7 +1020,11 @@ extern "C" int stokes_op_write_vtk(stokes_op *op, const double *state_dev, const
   if (op->force) { rc = fetch(op->force, fv, fp); if (rc) return rc; }                 // :1840-1851
   SHIPCHK(hipMemcpy(eta.data(), op->eta, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
   SHIPCHK(hipMemcpy(deta.data(), op->deta, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
-  for (int j = 0; j < d; j++) SHIPCHK(hipMemcpy(strain.data() + (size_t)j * N * d, op->strain[j], (size_t)N * d * sizeof(double), hipMemcpyDeviceToHost));
+  for (int j = 0; j < d; j++)
+    for (int k = 0; k < d; k++) {       // symmetric storage: entries below the diagonal come from their mirror
+      const double *src = (op->sym && k < j) ? op->strain[k] + (size_t)j * N : op->strain[j] + (size_t)k * N;
+      SHIPCHK(hipMemcpy(strain.data() + (size_t)j * N * d + (size_t)k * N, src, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    }
   FILE *f = fopen(path, "w");
   if (!f) return chebhip_fail(CHEBHIP_ERR_ARG, "cannot open %s", path);
   const int m = op->dims[0], n = op->dims[1], pp = d > 2 ? op->dims[2] : 1;

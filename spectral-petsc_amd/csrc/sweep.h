@@ -63,6 +63,12 @@ struct SweepParams {
   unsigned nouter, qmax;
   unsigned in_os, in_rs, acc_os, acc_rs, out_os, out_rs;
   unsigned in_bytes, acc_bytes, out_bytes;   // set by the launcher: exact sizes for the buffer descriptors of v4
+  // Input made of stacked FIELDS that are not contiguous (cheb_sweep_vec4_kernel only): field f of the input starts
+  // in_fskip elements further than the dense stacking would put it, per field (i.e. at f * (field size + in_fskip)).
+  // in_fblocks = outer blocks (COLFAST) / lines (JFAST, a multiple of the tile's lines) per field; 0 = dense.
+  // The Stokes stress tensor is stored as its 6 distinct components this way (stokes.hip).
+  unsigned in_fblocks, in_fskip;
+  unsigned in_fblocks_inv;                   // set by the launcher: ceil(2^32 / in_fblocks)
 };
 
 // Host description of the even/odd split differentiation matrices for P points.
@@ -142,7 +148,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_NO_ROCBLAS, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

@@ -496,7 +496,7 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
       return sweep_vec_launch(m, p, stream);
     }
   }
-  if (p.raw) return hipErrorInvalidValue;               // the raw modes exist in the 16-byte kernels only (sweep_vec_raw_eligible)
+  if (p.raw || p.in_fblocks) return hipErrorInvalidValue;   // the raw modes and spaced-out input fields exist in the 16-byte kernels only
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);

@@ -451,11 +451,19 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     return valid ? o * os8 + q0 * 8u : T_INVALID;
   };
 
+  // ... of the INPUT, whose fields may be spaced out (sweep.h: in_fblocks / in_fskip)
+  const u32 fb = p.in_fblocks, fskip8 = p.in_fskip * 8u;
+  auto in_tile_off = [&](u32 tl) -> u32 {
+    u32 off = tile_off(tl, true, in_os8);
+    if (fb) off += __umulhi(JFAST ? tl * NT : tl / tpo, p.in_fblocks_inv) * fskip8;
+    return off;
+  };
+
   d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
   d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];
 
   auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
-    const u32 t0 = tile_off(tl, true, in_os8);
+    const u32 t0 = in_tile_off(tl);
     if constexpr (V4_ABLATE & 1) { if (tl != p.ntiles + 12345u) {
 #pragma unroll
       for (int s = 0; s < CH; s++) { rj[s] = d2{1.0 + s, 2.0}; rm[s] = d2{0.5, 0.25 * chunk}; }
@@ -764,7 +772,15 @@ static int prepare_v(SweepParams &p) {
       if (JFAST) return ((unsigned long long)(p.ncols - 1) * os + P_) * 8ull;
       return ((unsigned long long)(p.nouter - 1) * os + (p.qmax - 1) + (P_ - 1) * rs + 1) * 8ull;
     };
-    const unsigned long long bi = span(p.in_os, p.in_rs), ba = span(p.acc_os, p.acc_rs), bo = span(p.out_os, p.out_rs);
+    unsigned long long bi = span(p.in_os, p.in_rs);
+    const unsigned long long ba = span(p.acc_os, p.acc_rs), bo = span(p.out_os, p.out_rs);
+    if (p.in_fblocks) {                                    // spaced-out input fields (sweep.h)
+      const unsigned units = JFAST ? p.ncols : p.nouter;
+      if (units % p.in_fblocks || (JFAST && p.in_fblocks % NT) || p.out_mode != OUT_STORE || p.raw) return 0;
+      bi += (unsigned long long)(units / p.in_fblocks - 1) * p.in_fskip * 8ull;
+      p.in_fblocks_inv = (unsigned)((0x100000000ull + p.in_fblocks - 1) / p.in_fblocks);
+      if ((unsigned long long)(JFAST ? p.ncols + NT : p.nouter) * p.in_fblocks >= 0x100000000ull) return 0;   // exactness of the reciprocal
+    }
     if (!(bi < 0x38000000ull && ba < 0x38000000ull && bo < 0x38000000ull)) return 0;   // < 1 GiB minus slack: see T_INVALID
     p.in_bytes = (unsigned)bi; p.acc_bytes = (unsigned)ba; p.out_bytes = (unsigned)bo;
     return 4;
@@ -803,6 +819,7 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   const SweepParams &p = p0;
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
   const bool jfast = p.inner < 16;
+  if (p.in_fblocks && (m.KS < 16 || (p.in_fskip & 1))) return false;
   if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: the long-line kernel only, every offset must stay 16-B aligned
     if (m.KS < 16) return false;
     const unsigned all = p.qmax | p.in_os | p.in_rs | p.acc_os | p.acc_rs | p.out_os | p.out_rs;
