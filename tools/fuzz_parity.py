@@ -50,29 +50,38 @@ while time.time() - t0 < budget:
         U = rng.standard_normal(op.global_size)
         note("ell-lin", rel(op.mult_host(U), orc.elliptic_mult(dims, U, mode=orc.FAST, nthreads=8)), dims)
         u = rng.random(op.global_size) + 0.5; b = rng.standard_normal(op.global_size); dv = rng.random(op.dirichlet_size) + 0.5
-        gam, ex = float(rng.random() * 3), float(rng.choice([1.0, 2.0, 3.0, 2.5]))
+        gam, ex = float(rng.random() * 3), float(rng.choice([1.0, 2.0, 2.0, 3.0, 2.5]))
+        if rng.random() < 0.4: dv = np.zeros(op.dirichlet_size)          # homogeneous rows: the interior-line FormFunction path (exponent 2)
         op.set_dirichlet(dv)
         r = op.function_host(u, b, gam, ex)
         ro, eta, deta, gradu = orc.elliptic_function(dims, u, b, dv, gam, ex, mode=orc.FAST, nthreads=8)
         note("ell-fn", rel(r, ro), (dims, gam, ex))
         note("ell-jac", rel(op.mult_host(U), orc.elliptic_mult(dims, U, eta, deta, gradu, mode=orc.FAST, nthreads=8)), (dims, gam, ex))
+        if rng.random() < 0.3:                                          # the stored state, whatever path produced it
+            note("ell-eta", rel(op.get_state(0), eta), dims)
+            k = int(rng.integers(0, rank)); note("ell-gradu", rel(op.get_state(2 + k), gradu[k]), (dims, k))
         op.destroy()
     elif kind == 2:      # Stokes
         d = int(rng.integers(2, 4)); dims = rand_dims(d, 3, 40 if d == 2 else 22, 12000)
+        if rng.random() < 0.25:                                         # long lines: the KS = 16 / 32 kernels, 6-component stress storage
+            dims = tuple(int(2 * rng.integers(33, 66)) for _ in range(d)) if d == 2 else tuple(int(v) for v in rng.choice([66, 68, 72, 96, 128, 130], size=3))
+            if d == 3 and np.prod(dims) > 1.3e6: dims = (dims[0], 66, dims[2])
         op = sp.StokesOp(dims)
         power = (1, 1.0, float(rng.choice([1.0, 2.0, 3.0])), 10.0 ** -float(rng.integers(1, 5)), 1.0)
         x = rng.standard_normal(op.global_size); dv = rng.standard_normal(op.dirichlet_size); f = rng.standard_normal(op.global_size)
         op.set_rheology(*power); op.set_dirichlet(dv); op.set_force(f)
         y = torch.empty(op.global_size, dtype=torch.float64, device="cuda")
         op.function(dev(x), y)
-        yo, eta, deta, strain = orc.stokes_function(dims, x, dv, f, rheology=power, mode=orc.FAST)
-        note("st-fn", rel(y.cpu().numpy(), yo) / 10, (dims, power))          # 1e-9 bar (pressure extrapolation)
+        yo, eta, deta, strain = orc.stokes_function(dims, x, dv, f, rheology=power, mode=orc.FAST, nthreads=8)
+        note("st-fn", rel(y.cpu().numpy(), yo), (dims, power))
         op.mult(dev(x), y)
-        note("st-mult", rel(y.cpu().numpy(), orc.stokes_mult(dims, x, eta, deta, strain, mode=orc.FAST)) / 10, (dims, power))
+        note("st-mult", rel(y.cpu().numpy(), orc.stokes_mult(dims, x, eta, deta, strain, mode=orc.FAST, nthreads=8)), (dims, power))
+        if rng.random() < 0.3:
+            j = int(rng.integers(0, d)); note("st-strain", rel(op.get_state(2 + j), strain[j]), (dims, j))
         op.destroy()
     elif kind == 3:      # slab-mode elliptic at one rank vs serial handle
         rank = int(rng.integers(2, 4)); dims = rand_dims(rank, 3, 40, 60000)
-        ser = sp.EllipticOp(dims); par = dsp.DistEllipticOp(dims, sp)
+        ser = sp.EllipticOp(dims); par = (dsp.DistEllipticC if rng.random() < 0.5 else dsp.DistEllipticOp)(dims, sp)
         u = dev(rng.random(ser.global_size) + 0.5); b = dev(rng.standard_normal(ser.global_size)); dv = rng.random(ser.dirichlet_size) + 0.5
         ser.set_dirichlet(dv); par.op.set_dirichlet(dv)
         r1, r2 = torch.empty_like(u), torch.empty_like(u)
@@ -81,7 +90,7 @@ while time.time() - t0 < budget:
         ser.destroy(); par.destroy()
     else:                # slab-mode Stokes at one rank vs serial handle
         d = int(rng.integers(2, 4)); dims = rand_dims(d, 3, 36 if d == 2 else 20, 9000)
-        ser = sp.StokesOp(dims); par = dsp.DistStokesOp(dims, sp)
+        ser = sp.StokesOp(dims); par = (dsp.DistStokesC if rng.random() < 0.5 else dsp.DistStokesOp)(dims, sp)
         x = dev(rng.standard_normal(ser.global_size)); dv = rng.standard_normal(ser.dirichlet_size)
         for o in (ser, par.op):
             o.set_rheology(1, 1.0, 3.0, 1e-3, 1.0); o.set_dirichlet(dv)
@@ -90,6 +99,8 @@ while time.time() - t0 < budget:
         note("slab-st", rel(y2.cpu().numpy(), y1.cpu().numpy()), dims)
         ser.destroy(); par.destroy()
     n += 1
+    if n % 500 == 0:
+        print("... %d cases, %.0f s" % (n, time.time() - t0), flush=True)
 print("fuzz: %d cases in %.0f s, all within tolerance; worst per kind:" % (n, time.time() - t0))
 for k, (e, what) in sorted(worst.items()):
     print("   %-9s %.2e  %s" % (k, e, what))
