@@ -388,6 +388,7 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
  *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
  *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120)
+ *   dist_single_stream    1: chebhip_dist_mult keeps its local sweeps on the caller's stream (no overlap with the exchanges)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

@@ -5,12 +5,18 @@
 // (SetupBC, elliptic.C:372-434).  Rank r owns the planes [s0[r], s0[r+1]) of dimension 0.  With L_k the interior
 // second-derivative operator of a zero-Dirichlet line (MatMult_Elliptic with eta = 1, deta = 0, elliptic.C:297-339):
 //
-//   main stream                               side stream
+//   side stream                               caller's stream
 //   A_1 = -L_1 U   (slab, local)              buf  = pack(U)                     blocks U[:, c1[s]:c1[s+1], :]
 //   A_2 = -L_2 U   ...                        UT   = exchange(buf)               slab -> pencil (M0, m1, R)
 //                                             TT   = -L_0 UT                     one launch on the pencil
 //                                             T    = exchange(TT)                pencil rows -> slab blocks
-//   V = ((T + A_1) + A_2) + ...               (waits for the side stream)
+//                                             V = ((T + A_1) + A_2) + ...        (after the side stream's event)
+//
+// The exchange chain is the critical path and stays on the caller's stream; the local sweeps, which have slack, go to the
+// side stream (a cross-stream dependency costs ~13 us when the waiting stream is the one on the critical path, measured
+// with the roles the other way round in round 2).  A rank's own block never passes through the exchange buffers: pack
+// writes it straight into the pencil, the final sum reads it straight from the pencil result.  pack and the final sum
+// work run-wise (one workgroup per (plane, peer): a contiguous run on both sides, 16-byte accesses).
 //
 // The sum runs in the serial order k = 0, 1, 2 (elliptic.C:331-334), so every G reproduces the G = 1 vector to the
 // last bits of the per-line products.  Two exchanges per matvec; the pencil side of the forward exchange and the
@@ -22,6 +28,7 @@
 // else the system one) and never linked.  chebhip_dist_set_exchange plugs in any other transport with the same
 // contract (the CPU tests run the exchange logic under gloo that way).
 #include "comm.h"
+#include "sweep.h"
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -40,30 +47,41 @@ namespace {
 
 // ---- pack / combine -------------------------------------------------------------------------------------------
 struct Split { int G; long c1[65]; };
-// position in the exchange buffer (peer-major: for peer s the block slab[:, c1[s]:c1[s+1], :]) of slab element e
-__device__ __forceinline__ long buf_index(const Split &sp, long m0, long M1, long R, long e) {
-  const long i0 = e / (M1 * R), rem = e - i0 * (M1 * R);
-  const long j = rem / R, r = rem - j * R;
-  int s = 0;
-  while (s + 1 < sp.G && j >= sp.c1[s + 1]) s++;
-  const long w = sp.c1[s + 1] - sp.c1[s];
-  return m0 * sp.c1[s] * R + (i0 * w + (j - sp.c1[s])) * R + r;
-}
-__global__ void k_pack(Split sp, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf) {
-  const long n = m0 * M1 * R;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) buf[buf_index(sp, m0, M1, R, e)] = slab[e];
-}
 struct APtrs { const double *p[9]; int n; };
+// One workgroup per (plane i0, peer s): slab[i0, c1[s]:c1[s+1], :] is a contiguous run of (c1[s+1] - c1[s]) R doubles, and so
+// is its place in the exchange buffer.  own >= 0: that peer's run goes to / comes from own_ptr (the pencil: the rank's own
+// block needs no message) instead of the buffer.  V2: every run starts on a 16-byte boundary and has even length.
+template <bool V2>
+__global__ __launch_bounds__(256) void k_pack(Split sp, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf,
+                                             int own, double *__restrict__ own_ptr) {
+  const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R;
+  const double *src = slab + (i0 * M1 + sp.c1[s]) * R;
+  double *dst = (s == own) ? own_ptr + i0 * len : buf + m0 * sp.c1[s] * R + i0 * len;
+  if (V2) { for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) ((double2 *)dst)[t] = ((const double2 *)src)[t]; }
+  else { for (long t = threadIdx.x; t < len; t += blockDim.x) dst[t] = src[t]; }
+}
 // V = ((T + A_1) + A_2) + ...   T in exchange order: the serial accumulation order k = 0, 1, 2 (elliptic.C:331-334)
-__global__ void k_combine(Split sp, long m0, long M1, long R, const double *__restrict__ buf, APtrs A, double *__restrict__ out) {
-  const long n = m0 * M1 * R;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    double v = buf[buf_index(sp, m0, M1, R, e)];
-    for (int k = 0; k < A.n; k++) v = v + A.p[k][e];
-    out[e] = v;
+template <bool V2>
+__global__ __launch_bounds__(256) void k_combine(Split sp, long m0, long M1, long R, const double *__restrict__ buf, int own,
+                                                const double *__restrict__ own_ptr, APtrs A, double *__restrict__ out) {
+  const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = (i0 * M1 + sp.c1[s]) * R;
+  const double *src = (s == own) ? own_ptr + i0 * len : buf + m0 * sp.c1[s] * R + i0 * len;
+  if (V2) {
+    for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) {
+      double2 v = ((const double2 *)src)[t];
+      for (int k = 0; k < A.n; k++) { const double2 a = ((const double2 *)(A.p[k] + e0))[t]; v.x = v.x + a.x; v.y = v.y + a.y; }
+      ((double2 *)(out + e0))[t] = v;
+    }
+  } else {
+    for (long t = threadIdx.x; t < len; t += blockDim.x) {
+      double v = src[t];
+      for (int k = 0; k < A.n; k++) v = v + A.p[k][e0 + t];
+      out[e0 + t] = v;
+    }
   }
 }
-static inline unsigned dgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 static void split_sizes(long n, int parts, std::vector<long> &sz) { sz.resize(parts); for (int i = 0; i < parts; i++) sz[i] = n / parts + (i < n % parts ? 1 : 0); }
 
 }  // namespace
@@ -171,40 +189,57 @@ extern "C" int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm) {
   return chebhip_dist_use_comm(D, D->own_comm);
 }
 
-// send[s] (doubles, peer-major, contiguous) -> recv[s]: one grouped launch of the transport, the own block a device copy
-static int exchange(chebhip_dist *D, const double *send, const long *sc, double *recv, const long *rc_, hipStream_t st) {
+// send[s] (doubles, peer-major, contiguous) -> recv[s]: one grouped launch of the transport.  own >= 0: that rank's block is
+// not moved (the kernels on either side read / write it in place)
+static int exchange(chebhip_dist *D, const double *send, const long *sc, double *recv, const long *rc_, int own, hipStream_t st) {
   if (D->xfn) return D->xfn(D->xctx, send, sc, recv, rc_, (void *)st);
   if (D->G > 1 && !D->comm) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist: no transport set (chebhip_dist_use_comm / _use_rccl / _set_exchange)");
   D->segs.clear();
   long so = 0, ro = 0;
-  for (int s = 0; s < D->G; s++) { D->segs.push_back(XSeg{s, send + so, sc[s], recv + ro, rc_[s]}); so += sc[s]; ro += rc_[s]; }
-  return chebhip::comm_exchange(D->comm, D->segs.data(), D->G, st);
+  for (int s = 0; s < D->G; s++) { if (s != own) D->segs.push_back(XSeg{s, send + so, sc[s], recv + ro, rc_[s]}); so += sc[s]; ro += rc_[s]; }
+  if (D->segs.empty()) return 0;
+  return chebhip::comm_exchange(D->comm, D->segs.data(), (int)D->segs.size(), st);
 }
 
 extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, void *stream) {
   if (!D || !U || !V) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (U == V) return chebhip_fail(CHEBHIP_ERR_ARG, "U and V must be distinct");
-  hipStream_t st = (hipStream_t)stream, side = D->side;
+  const bool one_stream = chebhip::opt(chebhip::OPT_DIST_SINGLE_STREAM) != 0;     // "dist_single_stream": no overlap, no cross-stream dependencies
+  hipStream_t st = (hipStream_t)stream, side = one_stream ? st : D->side;
   const int d = D->d, r = D->rank;
   const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
-  // side stream: U is ready when the caller's stream gets here
-  DHIPCHK(hipEventRecord(D->ev_in, st));
-  DHIPCHK(hipStreamWaitEvent(side, D->ev_in, 0));
+  // side stream: the local directions, each into its own array (they overlap both exchanges); U is ready when the
+  // caller's stream gets here
+  if (!one_stream) { DHIPCHK(hipEventRecord(D->ev_in, st)); DHIPCHK(hipStreamWaitEvent(side, D->ev_in, 0)); }
   int rc = 0;
-  hipLaunchKernelGGL(k_pack, dim3(dgrid(D->local)), dim3(256), 0, side, D->split, m0, M1, R, U, D->sendbuf);
-  if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pack launch failed");
-  if (!rc) rc = exchange(D, D->sendbuf, D->fwd_send.data(), D->UT, D->fwd_recv.data(), side);            // lands as the pencil
-  if (!rc) rc = cheb_apply_lap1d(D->pencil_plan, D->UT, nullptr, -1.0, D->TT, side);                      // TT = -L_0 UT
-  if (!rc) rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), side);             // pencil rows -> slab blocks
-  // main stream: the local directions, each into its own array (they overlap both exchanges)
-  for (int k = 1; k < d && !rc; k++) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[k - 1], st);
+  for (int k = 1; k < d && !rc; k++) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[k - 1], side);
+  hipError_t e1 = one_stream ? hipSuccess : hipEventRecord(D->ev_out, side);
+  // caller's stream: the exchange chain.  With a chebhip_exchange_fn (the older callback contract moves every block, the
+  // own one included) everything goes through the buffers; otherwise the own block bypasses them.
+  const int own = (D->xfn || chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES)) ? -1 : r;     // (the option: one-rank smoke runs of the transport)
+  double *own_in = D->UT + D->s0[r] * D->m1[r] * R;          // where the own block sits in the pencil: rows s0[r] .. s0[r+1]
+  const double *own_out = D->TT + D->s0[r] * D->m1[r] * R;
+  // 16-byte accesses: every run (c1[s+1] - c1[s]) R long starting at (i0 M1 + c1[s]) R must be even-aligned
+  bool v2 = ((R & 1) == 0 || ((M1 & 1) == 0)) && (((size_t)U | (size_t)V) & 15) == 0;
+  if (v2 && (R & 1)) for (int s = 0; s <= D->G; s++) v2 = v2 && (D->s1[s] & 1) == 0;
+  const unsigned grid = (unsigned)(m0 * D->G);
+  if (!rc && grid) {
+    if (v2) hipLaunchKernelGGL((k_pack<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, D->sendbuf, own, own_in);
+    else hipLaunchKernelGGL((k_pack<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, D->sendbuf, own, own_in);
+    if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pack launch failed");
+  }
+  if (!rc) rc = exchange(D, D->sendbuf, D->fwd_send.data(), D->UT, D->fwd_recv.data(), own, st);          // lands as the pencil
+  if (!rc) rc = cheb_apply_lap1d(D->pencil_plan, D->UT, nullptr, -1.0, D->TT, st);                        // TT = -L_0 UT
+  if (!rc) rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), own, st);           // pencil rows -> slab blocks
   // the caller's stream is rejoined with the side stream on every path, errors included
-  hipError_t e1 = hipEventRecord(D->ev_out, side), e2 = hipStreamWaitEvent(st, D->ev_out, 0);
+  hipError_t e2 = one_stream ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
   if (rc) return rc;
   if (e1 != hipSuccess || e2 != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream join failed");
   APtrs A; A.n = d - 1; for (int k = 0; k < 9; k++) A.p[k] = k < d - 1 ? D->A[k] : nullptr;
-  hipLaunchKernelGGL(k_combine, dim3(dgrid(D->local)), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, A, V);
+  if (grid) {
+    if (v2) hipLaunchKernelGGL((k_combine<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, own, own_out, A, V);
+    else hipLaunchKernelGGL((k_combine<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, own, own_out, A, V);
+  }
   DHIPCHK(hipGetLastError());
   return 0;
 }
-

@@ -34,6 +34,14 @@ import torch
 import torch.distributed as dist
 
 
+def _torch_stream(ptr):
+    """The torch stream object of a hipStream_t handed to a callback.  NULL is the device's default stream:
+    torch.cuda.ExternalStream(0) is NOT (work queued through it is not ordered with the default stream's kernels --
+    found as a nondeterministic Krylov solve when the exchange chain moved to the caller's stream)."""
+    p = int(ptr or 0)
+    return torch.cuda.default_stream() if p == 0 else torch.cuda.ExternalStream(p)
+
+
 def split_sizes(n, parts):
     """Near-equal contiguous split of n planes over `parts` ranks (first n % parts get one more)."""
     q, r = divmod(n, parts)
@@ -208,7 +216,7 @@ class DistPoissonC:
         def xfn(ctx, send, sc, recv, rc, stream):
             try:
                 scl = [int(sc[i]) for i in range(G)]; rcl = [int(rc[i]) for i in range(G)]
-                ext = torch.cuda.ExternalStream(int(stream or 0))
+                ext = _torch_stream(stream)
                 with torch.cuda.stream(ext):
                     hs = sp.device_view(send, max(sum(scl), 1))[:sum(scl)].cpu()          # synchronises with `stream`
                     hr = torch.empty(sum(rcl), dtype=torch.float64)
@@ -524,7 +532,7 @@ class Comm:
 
         def xfn(ctx, nseg, peers, sends, scounts, recvs, rcounts, stream):
             try:
-                ext = torch.cuda.ExternalStream(int(stream or 0))
+                ext = _torch_stream(stream)
                 with torch.cuda.stream(ext):
                     ops, back = [], []
                     for i in range(nseg):           # receives first, in segment order; matching is by order per peer
