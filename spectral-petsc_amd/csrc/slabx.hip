@@ -12,6 +12,7 @@
 // One exchange moves all fields of a call in ONE grouped launch (comm.hip).  The pencil side of the forward exchange and
 // the pencil-row side of the backward one need no (un)packing: a peer's block is a run of whole pencil planes.
 #include "comm.h"
+#include "sweep.h"
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -28,32 +29,38 @@ using chebhip::XSeg;
 namespace {
 
 struct Split { int G; long c1[65]; };
-// position inside one field's exchange buffer (peer-major: for peer s the block slab[:, c1[s]:c1[s+1], :]) of slab element e
-__device__ __forceinline__ long xbuf_index(const Split &sp, long m0, long M1, long R, long e) {
-  const long i0 = e / (M1 * R), rem = e - i0 * (M1 * R);
-  const long j = rem / R, r = rem - j * R;
-  int s = 0;
-  while (s + 1 < sp.G && j >= sp.c1[s + 1]) s++;
-  const long w = sp.c1[s + 1] - sp.c1[s];
-  return m0 * sp.c1[s] * R + (i0 * w + (j - sp.c1[s])) * R + r;
-}
-// nf stacked slab fields -> nf stacked exchange buffers, one launch
-__global__ void k_xpack(Split sp, int nf, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf) {
-  const long n = m0 * M1 * R;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const long b = xbuf_index(sp, m0, M1, R, e);
-    for (int f = 0; f < nf; f++) buf[f * n + b] = slab[f * n + e];
-  }
+// One workgroup per (plane i0, peer s, field f): slab[f][i0, c1[s]:c1[s+1], :] is a contiguous run of (c1[s+1] - c1[s]) R
+// doubles, and so is its place in the field's exchange buffer (peer-major: for peer s the block slab[:, c1[s]:c1[s+1], :]).
+// The rank's own block (peer `own`) goes straight to / comes straight from the pencil arrays: it needs no message.
+// V2: every run starts on a 16-byte boundary and has even length.
+template <bool V2>
+__global__ __launch_bounds__(256) void k_xpack(Split sp, long m0, long M1, long R, long Ns, const double *__restrict__ slab, double *__restrict__ buf,
+                                              int own, double *__restrict__ own_ptr, long own_fstride) {
+  const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G, f = blockIdx.y;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R;
+  const double *src = slab + f * Ns + (i0 * M1 + sp.c1[s]) * R;
+  double *dst = (s == own) ? own_ptr + f * own_fstride + i0 * len : buf + f * Ns + m0 * sp.c1[s] * R + i0 * len;
+  if (V2) { for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) ((double2 *)dst)[t] = ((const double2 *)src)[t]; }
+  else { for (long t = threadIdx.x; t < len; t += blockDim.x) dst[t] = src[t]; }
 }
 // out = (acc ? acc : 0) + alpha * slab-ordered(buf), nf fields, one launch
-__global__ void k_xunpack(Split sp, int nf, long m0, long M1, long R, const double *__restrict__ buf, const double *acc, double alpha, double *out) {
-  const long n = m0 * M1 * R;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const long b = xbuf_index(sp, m0, M1, R, e);
-    for (int f = 0; f < nf; f++) { const double t = alpha * buf[f * n + b]; out[f * n + e] = acc ? acc[f * n + e] + t : t; }
+template <bool V2>
+__global__ __launch_bounds__(256) void k_xunpack(Split sp, long m0, long M1, long R, long Ns, const double *__restrict__ buf, int own,
+                                                const double *__restrict__ own_ptr, long own_fstride, const double *acc, double alpha, double *out) {
+  const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G, f = blockIdx.y;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = f * Ns + (i0 * M1 + sp.c1[s]) * R;
+  const double *src = (s == own) ? own_ptr + f * own_fstride + i0 * len : buf + f * Ns + m0 * sp.c1[s] * R + i0 * len;
+  if (V2) {
+    for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) {
+      const double2 b = ((const double2 *)src)[t];
+      double2 v = make_double2(alpha * b.x, alpha * b.y);
+      if (acc) { const double2 a = ((const double2 *)(acc + e0))[t]; v.x = a.x + v.x; v.y = a.y + v.y; }
+      ((double2 *)(out + e0))[t] = v;
+    }
+  } else {
+    for (long t = threadIdx.x; t < len; t += blockDim.x) { const double v = alpha * src[t]; out[e0 + t] = acc ? acc[e0 + t] + v : v; }
   }
 }
-inline unsigned xgrid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 void split_sizes(long n, int parts, std::vector<long> &sz) { sz.resize(parts); for (int i = 0; i < parts; i++) sz[i] = n / parts + (i < n % parts ? 1 : 0); }
 
 // The slab <-> pencil machinery for fields on the full local grid (P0, P1, R): slabs of planes of dimension 0, pencils
@@ -89,14 +96,31 @@ struct SlabX {
     return 0;
   }
 
+  // the peer whose block bypasses the exchange buffers: this rank (none with option rccl_self_messages: one-rank smoke runs of the transport)
+  int own() const { return chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES) ? -1 : rank; }
+  // 16-byte accesses of the pack / unpack launches: every run must start even-aligned and have even length
+  bool vec2(const double *a, const double *b, const double *c) const {
+    if ((((size_t)a | (size_t)b | (size_t)c) & 15) != 0 || (Ns & 1) || (Np & 1)) return false;
+    if ((R & 1) == 0) return true;
+    if (P1 & 1) return false;
+    for (int s = 0; s <= G; s++) if (s1[s] & 1) return false;
+    return true;
+  }
   // nf slab fields at `in` -> pen_in as (nf, P0, m1, R)
   int to_pencil(int nf, const double *in, hipStream_t st) {
     if (nf < 1 || nf > nf_max) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: %d fields, at most %d", nf, nf_max);
-    if (Ns > 0) { hipLaunchKernelGGL(k_xpack, dim3(xgrid(Ns)), dim3(256), 0, st, split, nf, m0[rank], P1, R, in, sendbuf); XHIPCHK(hipGetLastError()); }
+    double *own_in = pen_in + s0[rank] * ncol;                 // the own block inside the pencil: planes s0[rank] .. s0[rank+1]
+    if (Ns > 0) {
+      const dim3 grid((unsigned)(m0[rank] * G), (unsigned)nf);
+      if (vec2(in, nullptr, nullptr)) hipLaunchKernelGGL((k_xpack<true>), grid, dim3(256), 0, st, split, m0[rank], P1, R, Ns, in, sendbuf, own(), own_in, Np);
+      else hipLaunchKernelGGL((k_xpack<false>), grid, dim3(256), 0, st, split, m0[rank], P1, R, Ns, in, sendbuf, own(), own_in, Np);
+      XHIPCHK(hipGetLastError());
+    }
     segs.clear();
     for (int s = 0; s < G; s++)
-      for (int f = 0; f < nf; f++)
+      for (int f = 0; f < nf && s != own(); f++)
         segs.push_back(XSeg{s, sendbuf + f * Ns + m0[rank] * s1[s] * R, m0[rank] * m1[s] * R, pen_in + f * Np + s0[s] * ncol, m0[s] * ncol});
+    if (segs.empty()) return 0;
     return chebhip::comm_exchange(comm, segs.data(), (int)segs.size(), st);
   }
   // pen_out (nf, P0, m1, R) -> out = (acc ? acc : 0) + alpha * slab fields
@@ -104,10 +128,16 @@ struct SlabX {
     if (nf < 1 || nf > nf_max) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: %d fields, at most %d", nf, nf_max);
     segs.clear();
     for (int s = 0; s < G; s++)
-      for (int f = 0; f < nf; f++)
+      for (int f = 0; f < nf && s != own(); f++)
         segs.push_back(XSeg{s, pen_out + f * Np + s0[s] * ncol, m0[s] * ncol, recvbuf + f * Ns + m0[rank] * s1[s] * R, m0[rank] * m1[s] * R});
-    int rc = chebhip::comm_exchange(comm, segs.data(), (int)segs.size(), st); if (rc) return rc;
-    if (Ns > 0) { hipLaunchKernelGGL(k_xunpack, dim3(xgrid(Ns)), dim3(256), 0, st, split, nf, m0[rank], P1, R, (const double *)recvbuf, acc, alpha, out); XHIPCHK(hipGetLastError()); }
+    if (!segs.empty()) { int rc = chebhip::comm_exchange(comm, segs.data(), (int)segs.size(), st); if (rc) return rc; }
+    if (Ns > 0) {
+      const dim3 grid((unsigned)(m0[rank] * G), (unsigned)nf);
+      const double *own_out = pen_out + s0[rank] * ncol;
+      if (vec2(out, acc, nullptr)) hipLaunchKernelGGL((k_xunpack<true>), grid, dim3(256), 0, st, split, m0[rank], P1, R, Ns, (const double *)recvbuf, own(), own_out, Np, acc, alpha, out);
+      else hipLaunchKernelGGL((k_xunpack<false>), grid, dim3(256), 0, st, split, m0[rank], P1, R, Ns, (const double *)recvbuf, own(), own_out, Np, acc, alpha, out);
+      XHIPCHK(hipGetLastError());
+    }
     return 0;
   }
 
