@@ -409,7 +409,8 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   static_assert(KS >= 16 && CH >= 1, "v4 needs two sub-tiles per tile");
 
 #ifdef CHEB_STAMPS
-  unsigned long long st_seg[5] = {0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0, st_loop = 0;   // diagnostic build only: see v3
+  unsigned long long st_seg[5] = {0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0, st_loop = 0;   // diagnostic build only (tools/stamp_probe3.py)
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();                     // 100 MHz: the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz
 #endif
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   STAMP3_MARK(st_begin);
@@ -697,7 +698,8 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     if (lane == 0 && p.in4) {
       unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 8;
       dbg[0] = st_seg[0]; dbg[1] = st_seg[1]; dbg[2] = st_seg[2]; dbg[3] = st_seg[3]; dbg[4] = st_seg[4];
-      dbg[5] = st_loop - st_begin; dbg[6] = st_wait - st_begin; dbg[7] = st_park - st_begin; (void)st_end;
+      // [5] prologue, [6] whole kernel in shader cycles, [7] whole kernel in 100 MHz ticks (MI355X_MICROARCH.md, DVFS note 6)
+      dbg[5] = st_loop - st_begin; dbg[6] = st_end - st_begin; dbg[7] = __builtin_amdgcn_s_memrealtime() - rt_begin; (void)st_wait; (void)st_park;
     }
   }
 #endif

@@ -6,6 +6,7 @@ usage: stamp_probe3.py [P]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
@@ -19,9 +20,12 @@ V = torch.empty_like(U)
 buf = torch.zeros(3 * 256 * 8 * 8, dtype=torch.int64, device="cuda")
 names = ("chain0", "epi0", "chain1", "epi1/top", "barrier")
 for var in variants:
-    for _ in range(60):
-        op.mult(U, V)
-    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 2.5:                      # >= 2 s of back-to-back launches on random data before the stamped ones
+        for _ in range(200):
+            op.mult(U, V)
+        torch.cuda.synchronize()
     L.chebhip_debug_stamp_buffer(C.c_void_p(buf.data_ptr()))
     for _ in range(10):
         op.mult(U, V)
@@ -32,7 +36,9 @@ for var in variants:
     for k in range(3):
         r = raw[k]
         ntile = 8.0
-        print("  launch %d: prologue %7.0f (loads and fragments landed at %6.0f, first tile parked at %6.0f)  loop %7.0f cycles" % (
-            k, r[:, :, 5].mean(), r[:, :, 6].mean(), r[:, :, 7].mean(), r[:, :, :5].sum(axis=2).mean()))
+        cyc, ticks = r[:, :, 6], r[:, :, 7]
+        ghz = np.median(cyc / np.maximum(ticks, 1.0)) * 0.1
+        print("  launch %d: prologue %7.0f  loop %7.0f  whole kernel %7.0f shader cycles in %6.1f us of s_memrealtime -> in-kernel clock %.3f GHz (median over waves)" % (
+            k, r[:, :, 5].mean(), r[:, :, :5].sum(axis=2).mean(), cyc.mean(), ticks.mean() / 100.0, ghz))
         for s_, nm in enumerate(names):
             print("     %-9s per tile:  waves 0-3 %7.0f   waves 4-7 %7.0f" % (nm, r[:, :4, s_].mean() / ntile, r[:, 4:, s_].mean() / ntile))
