@@ -385,6 +385,10 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #ifndef V4_ABLATE
 #define V4_ABLATE 0
 #endif
+// cache policy of the result stores (aux operand of the raw buffer store: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef V4_STORE_AUX
+#define V4_STORE_AUX 0
+#endif
 
 template <int KS, bool JFAST, bool ACC, int RAW = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
@@ -424,7 +428,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC ? p.acc : p.in0), 0, ACC ? p.acc_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
-  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { if (!(V4_ABLATE & 8) || v.x == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, 0); };
+  auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { if (!(V4_ABLATE & 8) || v.x == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, V4_STORE_AUX); };
 
   double ae[KS], ao[KR > 0 ? KR : 1];
   double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;
