@@ -474,13 +474,20 @@ struct ell_op {
   // they are 1 + gamma w0^2 and 2 gamma w0 (exponent 2) and are formed when something asks for them (ell_sync_coeffs)
   bool coef_stale = false; double coef_gamma = 0.0;
   bool bdy_lines_dirty = false;         // w0 / gradu hold non-zero values on lines inside the boundary (left by the general path)
+  // w0 and gradu[k] live SH elements into allocations of N + 16 doubles.  SH = 0 normally.  The interior-line FormFunction
+  // stores them (8-byte pieces, lanes across the lines of the last dimension) starting at local column 1: with SH = 15
+  // that column sits on a 128-byte boundary and a wave's row pieces are whole cache lines (256^3: 560 -> 505 us; at
+  // SH = 0 the counters showed 12-16 % more bytes written than stored).  Every FormFunction rewrites these arrays, so the
+  // shift is simply chosen per call (ell_state_layout); readers go through the pointers and are scalar kernels.
+  double *w0_alloc = nullptr; std::vector<double *> gradu_alloc, cprod_alloc;
+  int w0_shift = 0; std::vector<int> g_shift;
   CoeffMode mode = COEFF_UNIT;
   double *hU = nullptr, *hV = nullptr, *hB = nullptr;  // staging for host-pointer calls
 };
 
 static int ell_alloc_state(ell_op *op) {
-  const size_t bytes = (size_t)op->N * sizeof(double);
-  if (!op->w0) { HIPCHK(hipMalloc((void **)&op->w0, bytes)); HIPCHK(hipMemset(op->w0, 0, bytes)); }   // boundary nodes read as zero until a pass writes them
+  const size_t bytes = (size_t)op->N * sizeof(double), sbytes = bytes + 16 * sizeof(double);
+  if (!op->w0) { HIPCHK(hipMalloc((void **)&op->w0_alloc, sbytes)); HIPCHK(hipMemset(op->w0_alloc, 0, sbytes)); op->w0 = op->w0_alloc; op->w0_shift = 0; }   // boundary nodes read as zero until a pass writes them
   if (!op->eta) {
     HIPCHK(hipMalloc((void **)&op->eta, bytes));
     HIPCHK(hipMalloc((void **)&op->deta, bytes));
@@ -488,11 +495,13 @@ static int ell_alloc_state(ell_op *op) {
     HIPCHK(hipMemset(op->deta, 0, bytes));                                                           // VecSet(deta,0) :266
   }
   if (op->gradu.empty()) {
-    op->gradu.assign(op->d, nullptr); op->cprod.assign(op->d, nullptr);
+    op->gradu.assign(op->d, nullptr); op->cprod.assign(op->d, nullptr); op->gradu_alloc.assign(op->d, nullptr); op->g_shift.assign(op->d, 0); op->cprod_alloc.assign(op->d, nullptr);
     for (int k = 0; k < op->d; k++) {
-      HIPCHK(hipMalloc((void **)&op->gradu[k], bytes));
-      HIPCHK(hipMemset(op->gradu[k], 0, bytes));
-      HIPCHK(hipMalloc((void **)&op->cprod[k], 2 * bytes));
+      HIPCHK(hipMalloc((void **)&op->gradu_alloc[k], sbytes));
+      HIPCHK(hipMemset(op->gradu_alloc[k], 0, sbytes));
+      op->gradu[k] = op->gradu_alloc[k];
+      HIPCHK(hipMalloc((void **)&op->cprod_alloc[k], 2 * sbytes));
+      op->cprod[k] = op->cprod_alloc[k] + 2 * (k < op->d - 1 ? 15 : 0);   // the pairs of local column 1 on a 128-byte boundary for the strided directions (see w0_alloc): Jacobian apply 502 -> 495 us
     }
     op->cdirty = true;
   }
@@ -662,9 +671,9 @@ extern "C" int ell_op_destroy(ell_op *op) {
   for (auto &kv : op->laps) diffmat_destroy(&kv.second);
   for (auto p : op->gcol) if (p) (void)hipFree(p);
   for (auto p : op->g) if (p) (void)hipFree(p);
-  for (auto p : op->gradu) if (p) (void)hipFree(p);
-  for (auto p : op->cprod) if (p) (void)hipFree(p);
-  double *singles[] = {op->W, op->w0, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
+  for (auto p : op->gradu_alloc) if (p) (void)hipFree(p);
+  for (auto p : op->cprod_alloc) if (p) (void)hipFree(p);
+  double *singles[] = {op->W, op->w0_alloc, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
   for (double *p : singles) if (p) (void)hipFree(p);
   if (op->ixL) (void)hipFree(op->ixL);
   delete op;
@@ -745,6 +754,29 @@ static int ell_fused4_function(ell_op *op, int k, double gamma, double exponent,
     q.sub = b; q.sub_bytes = b ? gbytes : 0u;
   }
   HIPCHK(fused4_launch(op->mats[op->dims[k]], q, last, false, k > 0, last, st));
+  return 0;
+}
+
+// Where w0 and gradu[k] sit inside their allocations for the FormFunction about to run (see ell_op::w0_alloc).  An array whose
+// shift changes is cleared: the interior-line path relies on zeros on the lines inside the boundary, the general path
+// rewrites every entry anyway.
+static int ell_state_layout(ell_op *op, bool trim, hipStream_t st) {
+  const size_t sbytes = ((size_t)op->N + 16) * sizeof(double);
+  const int d = op->d;
+  bool cleared_all = true;
+  auto place = [&](double *alloc, double **ptr, int *cur, int want) -> hipError_t {
+    if (*cur == want) { cleared_all = false; return hipSuccess; }
+    hipError_t e = hipMemsetAsync(alloc, 0, sbytes, st);
+    *cur = want; *ptr = alloc + want;
+    return e;
+  };
+  HIPCHK(place(op->w0_alloc, &op->w0, &op->w0_shift, trim ? 15 : 0));
+  for (int k = 0; k < d; k++) HIPCHK(place(op->gradu_alloc[k], &op->gradu[k], &op->g_shift[k], (trim && k < d - 1) ? 15 : 0));
+  if (trim && op->bdy_lines_dirty && !cleared_all) {          // same layout as last time, but the general path left boundary-line values
+    HIPCHK(hipMemsetAsync(op->w0_alloc, 0, sbytes, st));
+    for (int k = 0; k < d; k++) HIPCHK(hipMemsetAsync(op->gradu_alloc[k], 0, sbytes, st));
+  }
+  if (trim) op->bdy_lines_dirty = false;
   return 0;
 }
 
@@ -973,11 +1005,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     // kernel: three launches on the interior lines, no gather pass; eta / deta are formed from w0 when somebody reads them
     const bool notrim = opt(OPT_ETA_FROM_MEMORY) || opt(OPT_GATHER_PASS);
     if (!notrim && exponent == 2.0 && !op->dir_nonzero && op->wpad && op->G > 0 && ell_fused4_ok(op) && aligned16(U) && aligned16(rhs)) {
-      if (op->bdy_lines_dirty) {                             // lines inside the boundary: zero in this state, not visited by the launches
-        HIPCHK(hipMemsetAsync(op->w0, 0, (size_t)op->N * sizeof(double), st));
-        for (int k = 0; k < d; k++) HIPCHK(hipMemsetAsync(op->gradu[k], 0, (size_t)op->N * sizeof(double), st));
-        op->bdy_lines_dirty = false;
-      }
+      if ((rc = ell_state_layout(op, true, st))) return rc;  // lines inside the boundary: zero in this state, not visited by the launches
       for (int k = 0; k < d; k++) if ((rc = ell_fused4_function_trim(op, k, gamma, U, b, rhs, st))) return rc;
       op->cdirty = true; op->coef_stale = true; op->coef_gamma = gamma;
       op->mode = (gamma == 0.0) ? COEFF_UNIT : COEFF_FULL;
@@ -985,6 +1013,7 @@ extern "C" int ell_op_function(ell_op *op, double gamma, double exponent, const 
     }
   }
   op->coef_stale = false;                                    // the pass below writes w0, eta and deta
+  if ((rc = ell_state_layout(op, false, st))) return rc;
   if (op->dir_nonzero) op->bdy_lines_dirty = true;
   if ((op->N & 1) == 0)
     hipLaunchKernelGGL(k_gather_coeff2, dim3(pw_grid(op->N >> 1) * 2), dim3(256), 0, st, op->N, (const int *)op->ixL, U,
