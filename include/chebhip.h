@@ -258,7 +258,7 @@ typedef int (*chebhip_exchangev_fn)(void *ctx, int nseg, const int *peers, const
                                     double *const *recv_dev, const long *recv_counts, void *stream);
 int chebhip_comm_create_rccl(void *nccl_comm, int nranks, int rank, chebhip_comm **out);      /* the ncclComm_t is not owned */
 int chebhip_local_group_create(int nranks, chebhip_local_group **out);
-int chebhip_local_group_destroy(chebhip_local_group *g);
+int chebhip_local_group_destroy(chebhip_local_group *g);   /* after every rank thread has finished; the group outlives its communicators */
 int chebhip_local_group_abort(chebhip_local_group *g);   /* a failing rank releases the ranks waiting for it: their calls return an error */
 int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebhip_comm **out);          /* call with the rank's device current */
 int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn, chebhip_reduce_fn rfn, void *ctx, chebhip_comm **out);
@@ -389,6 +389,7 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
  *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120)
  *   dist_single_stream    1: chebhip_dist_mult keeps its local sweeps on the caller's stream (no overlap with the exchanges)
+ *   long_lines_gemm       1: lines of 257 .. 1024 points go to rocBLAS instead of the library's own matrix-core kernel (A/B)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

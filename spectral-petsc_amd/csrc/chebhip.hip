@@ -487,6 +487,10 @@ struct ell_op {
 
 static int ell_alloc_state(ell_op *op) {
   const size_t bytes = (size_t)op->N * sizeof(double), sbytes = bytes + 16 * sizeof(double);
+  // The fills below run on the null stream, which does not order itself against a caller's non-blocking stream: the call
+  // that allocates waits for them (once per handle).  Without this the clear of w0 / gradu could land AFTER the first
+  // kernels of the caller's stream had written them (seen with thread ranks, each on a stream of its own).
+  const bool fresh = !op->w0 || !op->eta || op->gradu.empty();
   if (!op->w0) { HIPCHK(hipMalloc((void **)&op->w0_alloc, sbytes)); HIPCHK(hipMemset(op->w0_alloc, 0, sbytes)); op->w0 = op->w0_alloc; op->w0_shift = 0; }   // boundary nodes read as zero until a pass writes them
   if (!op->eta) {
     HIPCHK(hipMalloc((void **)&op->eta, bytes));
@@ -505,6 +509,7 @@ static int ell_alloc_state(ell_op *op) {
     }
     op->cdirty = true;
   }
+  if (fresh) HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -898,7 +903,13 @@ static int ell_mult_slab(ell_op *op, const double *U, double *V, hipStream_t st)
   hipLaunchKernelGGL(k_gather_bc, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, op->ixL, U, (const double *)nullptr, op->w0);
   for (int k = 0; k < op->d; k++) if ((rc = ell_slab_sweep(op, k, op->w0, op->g[k], st))) return rc;
   // a rank without interior nodes still takes part in the exchanges of the others
-  if (op->G == 0) return op->dim0(op->dim0_ctx, 0, 1, op->g[0], nullptr, -1.0, op->W, st);
+  // (its boundary plane carries the flux f_0 = eta g_0 of the lines that cross it: w0 is zero there, elliptic.C:305-308)
+  if (op->G == 0) {
+    if (op->mode != COEFF_UNIT)
+      hipLaunchKernelGGL(k_flux, dim3(pw_grid(op->N)), dim3(256), 0, st, op->N, (const double *)op->eta, (const double *)op->deta,
+                         (const double *)op->w0, (const double *)op->gradu[0], op->g[0]);
+    return op->dim0(op->dim0_ctx, 0, 1, op->g[0], nullptr, -1.0, op->W, st);
+  }
   return ell_slab_divergence(op, op->mode == COEFF_UNIT ? IN_PLAIN : IN_FLUX_FULL, op->g.data(), V, st);
 }
 

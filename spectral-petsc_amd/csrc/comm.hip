@@ -131,7 +131,17 @@ extern "C" int chebhip_local_group_create(int nranks, chebhip_local_group **out)
   *out = g;
   return 0;
 }
-extern "C" int chebhip_local_group_destroy(chebhip_local_group *g) { delete g; return 0; }
+// The slots' events live as long as the group: a rank that is done (and destroys its communicator) must not take them
+// away from a slower peer that is still enqueueing its last waits on them.
+extern "C" int chebhip_local_group_destroy(chebhip_local_group *g) {
+  if (!g) return 0;
+  for (int r = 0; r < MAXR; r++) {
+    if (g->slot[r].ready) (void)hipEventDestroy(g->slot[r].ready);
+    if (g->slot[r].done) (void)hipEventDestroy(g->slot[r].done);
+  }
+  delete g;
+  return 0;
+}
 // A rank that cannot go on (an error outside the library) releases the ranks waiting for it: their calls fail.
 extern "C" int chebhip_local_group_abort(chebhip_local_group *g) { if (g) g->abort(); return 0; }
 
@@ -145,8 +155,8 @@ extern "C" int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebh
   auto &s = g->slot[rank];
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+  if (e == hipSuccess && !s.ready) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);       // (kept by the group, see its destroy)
+  if (e == hipSuccess && !s.done) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void **)&c->scratch, MAXR * sizeof(double));
   if (e != hipSuccess) { delete c; return chebhip_fail(CHEBHIP_ERR_DEVICE, "local comm: %s", hipGetErrorString(e)); }
   {
@@ -204,10 +214,8 @@ extern "C" int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out
 extern "C" int chebhip_comm_destroy(chebhip_comm *c) {
   if (!c) return 0;
   if (c->kind == KIND_LOCAL && c->lg) {
-    auto &s = c->lg->slot[c->rank];
-    if (s.ready) (void)hipEventDestroy(s.ready);
-    if (s.done) (void)hipEventDestroy(s.done);
-    s.ready = s.done = nullptr; s.bound = false;
+    std::lock_guard<std::mutex> lk(c->lg->mu);
+    c->lg->slot[c->rank].bound = false;          // (the slot's events stay with the group: peers may still be waiting on them)
   }
   if (c->scratch) (void)hipFree(c->scratch);
   delete c;

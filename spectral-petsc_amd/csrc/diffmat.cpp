@@ -66,15 +66,40 @@ static hipError_t diffmat_create_long(int P, DiffMat *out) {
   for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) { const double v = (double)dentry(i, j, n); DT[(size_t)j * P + i] = v; D[(size_t)i * P + j] = v; }
   DiffMat m;
   m.P = P; m.H = (P + 1) / 2; m.KS = 0; m.MTP = 0;
-  hipError_t e = hipMalloc((void **)&m.fragE, (8 + 1024) * sizeof(double));
+  // Lines of up to 1024 points: the even / odd halves in MFMA-operand order for cheb_sweep_xl_kernel (sweep_xl.hip):
+  // [m-tile][k-step][64 lanes], m-tiles padded to whole workgroups (8), k-steps to the prefetch depth (8); zero padded.
+  std::vector<double> fe, fo;
+  size_t cnt = 0;
+  if (P <= 1024) {
+    const int H = m.H;
+    m.MTP = ((H + 15) / 16 + 7) / 8 * 8;
+    m.xl_ks = ((H + 3) / 4 + 7) / 8 * 8;
+    cnt = (size_t)m.MTP * m.xl_ks * 64;
+    fe.assign(cnt, 0.0); fo.assign(cnt, 0.0);
+    for (int mt = 0; mt < m.MTP; mt++)
+      for (int s = 0; s < m.xl_ks; s++)
+        for (int l = 0; l < 64; l++) {
+          const int i = mt * 16 + (l & 15), j = 4 * s + (l >> 4);
+          if (i >= H || j >= H) continue;
+          long double me, mo;
+          if (2 * j == n) { me = dentry(i, j, n); mo = 0.0L; }
+          else { const long double a = dentry(i, j, n), b = dentry(i, n - j, n); me = 0.5L * (a + b); mo = 0.5L * (a - b); }
+          fe[((size_t)mt * m.xl_ks + s) * 64 + l] = (double)me;
+          fo[((size_t)mt * m.xl_ks + s) * 64 + l] = (double)mo;
+        }
+  }
+  hipError_t e = hipMalloc((void **)&m.fragE, (cnt + 8 + 1024) * sizeof(double));
   if (e != hipSuccess) return e;
-  m.zero = m.fragE; m.sink = m.zero + 8;
+  m.zero = m.fragE + cnt; m.sink = m.zero + 8;
   e = hipMemset(m.zero, 0, 8 * sizeof(double));
+  if (e == hipSuccess && cnt) e = hipMemcpy(m.fragE, fe.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess && cnt) e = hipMalloc((void **)&m.fragO, cnt * sizeof(double));
+  if (e == hipSuccess && cnt) e = hipMemcpy(m.fragO, fo.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void **)&m.longDT, DT.size() * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m.longDT, DT.data(), DT.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void **)&m.longD, D.size() * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(m.longD, D.data(), D.size() * sizeof(double), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(m.fragE); if (m.longDT) (void)hipFree(m.longDT); if (m.longD) (void)hipFree(m.longD); return e; }
+  if (e != hipSuccess) { (void)hipFree(m.fragE); if (m.fragO) (void)hipFree(m.fragO); if (m.longDT) (void)hipFree(m.longDT); if (m.longD) (void)hipFree(m.longD); return e; }
   *out = m;
   return hipSuccess;
 }

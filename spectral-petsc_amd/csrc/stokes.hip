@@ -630,7 +630,8 @@ static inline unsigned ugrid(long n, int un) { long g = (n + 256L * un - 1) / (2
 static inline bool st_al16(const void *q) { return ((size_t)q & 15) == 0; }
 static void st_local(stokes_op *op, int gs, int go, const double *src, const double *dirloc, double *xL, double *pL, hipStream_t st) {
   const int d = op->d;
-  if (d == 3 && gs == 4 && go == 3 && xL && pL && st_al16(src)) {
+  // (k_st_local4 loads node 0 of src for boundary nodes too: not for a slab without unknowns, whose src may be NULL)
+  if (d == 3 && gs == 4 && go == 3 && xL && pL && op->I > 0 && st_al16(src)) {
     hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
     return;
   }
@@ -885,7 +886,10 @@ extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out
   chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_SCHUR, stream);
   hipStream_t st = (hipStream_t)stream;
   const size_t gv = (size_t)op->I * op->d;
-  if (!op->sv0) { int rc = st_alloc(&op->sv0, gv ? gv : 1); if (rc) return rc; if ((rc = st_alloc(&op->sv1, gv ? gv : 1))) return rc; }
+  if (!op->sv0) {
+    int rc = st_alloc(&op->sv0, gv ? gv : 1); if (rc) return rc; if ((rc = st_alloc(&op->sv1, gv ? gv : 1))) return rc;
+    SHIPCHK(hipStreamSynchronize(nullptr));       // st_alloc clears on the null stream, which a non-blocking caller's stream does not wait for
+  }
   int rc = stokes_op_mult_vp(op, pG, op->sv0, st); if (rc) return rc;                        // :530
   if (solve) { if ((rc = solve(solve_ctx, op->sv0, op->sv1, st))) return rc; }               // KSPSolve(KSPSchurVelocity), :531
   else {

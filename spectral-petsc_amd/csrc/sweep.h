@@ -83,6 +83,7 @@ struct DiffMat {
   double *zero = nullptr;                     // device, 8 zero doubles (tail of the fragE allocation)
   double *sink = nullptr;                     // device, 1024 doubles after `zero`: target of masked-off stores
   int sym = 0;                                // 0: centro-antisymmetric (D), 1: centro-symmetric (interior D D)
+  int xl_ks = 0;                              // long lines of up to 1024 points (KS == 0): k-steps of the fragment arrays for cheb_sweep_xl_kernel
 };
 
 // Builds (in long double) and uploads the fragment-ordered matrices.  Returns hipSuccess or error.
@@ -132,6 +133,10 @@ struct Fused4Params {
 bool fused4_eligible(const DiffMat &m);
 hipError_t fused4_launch(const DiffMat &m, Fused4Params p, bool jfast, bool full, bool acc, bool win, hipStream_t stream);
 
+// Lines of 257 .. 1024 points on the matrix cores (sweep_xl.hip): plain input, STORE / ACC output
+bool sweep_xl_eligible(const DiffMat &m, const SweepParams &p);
+hipError_t sweep_xl_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+
 // 16-byte-access specialisation (sweep_vec.hip); used by sweep_launch when eligible
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);
 // ... and may carry p.raw != 0 (the kernel generations that implement the raw modes)
@@ -148,7 +153,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_NO_ROCBLAS, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

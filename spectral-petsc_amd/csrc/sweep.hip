@@ -488,7 +488,12 @@ static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym;
   p.longDT = m.longDT; p.longD = m.longD;
-  if (m.KS == 0) return m.longDT ? launch_long(p, stream) : hipErrorInvalidValue;
+  if (m.KS == 0) {
+    if (!m.longDT) return hipErrorInvalidValue;
+    // lines of 257 .. 1024 points: the library's own matrix-core kernel; option "long_lines_gemm": the rocBLAS route (A/B)
+    if (!opt(OPT_LONG_LINES_GEMM) && sweep_xl_eligible(m, p)) return sweep_xl_launch(m, p, stream);
+    return launch_long(p, stream);
+  }
   {
     if (!opt(OPT_GENERAL_KERNELS) && sweep_vec_eligible(m, p)) {
       // diagnostic builds: three stamp areas of 256 x 8 x 8 words, used round-robin (one per launch of a 3-D matvec)

@@ -123,7 +123,9 @@ def stokes_inputs(dims):
 
 
 # (3, (4, 6)): the last rank owns only a boundary plane -- no unknowns, empty vectors, but it takes part in the exchanges
-@pytest.mark.parametrize("G,dims", [(2, (10, 9, 8)), (3, (13, 12)), (3, (4, 6)), (4, (18, 17, 9)), (8, (24, 16, 10))], ids=str)
+# (6, (11, 15, 25)): the same in 3-D, where the gather is the 16-byte kernel (it read node 0 of the -- NULL -- vector of such a
+# rank for its boundary nodes: a GPU fault found by tools/fuzz_dist_threads.py)
+@pytest.mark.parametrize("G,dims", [(2, (10, 9, 8)), (3, (13, 12)), (3, (4, 6)), (4, (18, 17, 9)), (8, (24, 16, 10)), (6, (11, 15, 25))], ids=str)
 def test_stokes_thread_ranks_small(G, dims):
     x, dv, force, w = stokes_inputs(dims)
     yf, ym = stokes_ranks(dims, G, x, dv, force, w, POWER)
@@ -151,10 +153,12 @@ def test_stokes_128_power_law_over_8_ranks():
     assert relerr(ym, orc.stokes_mult(dims, w, eta, deta, strain, mode=orc.FAST, nthreads=16)) < 1e-10
 
 
-def test_elliptic_general_thread_ranks():
-    """FormFunction and the Jacobian apply with variable coefficients on 4 slabs (chebhip_dist_ell_*) vs the oracle."""
+@pytest.mark.parametrize("dims,G", [((20, 18, 10), 4), ((5, 29), 3), ((6, 7, 5), 4)], ids=["20x18x10-4", "5x29-3", "6x7x5-4"])
+def test_elliptic_general_thread_ranks(dims, G):
+    """FormFunction and the Jacobian apply with variable coefficients on slabs (chebhip_dist_ell_*) vs the oracle.  In the
+    second and third case the last rank owns nothing but the boundary plane: no unknowns, yet the flux eta g_0 on that plane
+    is its to form (found by tools/fuzz_dist_threads.py: the Jacobian apply sent g_0 without eta from such a rank)."""
     sp = ge.load(); dsp = ge.load_dist()
-    dims, G = (20, 18, 10), 4
     n, g, nd = orc.sizes(dims)
     rng = np.random.default_rng(SEED)
     U = rng.random(g) + 0.5; b = rng.standard_normal(g); dirv = rng.standard_normal(nd); X = rng.standard_normal(g)

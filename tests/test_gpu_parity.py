@@ -101,14 +101,22 @@ def test_cheb_large_vs_oracle(shape, tr):
     assert relerr(y, ref) < TOL
 
 
-@pytest.mark.parametrize("shape,tr", [((300, 40), 0), ((12, 513), 1), ((6, 400, 5), 1)])
-def test_cheb_long_lines(shape, tr):
-    """Lines longer than 256 points take the dense VALU path of cheb_apply (no register-resident matrix)."""
+@pytest.mark.parametrize("shape,tr", [((300, 40), 0), ((12, 513), 1), ((6, 400, 5), 1), ((257, 33), 0), ((19, 258), 1), ((1024, 21), 0),
+                                      ((3, 1024), 1), ((5, 700, 17), 1), ((640, 4, 9), 0), ((2, 3, 999), 2), ((1025, 18), 0), ((7, 1100), 1)])
+@pytest.mark.parametrize("gemm", [0, 1], ids=["own", "rocblas"])
+def test_cheb_long_lines(shape, tr, gemm):
+    """Lines of 257 .. 1024 points: cheb_sweep_xl_kernel (the matrix halves stream past a tile of lines held in LDS), both
+    tilings, ragged tiles, odd and even extents; beyond 1024 and with option long_lines_gemm: rocBLAS, or the VALU kernel
+    where the layout is no GEMM."""
     rng = np.random.default_rng(SEED)
     x = rng.standard_normal(shape)
-    y = gpu_cheb(x, tr)
+    sp.set_option("long_lines_gemm", gemm)
+    try:
+        y = gpu_cheb(x, tr)
+    finally:
+        sp.set_option("long_lines_gemm", 0)
     ref = orc.cheb_mult(x, tr, orc.FAST, nthreads=8)
-    assert relerr(y, ref) < TOL
+    assert relerr(y, ref) < TOL, relerr(y, ref)
 
 
 @pytest.mark.parametrize("dims", [(33, 32, 31), (64, 64, 64)])

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/../spectral-petsc_amd/csrc"
 make -s
 for b in "$@"; do
   /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -DV4_ABLATE=$b -c sweep_vec.hip -o /tmp/sweep_vec_a$b.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libchebhip_v4a$b.so sweep.o /tmp/sweep_vec_a$b.o fused.o fused4.o chebhip.o stokes.o krylov.o diffmat.o precond.o saddle.o dist.o comm.o slabx.o options.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libchebhip_v4a$b.so sweep.o sweep_xl.o /tmp/sweep_vec_a$b.o fused.o fused4.o chebhip.o stokes.o krylov.o diffmat.o precond.o saddle.o dist.o comm.o slabx.o options.o -ldl
 done
