@@ -14,7 +14,13 @@
  *  - *_dev pointers are device (HBM) pointers; `stream` is a hipStream_t passed
  *    as void* (NULL = default stream).  Device-pointer calls are asynchronous
  *    on that stream; *_host calls stage through device memory and return after
- *    the result is in the host buffer.
+ *    the result is in the host buffer.  A stream created with
+ *    hipStreamNonBlocking is fine: state the library allocates on first use is
+ *    complete before the call that allocates it enqueues anything.  The set_* /
+ *    create / update calls that take host data are synchronous copies that do
+ *    NOT wait for work still queued on a non-blocking stream: synchronise that
+ *    stream before changing the state a queued call reads (as before VecSet on
+ *    a vector a MatMult in flight is reading).
  *  - every call returns 0 on success or a CHEBHIP_ERR_* code; nothing throws or
  *    exits across the ABI.  chebhip_last_error() returns a message for the
  *    calling thread's most recent failure.

@@ -174,6 +174,41 @@ def test_calls_on_a_non_default_stream():
     st.destroy(); op.destroy()
 
 
+def test_first_call_on_a_non_blocking_stream_while_the_null_stream_is_busy():
+    """State the library allocates on first use (w0, eta, gradu of the elliptic callbacks) is cleared on the null stream,
+    which a non-blocking stream does not wait for: the allocating call must, or the clear lands on top of what the caller's
+    stream has written meanwhile.  Here the null stream is kept busy (torch's default stream IS the null stream) so that a
+    missing wait shows every time: the clear would land after FormFunction has stored its linearisation state, and the
+    Jacobian apply that follows would use zeros.  (Found by tools/fuzz_dist_threads.py, whose thread ranks each own a
+    non-blocking stream; there the clear landed between two kernels once in a few hundred cases.)"""
+    import numpy as np
+    import torch
+    dims = (40, 36, 34)
+
+    def run(side):
+        op = sp.EllipticOp(dims); op.set_dirichlet(np.full(op.dirichlet_size, 0.5))
+        g = torch.Generator(device="cuda").manual_seed(5)
+        u = torch.rand(op.global_size, dtype=torch.float64, device="cuda", generator=g) + 0.5
+        outs = [torch.full_like(u, float("nan")) for _ in range(3)]
+        torch.cuda.synchronize()
+        if side is not None:
+            torch.cuda._sleep(400_000_000)                  # ~0.2 s on the null stream, queued ahead of anything the library puts there
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+            op.function(u, None, outs[0], 1.5, 3.0); op.mult(u, outs[1])
+            torch.cuda.current_stream().synchronize()
+        torch.cuda.synchronize()                            # the null stream has drained: whatever was queued there has landed
+        state = [op.get_state(w) for w in range(2 + len(dims))]      # eta, deta, gradu[k] as FormFunction left them
+        op.destroy()
+        return outs[:2], state
+    got, got_state = run(torch.cuda.Stream())
+    ref, ref_state = run(None)
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    for w, (a, b) in enumerate(zip(got_state, ref_state)):
+        assert np.array_equal(a, b), "state array %d was overwritten after FormFunction stored it" % w
+    assert np.abs(ref_state[2]).max() > 0 and ref_state[0].min() > 1.0
+
+
 def test_two_host_threads_with_their_own_handles():
     """One handle belongs to one host thread at a time, but two threads may drive two handles at once (ctypes releases the GIL):
     the library's shared state -- lazily read environment switches, the CU-count cache, the timer registry, rocBLAS handles --
