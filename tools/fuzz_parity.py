@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
     if kind == 0:        # ChebMult
         rank = int(rng.integers(1, 5)); dims = rand_dims(rank, 2, 70 if rank > 1 else 300, 400000); tr = int(rng.integers(0, rank))
         if rank in (2, 3) and rng.random() < 0.15:        # a long line (> 256 points) inside a small tensor
-            dl = list(rand_dims(rank, 2, 12, 2000)); dl[tr] = int(rng.integers(257, 600)); dims = tuple(dl)
+            dl = list(rand_dims(rank, 2, 40, 3000)); dl[tr] = int(rng.integers(257, 1100)); dims = tuple(dl)      # both tilings of sweep_xl.hip, ragged tiles, and beyond 1024
         if dims[tr] < 2: continue
         x = rng.standard_normal(dims)
         plan = sp.ChebPlan(dims, tr); y = torch.empty(x.size, dtype=torch.float64, device="cuda")
@@ -41,6 +41,8 @@ while time.time() - t0 < budget:
         rank = int(rng.integers(1, 4)); dims = rand_dims(rank, 3, 48 if rank > 1 else 200, 120000)
         if rank == 2 and rng.random() < 0.1:
             dims = (int(rng.integers(257, 400)), int(rng.integers(3, 12)))[::int(rng.choice([1, -1]))]
+        elif rank == 3 and rng.random() < 0.06:                          # a long direction inside a 3-D operator (plain sweeps + pointwise passes)
+            dl = [int(rng.integers(3, 20)) for _ in range(3)]; dl[int(rng.integers(0, 3))] = int(rng.integers(257, 420)); dims = tuple(dl)
         elif rank in (2, 3) and rng.random() < 0.35:
             # the shapes of cheb_fused4_kernel / the padded-W path: even extents of 66..256 points, mixed KS = 16 / 32
             hi = 256 if rank == 2 else 110
@@ -66,6 +68,8 @@ while time.time() - t0 < budget:
         if rng.random() < 0.25:                                         # long lines: the KS = 16 / 32 kernels, 6-component stress storage
             dims = tuple(int(2 * rng.integers(33, 66)) for _ in range(d)) if d == 2 else tuple(int(v) for v in rng.choice([66, 68, 72, 96, 128, 130], size=3))
             if d == 3 and np.prod(dims) > 1.3e6: dims = (dims[0], 66, dims[2])
+        if d == 2 and rng.random() < 0.06:                              # one long direction (> 256 points)
+            dims = (int(rng.integers(257, 330)), int(rng.integers(4, 20)))[::int(rng.choice([1, -1]))]
         op = sp.StokesOp(dims)
         power = (1, 1.0, float(rng.choice([1.0, 2.0, 3.0])), 10.0 ** -float(rng.integers(1, 5)), 1.0)
         x = rng.standard_normal(op.global_size); dv = rng.standard_normal(op.dirichlet_size); f = rng.standard_normal(op.global_size)
