@@ -54,10 +54,12 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_xl_kernel   // (4 waves per
   if (qlim > (u32)NL) qlim = NL;                 // lines of the tile that exist
 
   // ---- fragment queue: XL_PF k-steps ahead, across the chunks ----------------------------------------------------
+  // (the m-tiles are padded to whole workgroups: a wave whose rows lie beyond the half only helps with the images)
+  const bool live = 16 * mt < H;
   const double *fE = p.fragE + ((long)mt * KS) * 64 + lane, *fO = p.fragO + ((long)mt * KS) * 64 + lane;
   double ae[XL_PF], ao[XL_PF];
 #pragma unroll
-  for (int s = 0; s < XL_PF; s++) { ae[s] = fE[(long)s * 64]; ao[s] = fO[(long)s * 64]; }
+  for (int s = 0; s < XL_PF; s++) { ae[s] = live ? fE[(long)s * 64] : 0.0; ao[s] = live ? fO[(long)s * 64] : 0.0; }
   v4d ce[NT2], co[NT2];
 #pragma unroll
   for (int t = 0; t < NT2; t++) { ce[t] = (v4d){0.0, 0.0, 0.0, 0.0}; co[t] = (v4d){0.0, 0.0, 0.0, 0.0}; }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_xl_kernel   // (4 waves per
     }
     __syncthreads();
 
-    const int kend = min(KS - k0, XL_KC / 4);
+    const int kend = live ? min(KS - k0, XL_KC / 4) : 0;
     for (int g = 0; g < kend; g += XL_PF) {
 #pragma unroll
       for (int s = 0; s < XL_PF; s++) {
