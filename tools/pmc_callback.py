@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A short loop of one operator callback for rocprofv3 counter / trace passes.
-usage: pmc_callback.py <what> [P] [n]     what: stokes_lin | stokes_pl | ell_fn | ell_jac | chebmult"""
+usage: pmc_callback.py <what> [P] [n]     what: stokes_lin | stokes_pl | ell_fn | ell_jac | chebmult | longline (P = line length, 257..1024)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,6 +31,12 @@ elif what in ("ell_fn", "ell_jac"):
     for i in range(n):
         op.function(U, b, R, gamma=4.0, exponent=2.0)
         op.mult(b, R)
+elif what == "longline":            # cheb_sweep_xl_kernel, both tilings: P x 8192 along dim 0, 8192 x P along dim 1
+    for shape, tr in (((P, 8192), 0), ((8192, P), 1)):
+        pl = sp.ChebPlan(shape, tr)
+        x = torch.randn(shape, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)
+        for i in range(n):
+            pl.mult(x, y)
 elif what == "chebmult":
     for tr in range(3):
         pl = sp.ChebPlan(dims, tr)
