@@ -67,12 +67,12 @@ static hipError_t diffmat_create_long(int P, DiffMat *out) {
   DiffMat m;
   m.P = P; m.H = (P + 1) / 2; m.KS = 0; m.MTP = 0;
   // Lines of up to 1024 points: the even / odd halves in MFMA-operand order for cheb_sweep_xl_kernel (sweep_xl.hip):
-  // [m-tile][k-step][64 lanes], m-tiles padded to whole workgroups (8), k-steps to the prefetch depth (8); zero padded.
+  // [m-tile][k-step][64 lanes], m-tiles padded by a workgroup's worth (16), k-steps to a multiple of 8; zero padded.
   std::vector<double> fe, fo;
   size_t cnt = 0;
   if (P <= 1024) {
     const int H = m.H;
-    m.MTP = ((H + 15) / 16 + 7) / 8 * 8;
+    m.MTP = (H + 15) / 16 + 16;                  // (a workgroup covers up to 16 m-tiles: its last one starts below ceil(H/16))
     m.xl_ks = ((H + 3) / 4 + 7) / 8 * 8;
     cnt = (size_t)m.MTP * m.xl_ks * 64;
     fe.assign(cnt, 0.0); fo.assign(cnt, 0.0);

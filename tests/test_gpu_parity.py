@@ -119,6 +119,17 @@ def test_cheb_long_lines(shape, tr, gemm):
     assert relerr(y, ref) < TOL, relerr(y, ref)
 
 
+@pytest.mark.parametrize("shape,tr", [((512, 16400), 0), ((16400, 512), 1), ((1000, 8200), 0), ((4104, 2, 1000), 2)], ids=str)
+def test_cheb_long_lines_large(shape, tr):
+    """Arrays large enough for the long-line kernel's tiles of 32 lines with two m-tiles per wave (at least 512 workgroups),
+    with a ragged last tile; 512 points = one row block of 16 m-tiles, 1000 points = two (the last m-tile partly real)."""
+    rng = np.random.default_rng(SEED)
+    x = rng.standard_normal(shape)
+    y = gpu_cheb(x, tr)
+    ref = orc.cheb_mult(x, tr, orc.FAST, nthreads=16)
+    assert relerr(y, ref) < TOL, relerr(y, ref)
+
+
 @pytest.mark.parametrize("dims", [(33, 32, 31), (64, 64, 64)])
 def test_cheb_exp_known_answer(dims):
     """cheb.c:73-112 on the GPU: d/dx_d (e^x+e^y+e^z) = e^{x_d}; HIP error <= 4x oracle error + eps."""
