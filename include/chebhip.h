@@ -385,10 +385,11 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  * environment).  Unknown names are an error.  Set them before creating the handles they concern.
  *   general_kernels       1: every sweep runs the general 8-byte kernel (A/B against the 16-byte kernels)
  *   separate_launches     1: the d sweeps of a Stokes gradient / divergence are d launches instead of one
- *   no_rocblas            1: lines of more than 256 points use the library's own kernel, never rocBLAS (first use decides)
+ *   no_rocblas            1: sweeps that would go to rocBLAS (lines of more than 1024 points; or see long_lines_gemm, force_gemm)
+ *                            use the library's own FP64-VALU kernel instead (first use decides)
  *   no_raw_transforms     1: the preconditioner's line transforms take two launches instead of one
  *   equal_shares          1: multi-job launches give every job min(tiles, CUs) workgroups instead of proportional shares
- *   force_gemm            1: every extent >= 4 takes the long-line (library DGEMM) route (read at operator create)
+ *   force_gemm            1: every extent of 4 .. 256 points takes the library-DGEMM route of the longest lines (read at operator create)
  *   stokes_single_stream  1: StokesMatMult / StokesFunction keep the pressure chain on the caller's stream (read at create)
  *   eta_from_memory       1: FormFunction reads eta instead of forming 1 + gamma u^2 on chip (exponent 2)
  *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
