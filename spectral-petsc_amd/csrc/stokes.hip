@@ -533,7 +533,10 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     OPCHK(hipMemcpy(op->w1[k], b.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
   }
   {
-    if (!opt(OPT_STOKES_SINGLE_STREAM) && !slab) {          // "stokes_single_stream": read when the handle is created
+    // The pressure chain on a second stream pays on large grids (128^3 StokesMatMult 298 against 325 us, 120^3 260 against
+    // 275); below about 100^3 the fork / join events cost more than the overlap gives (64^3: 70.5 against 66.5 us, and
+    // 62 us with the one-launch gradients of the one-stream path; 96^3 .. 112^3: a tie), so smaller grids stay on one stream.
+    if (!opt(OPT_STOKES_SINGLE_STREAM) && !slab && N >= 1200000) {         // "stokes_single_stream": read when the handle is created
       OPCHK(hipStreamCreateWithFlags(&op->aux, hipStreamNonBlocking));
       OPCHK(hipEventCreateWithFlags(&op->ev_fork, hipEventDisableTiming));
       OPCHK(hipEventCreateWithFlags(&op->ev_join, hipEventDisableTiming));
@@ -698,11 +701,31 @@ static int st_gradient(stokes_op *op, double *const *out, hipStream_t st) {
   return sweeps_multi(op, true, 0, x, out, 1.0, st);
 }
 
-// viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]; div (may be null)
-// receives the trace of the gradient = StokesDivergence of the same xL
-static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st) {
+// One stream (small grids, see st_create): the d gradient sweeps out[j] = DV[j] xL and the d pressure-gradient sweeps
+// gp[i] = DP[i] pL of a callback are 2d independent plain sweeps of the same two local vectors -- ONE launch (64^3: one
+// dependent launch less on a chain that is all launch latency).  pL must hold its extrapolated boundary values.
+static int st_gradient_and_pressure_gradient(stokes_op *op, double *const *out, hipStream_t st) {
   const int d = op->d;
-  { int rc = st_gradient(op, op->V, st); if (rc) return rc; }                                                                   // :639
+  const DiffMat *m[6]; SweepParams sp[6];
+  int n = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int k = 0; k < d; k++, n++) {
+      const bool vec = pass == 0;
+      sp[n] = SweepParams{};
+      sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
+      sp[n].in0 = vec ? op->xL : op->pL; sp[n].in_mode = IN_PLAIN; sp[n].out = vec ? out[k] : op->gp[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = 1.0;
+      m[n] = &op->mats[op->dims[k]];
+    }
+  SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  return 0;
+}
+static inline bool st_one_launch_gradients(const stokes_op *op) { return !op->aux && !op->slab; }
+
+// viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]; div (may be null)
+// receives the trace of the gradient = StokesDivergence of the same xL.  have_gradient: V already holds DV[j] xL.
+static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st, bool have_gradient = false) {
+  const int d = op->d;
+  if (!have_gradient) { int rc = st_gradient(op, op->V, st); if (rc) return rc; }                                               // :639
 #define NODE_VV(D_, DETA_) hipLaunchKernelGGL((k_st_node_vv<D_, DETA_>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
     (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
 #define NODE_VV_PAIR(DETA_, SYM_) hipLaunchKernelGGL((k_st_node_vv_pair<DETA_, SYM_>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
@@ -824,8 +847,15 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   // scatterGV + scatterVL (zero boundary) and scatterGP (:505-510) in one pass over xG; the same xL serves
   // MatVV (:508) and MatPV (:509), whose result is the trace written by the node loop
   st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
-  int rc = st_pressure_gradient_forked(op, st); if (rc) return rc;                                                               // MatVP (:512)
-  if ((rc = st_viscous_jacobian(op, op->p2, st))) return rc;
+  int rc;
+  if (st_one_launch_gradients(op)) {
+    st_pressure_extrapolate(op, op->pL, st);
+    if ((rc = st_gradient_and_pressure_gradient(op, op->V, st))) return rc;                                                      // MatVP (:512) + :639
+    if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
+  } else {
+    if ((rc = st_pressure_gradient_forked(op, st))) return rc;                                                                   // MatVP (:512)
+    if ((rc = st_viscous_jacobian(op, op->p2, st))) return rc;
+  }
   if ((rc = st_join(op, st))) return rc;
   st_out_full(op, nullptr, yG, st);
   SHIPCHK(hipGetLastError());
@@ -839,8 +869,13 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   const int d = op->d;
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
-  { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                           // :747
-  { int rc = st_gradient(op, op->strain, st); if (rc) return rc; }                                                                // :701
+  if (st_one_launch_gradients(op)) {
+    st_pressure_extrapolate(op, op->pL, st);
+    int rc = st_gradient_and_pressure_gradient(op, op->strain, st); if (rc) return rc;                                           // :747, :701
+  } else {
+    { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                         // :747
+    { int rc = st_gradient(op, op->strain, st); if (rc) return rc; }                                                              // :701
+  }
   if (op->sym)
     hipLaunchKernelGGL((k_st_node_fn_pair<true>), dim3(sgrid(op->N >> 1)), dim3(256), 0, st, op->N, op->strain[0], op->strain[1], op->strain[2],
                        op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2, op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0, op->T);
