@@ -397,6 +397,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120)
  *   dist_single_stream    1: chebhip_dist_mult keeps its local sweeps on the caller's stream (no overlap with the exchanges)
  *   long_lines_gemm       1: lines of 257 .. 1024 points go to rocBLAS instead of the library's own matrix-core kernel (A/B)
+ *   pressure_passes       1: Stokes handles run the three boundary-extrapolation passes of StokesPressureReduceOrder before the
+ *                            pressure gradient instead of folding each direction's extrapolation into its matrix (read at create)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

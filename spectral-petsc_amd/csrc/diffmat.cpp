@@ -222,6 +222,28 @@ hipError_t diffmat_create_lap(int P, DiffMat *out) {
   return diffmat_from_dense(M, L.data(), 1, out);
 }
 
+// D with the end values of a line replaced by their extrapolation from the interior (StokesPressureReduceOrder,
+// stokes.C:1029-1080: the degree-(P-3) polynomial through the interior values, evaluated at both ends):
+//     x_0 = sum_j w0_j x_j,  x_n = sum_j w1_j x_j   (j = 1 .. n-1, Lagrange weights)
+//     D (x_0, x_1 .. x_{n-1}, x_n)^T = Dext x,   Dext[i][j] = D[i][j] + D[i][0] w0_j + D[i][n] w1_j,  Dext[i][0] = Dext[i][n] = 0.
+// w1_j = w0_{n-j} (mirror nodes), so Dext is centro-antisymmetric like D and runs on the same kernels.  Formed in long
+// double, rounded once.  The interior values of a pressure-gradient line never depend on the extrapolations along the
+// OTHER directions, so a Stokes callback needs no extrapolation pass at all (stokes.hip).
+hipError_t diffmat_create_pext(int P, DiffMat *out) {
+  if (P < 3 || P > 256) return hipErrorInvalidValue;
+  const int n = P - 1, m = P - 2;
+  std::vector<long double> x(P), w0(P, 0.0L), w1(P, 0.0L), A((size_t)P * P, 0.0L);
+  for (int i = 0; i < P; i++) x[i] = cosl(PI_L * i / n);
+  for (int j = 1; j <= m; j++) {
+    long double l0 = 1.0L, l1 = 1.0L;
+    for (int q = 1; q <= m; q++) if (q != j) { l0 *= (x[0] - x[q]) / (x[j] - x[q]); l1 *= (x[n] - x[q]) / (x[j] - x[q]); }
+    w0[j] = l0; w1[j] = l1;
+  }
+  for (int i = 0; i < P; i++)
+    for (int j = 1; j <= m; j++) A[(size_t)i * P + j] = dentry(i, j, n) + dentry(i, 0, n) * w0[j] + dentry(i, n, n) * w1[j];
+  return diffmat_from_dense(P, A.data(), 0, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fast diagonalisation of the finite-difference preconditioner (elliptic.C:556-579 with eta = 1, deta = 0;
 // stokes.C:1181-1226 per velocity component): on the tensor grid that matrix is  sum_k I x .. x T_k x .. x I  with

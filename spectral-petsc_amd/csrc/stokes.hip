@@ -385,6 +385,9 @@ struct stokes_op {
   std::vector<int> dims;
   long N = 0, I = 0;
   std::map<int, DiffMat> mats;
+  // D with the end-point extrapolation of StokesPressureReduceOrder folded in, per extent (serial handles, every extent of
+  // 3 .. 256 points): gp[i] = matsP * pL needs no extrapolation pass -- see st_pressure_gradient
+  std::map<int, DiffMat> matsP; bool pext = false;
   std::vector<unsigned> innerP, ncolsP, innerV, ncolsV;      // DP[i] / DV[i] geometry
   int *ixL = nullptr;
   double *xL = nullptr, *yL = nullptr;                       // workV[0], workV[1]
@@ -431,6 +434,7 @@ static int st_alloc(double **p, size_t n) { SHIPCHK(hipMalloc((void **)p, n * si
 extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
+  for (auto &kv : op->matsP) diffmat_destroy(&kv.second);
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
                    op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T};
   for (double *p : all) if (p) (void)hipFree(p);
@@ -484,6 +488,11 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
 #define OPRC(expr) do { int rc_ = (expr); if (rc_) { stokes_op_destroy(op); return rc_; } } while (0)
   for (int k = 0; k < d; k++)      // dimension 0: the global extent (in slab mode it is applied on pencils)
     if (!op->mats.count(gdims[k])) { DiffMat m; OPCHK(diffmat_create(gdims[k], &m)); op->mats[gdims[k]] = m; }
+  op->pext = !slab && !opt(OPT_PRESSURE_PASSES);            // "pressure_passes": the three extrapolation passes of the reference (A/B)
+  for (int k = 0; k < d; k++) op->pext = op->pext && gdims[k] >= 3 && op->mats[gdims[k]].KS != 0;
+  if (op->pext)
+    for (int k = 0; k < d; k++)
+      if (!op->matsP.count(gdims[k])) { DiffMat m; OPCHK(diffmat_create_pext(gdims[k], &m)); op->matsP[gdims[k]] = m; }
   {  // ixLP of StokesSetupDomain (stokes.C:791-879): interior index or -1, BlockIt order (of this slab)
     std::vector<int> ixL((size_t)N), ind(d, 0);
     long g = 0;
@@ -655,7 +664,8 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
 
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
 // kernels allow it (sweep_launch_multi), else one launch each.  Serial handles only.
-static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st, bool spaced = false) {
+static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st, bool spaced = false,
+                        bool pext = false) {          // pext: the matrices with the end-point extrapolation of the pressure folded in
   const DiffMat *m[3]; SweepParams sp[3];
   int n = 0;
   for (int k = k0; k < op->d; k++, n++) {
@@ -666,7 +676,7 @@ static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x,
       sp[n].in_fskip = (unsigned)((long)k * op->N);
     }
     sp[n].in0 = x[k]; sp[n].in_mode = IN_PLAIN; sp[n].out = y[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = alpha;
-    m[n] = &op->mats[op->dims[k]];
+    m[n] = pext ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
   }
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
   return 0;
@@ -703,7 +713,7 @@ static int st_gradient(stokes_op *op, double *const *out, hipStream_t st) {
 
 // One stream (small grids, see st_create): the d gradient sweeps out[j] = DV[j] xL and the d pressure-gradient sweeps
 // gp[i] = DP[i] pL of a callback are 2d independent plain sweeps of the same two local vectors -- ONE launch (64^3: one
-// dependent launch less on a chain that is all launch latency).  pL must hold its extrapolated boundary values.
+// dependent launch less on a chain that is all launch latency).  Without op->pext, pL must hold its extrapolated boundary values.
 static int st_gradient_and_pressure_gradient(stokes_op *op, double *const *out, hipStream_t st) {
   const int d = op->d;
   const DiffMat *m[6]; SweepParams sp[6];
@@ -714,7 +724,7 @@ static int st_gradient_and_pressure_gradient(stokes_op *op, double *const *out, 
       sp[n] = SweepParams{};
       sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
       sp[n].in0 = vec ? op->xL : op->pL; sp[n].in_mode = IN_PLAIN; sp[n].out = vec ? out[k] : op->gp[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = 1.0;
-      m[n] = &op->mats[op->dims[k]];
+      m[n] = (!vec && op->pext) ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
     }
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
   return 0;
@@ -769,6 +779,14 @@ static void st_pressure_extrapolate(stokes_op *op, double *pL, hipStream_t st) {
 // pL (interior filled, boundary zero) -> boundary extrapolation -> gp[i] = DP[i] pL   (stokes.C:609-614)
 static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   const int d = op->d;
+  // Serial handles, lines of at most 256 points: gp[i] at an interior node needs the end values of ITS line along i only,
+  // and those are a linear functional of the line's interior values (the other directions' extrapolations touch boundary
+  // lines, whose gradients the scatter never reads): the extrapolation is part of the matrix (diffmat_create_pext) and
+  // the three passes of StokesPressureReduceOrder are not run at all.  64^3 StokesMatMult: 62 -> 5x us.
+  if (op->pext) {
+    const double *x[3] = {op->pL, op->pL, op->pL};
+    return sweeps_multi(op, false, 0, x, op->gp, 1.0, st, false, true);
+  }
   st_pressure_extrapolate(op, op->pL, st);      // z lines, y lines (and, on one GPU, x lines): stokes.C:1043-1074
   if (op->slab) {
     // x lines cross the slabs: extrapolation (stokes.C:1064-1074) and DP[0] happen on pencils, in the driver.  The end
@@ -849,7 +867,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
   int rc;
   if (st_one_launch_gradients(op)) {
-    st_pressure_extrapolate(op, op->pL, st);
+    if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     if ((rc = st_gradient_and_pressure_gradient(op, op->V, st))) return rc;                                                      // MatVP (:512) + :639
     if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
   } else {
@@ -870,7 +888,7 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
   if (st_one_launch_gradients(op)) {
-    st_pressure_extrapolate(op, op->pL, st);
+    if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     int rc = st_gradient_and_pressure_gradient(op, op->strain, st); if (rc) return rc;                                           // :747, :701
   } else {
     { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                         // :747

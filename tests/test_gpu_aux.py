@@ -291,6 +291,26 @@ def test_options_and_kernel_families_agree():
     torch.cuda.synchronize()
     assert float((y1 - y0).norm() / y0.norm()) < 1e-13
     st.destroy()
+    # the pressure gradient with each direction's end-point extrapolation folded into its matrix (the default) against the
+    # three extrapolation passes of StokesPressureReduceOrder followed by plain D (option pressure_passes, read at create)
+    for dims in ((48, 40, 36), (30, 41), (66, 68, 72)):
+        outs = []
+        for passes in (0, 1):
+            sp.set_option("pressure_passes", passes)
+            try:
+                st = sp.StokesOp(dims)
+            finally:
+                sp.set_option("pressure_passes", 0)
+            st.set_rheology(1, 1.0, 3.0, 1e-3, 1.0)
+            g = torch.Generator(device="cuda").manual_seed(9)
+            x = torch.randn(st.global_size, dtype=torch.float64, device="cuda", generator=g)
+            p = torch.randn(st.pressure_size, dtype=torch.float64, device="cuda", generator=g)
+            f, m, vp = torch.empty_like(x), torch.empty_like(x), torch.empty(st.velocity_size, dtype=torch.float64, device="cuda")
+            st.function(x, f); st.mult(x, m); st.mult_vp(p, vp)
+            torch.cuda.synchronize()
+            outs.append((f, m, vp)); st.destroy()
+        for a, b in zip(*outs):
+            assert float((a - b).norm() / b.norm()) < 1e-12, dims
 
 
 def test_cheb_apply_on_an_array_of_a_gigabyte():
