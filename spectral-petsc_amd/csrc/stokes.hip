@@ -385,8 +385,8 @@ struct stokes_op {
   std::vector<int> dims;
   long N = 0, I = 0;
   std::map<int, DiffMat> mats;
-  // D with the end-point extrapolation of StokesPressureReduceOrder folded in, per extent (serial handles, every extent of
-  // 3 .. 256 points): gp[i] = matsP * pL needs no extrapolation pass -- see st_pressure_gradient
+  // D with the end-point extrapolation of StokesPressureReduceOrder folded in, per extent (every extent of 3 .. 256 points;
+  // in slab mode the matrix of dimension 0 is applied on the pencils): gp[i] = matsP * pL needs no extrapolation pass -- see st_pressure_gradient
   std::map<int, DiffMat> matsP; bool pext = false;
   std::vector<unsigned> innerP, ncolsP, innerV, ncolsV;      // DP[i] / DV[i] geometry
   int *ixL = nullptr;
@@ -488,7 +488,7 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
 #define OPRC(expr) do { int rc_ = (expr); if (rc_) { stokes_op_destroy(op); return rc_; } } while (0)
   for (int k = 0; k < d; k++)      // dimension 0: the global extent (in slab mode it is applied on pencils)
     if (!op->mats.count(gdims[k])) { DiffMat m; OPCHK(diffmat_create(gdims[k], &m)); op->mats[gdims[k]] = m; }
-  op->pext = !slab && !opt(OPT_PRESSURE_PASSES);            // "pressure_passes": the three extrapolation passes of the reference (A/B)
+  op->pext = !opt(OPT_PRESSURE_PASSES);                     // "pressure_passes": the three extrapolation passes of the reference (A/B)
   for (int k = 0; k < d; k++) op->pext = op->pext && gdims[k] >= 3 && op->mats[gdims[k]].KS != 0;
   if (op->pext)
     for (int k = 0; k < d; k++)
@@ -623,14 +623,14 @@ extern "C" int stokes_op_set_force(stokes_op *op, const double *force) {
 // ---- building blocks ------------------------------------------------------------------------
 // DP[k] (scalar field) or DV[k] (d stacked fields: same lines, d times as many)
 static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *y, int out_mode, const double *acc,
-                       double alpha, hipStream_t st) {
+                       double alpha, hipStream_t st, bool pext = false) {       // pext: the pressure matrices (stokes_op::matsP)
   if (op->slab && k == 0)       // lines along dimension 0 cross the slabs: transposes and the pencil sweep are the driver's
     return op->dim0(op->dim0_ctx, 0, vec ? op->d : 1, x, out_mode == OUT_ACC ? acc : nullptr, alpha, y, st);
   SweepParams sp = {};
   sp.ncols = vec ? op->ncolsV[k] : op->ncolsP[k];
   sp.inner = op->innerP[k];
   sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.out_mode = out_mode; sp.acc = acc; sp.alpha = alpha;
-  SHIPCHK(sweep_launch(op->mats[op->dims[k]], sp, st));
+  SHIPCHK(sweep_launch(pext ? op->matsP[op->dims[k]] : op->mats[op->dims[k]], sp, st));
   return 0;
 }
 
@@ -779,26 +779,21 @@ static void st_pressure_extrapolate(stokes_op *op, double *pL, hipStream_t st) {
 // pL (interior filled, boundary zero) -> boundary extrapolation -> gp[i] = DP[i] pL   (stokes.C:609-614)
 static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
   const int d = op->d;
-  // Serial handles, lines of at most 256 points: gp[i] at an interior node needs the end values of ITS line along i only,
-  // and those are a linear functional of the line's interior values (the other directions' extrapolations touch boundary
-  // lines, whose gradients the scatter never reads): the extrapolation is part of the matrix (diffmat_create_pext) and
-  // the three passes of StokesPressureReduceOrder are not run at all.  64^3 StokesMatMult: 62 -> 5x us.
-  if (op->pext) {
-    const double *x[3] = {op->pL, op->pL, op->pL};
-    return sweeps_multi(op, false, 0, x, op->gp, 1.0, st, false, true);
-  }
-  st_pressure_extrapolate(op, op->pL, st);      // z lines, y lines (and, on one GPU, x lines): stokes.C:1043-1074
+  // Lines of at most 256 points: gp[i] at an interior node needs the end values of ITS line along i only, and those are a
+  // linear functional of the line's interior values (the other directions' extrapolations touch boundary lines, whose
+  // gradients the scatter never reads): the extrapolation is part of the matrix (diffmat_create_pext) and the three passes
+  // of StokesPressureReduceOrder are not run at all.  64^3 StokesMatMult: 62.7 -> 47.8 us.
+  if (!op->pext) st_pressure_extrapolate(op, op->pL, st);      // z lines, y lines (and, on one GPU, x lines): stokes.C:1043-1074
   if (op->slab) {
-    // x lines cross the slabs: extrapolation (stokes.C:1064-1074) and DP[0] happen on pencils, in the driver.  The end
-    // planes of pL it would have filled only feed DP[1], DP[2] on those planes, which the final scatter never reads.
+    // x lines cross the slabs: their extrapolation (stokes.C:1064-1074) and DP[0] happen on pencils, in the driver
+    // (stokes_op_pencil_pressure).  Without pext, the end planes of pL the x pass would have filled only feed DP[1], DP[2]
+    // on those planes, which the final scatter never reads.
     int rc = op->dim0(op->dim0_ctx, 1, 1, op->pL, nullptr, 1.0, op->gp[0], st); if (rc) return rc;
-  }
-  if (op->slab) {
-    for (int i = 1; i < d; i++) { int rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
+    for (int i = 1; i < d; i++) { rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st, op->pext); if (rc) return rc; }
     return 0;
   }
   const double *x[3] = {op->pL, op->pL, op->pL};
-  return sweeps_multi(op, false, 0, x, op->gp, 1.0, st);
+  return sweeps_multi(op, false, 0, x, op->gp, 1.0, st, false, op->pext);
 }
 
 // pressure chain on the second stream, between the gather (already enqueued on st) and the final scatter
@@ -976,6 +971,13 @@ extern "C" int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pen
   ARGCHK(op && p_pencil && gp0_pencil);
   if (ncol <= 0) return ncol == 0 ? 0 : chebhip_fail(CHEBHIP_ERR_ARG, "bad pencil geometry");
   hipStream_t st = (hipStream_t)stream;
+  if (op->pext) {                                  // the extrapolation is part of the matrix: p_pencil is left as it is
+    SweepParams sp = {};
+    sp.ncols = (unsigned)ncol; sp.inner = (unsigned)ncol;
+    sp.in0 = p_pencil; sp.in_mode = IN_PLAIN; sp.out = gp0_pencil; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+    SHIPCHK(sweep_launch(op->matsP[op->gP0], sp, st));
+    return 0;
+  }
   hipLaunchKernelGGL(k_st_preduce, dim3(pgrid(ncol)), dim3(256), 0, st, p_pencil, ncol, 0L, 1L, 1L, 0L, 0L, ncol,
                      op->gP0, (const double *)op->w0[0], (const double *)op->w1[0]);
   return stokes_op_pencil_sweep(op, 1, ncol, p_pencil, gp0_pencil, stream);
