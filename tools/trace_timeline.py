@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The last n dispatches of a rocprofv3 --kernel-trace CSV in time order: name, duration, gap to the previous kernel's end, grid.
+usage: trace_timeline.py <directory holding *kernel_trace.csv> <n>"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
