@@ -399,6 +399,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   long_lines_gemm       1: lines of 257 .. 1024 points go to rocBLAS instead of the library's own matrix-core kernel (A/B)
  *   pressure_passes       1: Stokes handles run the three boundary-extrapolation passes of StokesPressureReduceOrder before the
  *                            pressure gradient instead of folding each direction's extrapolation into its matrix (read at create)
+ *   general_viscous       1: StokesMatMult / StokesMatMultVV take the general viscous block also when the viscosity is uniform and
+ *                            eta' = 0 (linear rheology), instead of -eta/2 (sum_j D_j D_j v + grad div v) (read at create)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

@@ -244,6 +244,22 @@ hipError_t diffmat_create_pext(int P, DiffMat *out) {
   return diffmat_from_dense(P, A.data(), 0, out);
 }
 
+// D D on all P points (rows and columns 0 .. n): formed in long double, rounded once.  D is centro-antisymmetric, so the
+// product is centro-symmetric.
+hipError_t diffmat_create_dd(int P, DiffMat *out) {
+  if (P < 3 || P > 256) return hipErrorInvalidValue;
+  const int n = P - 1;
+  std::vector<long double> D((size_t)P * P), A((size_t)P * P);
+  for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) D[(size_t)i * P + j] = dentry(i, j, n);
+  for (int i = 0; i < P; i++)
+    for (int j = 0; j < P; j++) {
+      long double s = 0.0L;
+      for (int q = 0; q < P; q++) s += D[(size_t)i * P + q] * D[(size_t)q * P + j];
+      A[(size_t)i * P + j] = s;
+    }
+  return diffmat_from_dense(P, A.data(), 1, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fast diagonalisation of the finite-difference preconditioner (elliptic.C:556-579 with eta = 1, deta = 0;
 // stokes.C:1181-1226 per velocity component): on the tensor grid that matrix is  sum_k I x .. x T_k x .. x I  with

@@ -311,7 +311,8 @@ template <int D>
 __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const double *__restrict__ yL,
                          const double *__restrict__ yL1, const double *__restrict__ yL2,
                          const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
-                         const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out) {
+                         const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out,
+                         const double *__restrict__ G) {                // G (may be null): one more velocity term (d fields), added after yL2
   GS_LOOP(l, N) {
     const int n = ixL[l];
     if (n < 0) continue;
@@ -324,6 +325,7 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
         double t = yL ? yL[k * N + l] : 0.0;
         if (yL1) t = t + yL1[k * N + l];
         if (yL2) t = t + yL2[k * N + l];
+        if (G) t = t + G[k * N + l];
         v[k] = t;
       }
       if (gp0) {
@@ -344,7 +346,8 @@ template <int UN>
 __global__ __launch_bounds__(256) void k_st_out4(long N, const int *__restrict__ ixL, const double *__restrict__ yL,
                                                  const double *__restrict__ yL1, const double *__restrict__ yL2,
                                                  const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
-                                                 const double *__restrict__ p2, const double *__restrict__ force, double *__restrict__ out) {
+                                                 const double *__restrict__ p2, const double *__restrict__ force, double *__restrict__ out,
+                                                 const double *__restrict__ G) {                // G (may be null): as in k_st_out
   const long T = (long)gridDim.x * blockDim.x;
   for (long l0 = blockIdx.x * (long)blockDim.x + threadIdx.x; l0 < N; l0 += UN * T) {
     int n[UN];
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(256) void k_st_out4(long N, const int *__restrict__
         double t = yL[k * N + l];
         t = t + yL1[k * N + l];
         t = t + yL2[k * N + l];
+        if (G) t = t + G[k * N + l];
         v[u][k] = t;
       }
       v[u][0] += 1.0 * gp0[l]; v[u][1] += 1.0 * gp1[l]; v[u][2] += 1.0 * gp2[l];
@@ -388,6 +392,9 @@ struct stokes_op {
   // D with the end-point extrapolation of StokesPressureReduceOrder folded in, per extent (every extent of 3 .. 256 points;
   // in slab mode the matrix of dimension 0 is applied on the pencils): gp[i] = matsP * pL needs no extrapolation pass -- see st_pressure_gradient
   std::map<int, DiffMat> matsP; bool pext = false;
+  // Uniform viscosity with eta' = 0 (the state after create and after a StokesFunction with the linear rheology): the viscous
+  // block of the Jacobian is -eta/2 (sum_j D_j D_j v + grad div v) -- see st_viscous_uniform.  matsDD: D D per extent.
+  std::map<int, DiffMat> matsDD; bool uniform_ok = false, eta_uniform = true; double eta_value = 1.0;
   std::vector<unsigned> innerP, ncolsP, innerV, ncolsV;      // DP[i] / DV[i] geometry
   int *ixL = nullptr;
   double *xL = nullptr, *yL = nullptr;                       // workV[0], workV[1]
@@ -435,6 +442,7 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
   for (auto &kv : op->matsP) diffmat_destroy(&kv.second);
+  for (auto &kv : op->matsDD) diffmat_destroy(&kv.second);
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
                    op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T};
   for (double *p : all) if (p) (void)hipFree(p);
@@ -493,6 +501,10 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
   if (op->pext)
     for (int k = 0; k < d; k++)
       if (!op->matsP.count(gdims[k])) { DiffMat m; OPCHK(diffmat_create_pext(gdims[k], &m)); op->matsP[gdims[k]] = m; }
+  op->uniform_ok = op->pext && !slab && d >= 2 && !opt(OPT_GENERAL_VISCOUS);        // "general_viscous": A/B
+  if (op->uniform_ok)
+    for (int k = 0; k < d; k++)
+      if (!op->matsDD.count(gdims[k])) { DiffMat m; OPCHK(diffmat_create_dd(gdims[k], &m)); op->matsDD[gdims[k]] = m; }
   {  // ixLP of StokesSetupDomain (stokes.C:791-879): interior index or -1, BlockIt order (of this slab)
     std::vector<int> ixL((size_t)N), ind(d, 0);
     long g = 0;
@@ -650,16 +662,18 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
   ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL);
 }
 // final scatter with every term present (StokesMatMult, StokesFunction)
-static void st_out_full(stokes_op *op, const double *force, double *out, hipStream_t st) {
+// y0, y1, y2 (+ G): the velocity terms, summed in this order (the general path: yL, yLx[1], yLx[2]; y1, y2, G may be null)
+static void st_out_full(stokes_op *op, const double *force, double *out, hipStream_t st, const double *y0 = nullptr, const double *y1 = nullptr,
+                        const double *y2 = nullptr, const double *G = nullptr) {
   const int d = op->d;
-  if (d == 3 && op->yLx[1] && op->yLx[2] && st_al16(out) && (!force || st_al16(force))) {
-    hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, (const double *)op->yL,
-                       (const double *)op->yLx[1], (const double *)op->yLx[2], (const double *)op->gp[0], (const double *)op->gp[1],
-                       (const double *)op->gp[2], (const double *)op->p2, force, out);
+  if (!y0) { y0 = op->yL; y1 = op->yLx[1]; y2 = op->yLx[2]; }
+  if (d == 3 && y1 && y2 && st_al16(out) && (!force || st_al16(force))) {
+    hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
+                       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
     return;
   }
-  ST_D(k_st_out, d + 1, (const int *)op->ixL, (const double *)op->yL, (const double *)op->yLx[1], (const double *)op->yLx[2],
-       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, force, out);
+  ST_D(k_st_out, d + 1, (const int *)op->ixL, y0, y1, y2,
+       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, force, out, G);
 }
 
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
@@ -730,6 +744,39 @@ static int st_gradient_and_pressure_gradient(stokes_op *op, double *const *out, 
   return 0;
 }
 static inline bool st_one_launch_gradients(const stokes_op *op) { return !op->aux && !op->slab; }
+
+// Uniform viscosity, eta' = 0 (linear rheology, stokes.C:470-474; the state after create): the viscous block of the Jacobian,
+//   -sum_j D_j eta (D_j v_c + D_c v_j) / 2 = -eta/2 ( sum_j D_j D_j v_c + D_c div v ),   div v = sum_j D_j v_j
+// (sweeps along different directions commute), needs no node loop and no second set of d^2 sweeps: ONE launch of the d
+// second-derivative sweeps V[j] = -eta/2 (D D)_j xL (d fields each), the d sweeps of the trace t_j = D_j v_j and, for
+// StokesMatMult, the d pressure-gradient sweeps; a pointwise sum div v = sum t_j (also the pressure rows); one launch of the
+// d sweeps G_c = -eta/2 D_c div v.  The scatter adds V[0] + V[1] + V[2] + G (+ grad p).  15 field sweeps instead of 18 and a
+// 3-array sum instead of the 27-array node loop.  Same result to rounding (tests: against the general path and the oracle).
+__global__ void k_st_sum_fields(long N, int d, const double *__restrict__ t, double *__restrict__ out) {
+  GS_LOOP(i, N) { double v = t[i] + t[N + i]; if (d == 3) v = v + t[2 * N + i]; out[i] = v; }
+}
+static inline bool st_uniform(const stokes_op *op) { return op->uniform_ok && op->eta_uniform && !op->deta_nonzero; }
+static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st) {
+  const int d = op->d; const long N = op->N;
+  const double a = -0.5 * op->eta_value;
+  const DiffMat *m[9]; SweepParams sp[9];
+  int n = 0;
+  auto job = [&](const DiffMat &mat, bool vec, int k, const double *in, double *out, double alpha) {
+    sp[n] = SweepParams{};
+    sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
+    sp[n].in0 = in; sp[n].in_mode = IN_PLAIN; sp[n].out = out; sp[n].out_mode = OUT_STORE; sp[n].alpha = alpha;
+    m[n++] = &mat;
+  };
+  for (int k = 0; k < d; k++) job(op->matsDD[op->dims[k]], true, k, op->xL, op->V[k], a);
+  for (int k = 0; k < d; k++) job(op->mats[op->dims[k]], false, k, op->xL + (size_t)k * N, op->yL + (size_t)k * N, 1.0);
+  if (with_pressure) for (int k = 0; k < d; k++) job(op->matsP[op->dims[k]], false, k, op->pL, op->gp[k], 1.0);
+  SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  hipLaunchKernelGGL(k_st_sum_fields, dim3(sgrid(N)), dim3(256), 0, st, N, d, (const double *)op->yL, op->p2);
+  n = 0;
+  for (int c = 0; c < d; c++) job(op->mats[op->dims[c]], false, c, op->p2, op->yLx[1] + (size_t)c * N, a);
+  SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  return 0;
+}
 
 // viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]; div (may be null)
 // receives the trace of the gradient = StokesDivergence of the same xL.  have_gradient: V already holds DV[j] xL.
@@ -822,8 +869,14 @@ extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, v
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
+  if (st_uniform(op)) {
+    int rc = st_viscous_uniform(op, false, st); if (rc) return rc;
+    ST_OUT(d, (const int *)op->ixL, CDP(op->V[0]), CDP(op->V[1]), CDP(op->V[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(op->yLx[1]));
+    SHIPCHK(hipGetLastError());
+    return 0;
+  }
   int rc = st_viscous_jacobian(op, nullptr, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out);
+  ST_OUT(d, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(nullptr));
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -835,7 +888,7 @@ extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, 
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
   int rc = st_divergence(op, st); if (rc) return rc;
-  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout);
+  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout, CDP(nullptr));
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -847,7 +900,7 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
   const int d = op->d;
   st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
   int rc = st_pressure_gradient(op, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout);
+  ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout, CDP(nullptr));
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -861,6 +914,12 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   // MatVV (:508) and MatPV (:509), whose result is the trace written by the node loop
   st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
   int rc;
+  if (st_uniform(op)) {
+    if ((rc = st_viscous_uniform(op, true, st))) return rc;
+    st_out_full(op, nullptr, yG, st, op->V[0], op->V[1], op->V[2], op->yLx[1]);
+    SHIPCHK(hipGetLastError());
+    return 0;
+  }
   if (st_one_launch_gradients(op)) {
     if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     if ((rc = st_gradient_and_pressure_gradient(op, op->V, st))) return rc;                                                      // MatVP (:512) + :639
@@ -899,6 +958,7 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
     ST_D(k_st_node_fn, op->strain[0], op->strain[1], op->strain[2], op->V[0], op->V[1], op->V[2], op->eta, op->deta, op->p2,
          op->rh_kind, op->rh_hard, op->rh_expo, op->rh_eps, op->rh_g0);
   op->deta_nonzero = (op->rh_kind == 1);
+  op->eta_uniform = (op->rh_kind == 0); op->eta_value = 1.0;                      // linear rheology: eta = 1, eta' = 0 (k_st_node_fn)
   int rc = st_div_stress(op, st, op->sym); if (rc) return rc;                                                                    // :737-740
   if ((rc = st_join(op, st))) return rc;
   st_out_full(op, op->force, yG, st);                                                                                              // :750-756
@@ -1017,6 +1077,7 @@ extern "C" int stokes_op_set_state(stokes_op *op, int which, const double *src) 
   if (!soa) {
     SHIPCHK(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
     if (which == 1) { bool nz = false; for (size_t i = 0; i < n && !nz; i++) nz = (src[i] != 0.0); op->deta_nonzero = nz; }
+    if (which == 0) { bool same = n > 0; for (size_t i = 1; i < n && same; i++) same = (src[i] == src[0]); op->eta_uniform = same; op->eta_value = same ? src[0] : 1.0; }
     return 0;
   }
   std::vector<double> tmp(n);

@@ -93,6 +93,8 @@ hipError_t diffmat_create(int P, DiffMat *out);
 hipError_t diffmat_create_lap(int P, DiffMat *out);
 // D acting on the interior values of a line whose two end values are extrapolated from them (3 <= P <= 256; see diffmat.cpp)
 hipError_t diffmat_create_pext(int P, DiffMat *out);
+// D D on all P points of a line (3 <= P <= 256; centro-symmetric): the second derivative of a line that carries its end values
+hipError_t diffmat_create_dd(int P, DiffMat *out);
 void diffmat_destroy(DiffMat *m);
 // Fragments of an arbitrary centro-symmetric (sym = 1) / centro-antisymmetric (sym = 0) dense M x M matrix, M <= 256.
 hipError_t diffmat_from_dense(int M, const long double *A, int sym, DiffMat *out);
@@ -155,7 +157,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_NO_ROCBLAS, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

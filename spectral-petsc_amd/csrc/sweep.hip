@@ -518,8 +518,8 @@ static void sweep_fill(const DiffMat &m, SweepParams &p) {
 }
 
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {
-  if (n >= 2 && n <= 6 && !opt(OPT_SEPARATE_LAUNCHES)) {
-    SweepParams jobs[6];
+  if (n >= 2 && n <= 9 && !opt(OPT_SEPARATE_LAUNCHES)) {
+    SweepParams jobs[9];
     bool ok = true;
     for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); ok = ok && m[j]->KS != 0; }
     if (ok) {

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
 // that its XCD-aware tile walk holds.  Small grids are bound by the fixed cost of a launch (~5 us at 64^3), not
 // by its work: the d gradient sweeps of a Stokes callback, its d divergence sweeps and its d pressure-gradient
 // sweeps are one launch each this way (stokes.hip); on one stream the gradient and pressure-gradient sweeps share a launch.
-constexpr int MULTI_MAX = 6;
+constexpr int MULTI_MAX = 9;
 struct MultiParams { int njobs; unsigned bstart[MULTI_MAX + 1]; SweepParams job[MULTI_MAX]; };
 
 template <int KS>

@@ -313,6 +313,64 @@ def test_options_and_kernel_families_agree():
             assert float((a - b).norm() / b.norm()) < 1e-12, dims
 
 
+@pytest.mark.parametrize("dims", [(48, 40, 36), (30, 41), (66, 68, 72), (33, 17, 9)], ids=lambda d: "x".join(map(str, d)))
+def test_uniform_viscosity_jacobian_path(dims):
+    """With a uniform viscosity and eta' = 0 (after create, after a StokesFunction with the linear rheology, after
+    set_state(eta = const)) StokesMatMult / StokesMatMultVV run -eta/2 (sum_j D_j D_j v + grad div v) instead of the node loop
+    (option general_viscous, read at create, keeps the general block): both against each other and against the oracle; a
+    non-uniform viscosity or a power-law state must take the general path again."""
+    d = len(dims)
+    rng = np.random.default_rng(SEED)
+    ops = []
+    for general in (0, 1):
+        sp.set_option("general_viscous", general)
+        try:
+            ops.append(sp.StokesOp(dims))
+        finally:
+            sp.set_option("general_viscous", 0)
+    fast, gen = ops
+    x = rng.standard_normal(fast.global_size); v = rng.standard_normal(fast.velocity_size)
+    N = fast.local_nodes
+
+    def both(state):
+        outs = []
+        for op in ops:
+            state(op)
+            y = torch.empty(op.global_size, dtype=torch.float64, device="cuda"); yv = torch.empty(op.velocity_size, dtype=torch.float64, device="cuda")
+            op.mult(dev(x), y); op.mult_vv(dev(v), yv); torch.cuda.synchronize()
+            outs.append((y.cpu().numpy(), yv.cpu().numpy()))
+        return outs
+    # 1. the state after create: eta = 1
+    (y0, v0), (y1, v1) = both(lambda op: None)
+    assert relerr(y0, y1) < 1e-12 and relerr(v0, v1) < 1e-12
+    assert relerr(y0, orc.stokes_mult(dims, x, mode=orc.DIRECT)) < 1e-10 and relerr(v0, orc.stokes_mult_vv(dims, v, mode=orc.DIRECT)) < 1e-10
+    # 2. a uniform viscosity other than 1
+    (y0, v0), (y1, v1) = both(lambda op: op.set_state(0, np.full(N, 2.5)))
+    assert relerr(y0, y1) < 1e-12 and relerr(v0, v1) < 1e-12
+    assert relerr(v0, orc.stokes_mult_vv(dims, v, eta=np.full(N, 2.5), mode=orc.DIRECT)) < 1e-10
+    # 3. a variable viscosity: the general path in both handles (bitwise the same code)
+    eta = np.exp(rng.uniform(-1, 1, N))
+    (y0, v0), (y1, v1) = both(lambda op: op.set_state(0, eta))
+    assert np.array_equal(y0, y1) and np.array_equal(v0, v1)
+    assert relerr(v0, orc.stokes_mult_vv(dims, v, eta=eta, mode=orc.DIRECT)) < 1e-10
+    # 4. StokesFunction: linear rheology re-arms the fast path, power law disarms it
+    dv = rng.standard_normal(fast.dirichlet_size); f = rng.standard_normal(fast.global_size)
+    for op in ops:
+        op.set_dirichlet(dv); op.set_force(f)
+    def fn(rheo):
+        def go(op):
+            op.set_rheology(*rheo); r = torch.empty(op.global_size, dtype=torch.float64, device="cuda"); op.function(dev(x), r)
+        return go
+    (y0, v0), (y1, v1) = both(fn((0, 1.0, 1.0, 1.0, 1.0)))
+    assert relerr(y0, y1) < 1e-12 and relerr(y0, orc.stokes_mult(dims, x, mode=orc.DIRECT)) < 1e-10
+    (y0, v0), (y1, v1) = both(fn(POWER))
+    assert np.array_equal(y0, y1)
+    _, eta_p, deta_p, strain_p = orc.stokes_function(dims, x, dv, f, rheology=POWER, mode=orc.DIRECT)
+    assert relerr(y0, orc.stokes_mult(dims, x, eta_p, deta_p, strain_p, mode=orc.DIRECT)) < 1e-10
+    for op in ops:
+        op.destroy()
+
+
 def test_cheb_apply_on_an_array_of_a_gigabyte():
     """Arrays of 0.94 GB and more are beyond the 32-bit buffer offsets of the long-line kernel: the general kernel takes
     them (sweep_vec_eligible).  Checked against the same plan applied to the two halves of the tensor (dimension 0 is not
