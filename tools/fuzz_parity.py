@@ -72,6 +72,7 @@ while time.time() - t0 < budget:
             dims = (int(rng.integers(257, 330)), int(rng.integers(4, 20)))[::int(rng.choice([1, -1]))]
         op = sp.StokesOp(dims)
         power = (1, 1.0, float(rng.choice([1.0, 2.0, 3.0])), 10.0 ** -float(rng.integers(1, 5)), 1.0)
+        if rng.random() < 0.35: power = (0, 1.0, 1.0, 1.0, 1.0)          # linear rheology: the uniform-viscosity Jacobian (no node loop)
         x = rng.standard_normal(op.global_size); dv = rng.standard_normal(op.dirichlet_size); f = rng.standard_normal(op.global_size)
         op.set_rheology(*power); op.set_dirichlet(dv); op.set_force(f)
         y = torch.empty(op.global_size, dtype=torch.float64, device="cuda")
