@@ -252,6 +252,9 @@ def device_view(ptr, n):
     """A float64 tensor over n doubles of device memory owned by someone else (no copy)."""
     import torch
 
+    if not ptr or int(n) == 0:          # an empty vector (a slab that owns only boundary planes): the library may hand over NULL
+        return torch.empty(0, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+
     class _Arr:
         pass
     a = _Arr()

@@ -14,32 +14,60 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_dist as t
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0 = time.time(); nfail = 0; ncase = 0
-while time.time() - t0 < budget:
-    kind = int(rng.integers(0, 3))
-    world = int(rng.integers(2, 5))
-    try:
-        if kind == 0:
-            d = int(rng.integers(2, 4))
-            dims = tuple(int(v) for v in rng.integers(max(world + 2, 5), 14, size=d))
-            t.test_distributed_poisson_solve(world, dims)
-            tag = "poisson"
-        elif kind == 1:
-            d = int(rng.integers(2, 4))
-            dims = tuple(int(v) for v in rng.integers(max(world + 1, 4), 13 if d == 2 else 10, size=d))
-            t.test_elliptic_slab_ranks_match_oracle_and_solve(world, dims)
-            tag = "elliptic"
-        else:
-            dims = tuple(int(v) for v in rng.integers(max(world + 1, 5), 10, size=3))
-            t.test_slab_ranks_match_oracle(world, dims)
-            tag = "stokes"
-        print("ok", tag, world, dims, flush=True)
-    except Exception as e:                                   # noqa: BLE001 -- a fuzz driver reports and goes on
-        nfail += 1
-        print("FAIL", kind, world, dims, repr(e), flush=True)
-        traceback.print_exc()
-    ncase += 1
-print("cases %d failures %d in %.0f s" % (ncase, nfail, time.time() - t0))
-sys.exit(min(nfail, 100))
+def serial_newton_converges(dims):
+    """The acceptance solve of the elliptic case (Newton with backtracking from x = 0, gamma = 4, cos_scale = 3) stalls at a
+    local minimum of |F| on some unresolved grids -- (11, 5), (7, 9), (5, 9, 7), (7, 6, 9), (7, 7, 6) ... -- on ONE GPU too;
+    such draws say nothing about the slab code and are skipped."""
+    import torch
+    from importlib import import_module
+    import __graft_entry__ as ge
+    import oracle_lib as orc
+    sp = ge.load(); solve = import_module(sp.__name__ + ".solve")
+    u, u2, dv = orc.elliptic_exact(dims, 0, gamma=4.0, exponent=2.0, cos_scale=3.0)
+    op = sp.EllipticOp(dims); op.set_dirichlet(dv)
+    b = torch.from_numpy(u2.copy()).cuda(); x = torch.zeros_like(b)
+    G = int(np.prod([v - 2 for v in dims]))
+    its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-11, ksp_rtol=1e-12, ksp_restart=min(256, G), ksp_max_it=20000, snes_max_it=100)
+    op.destroy()
+    return fn <= 1e-9 * float(np.linalg.norm(u2))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t0 = time.time(); nfail = 0; ncase = 0
+    while time.time() - t0 < budget:
+        kind = int(rng.integers(0, 3))
+        world = int(rng.integers(2, 5))
+        try:
+            if kind == 0:
+                d = int(rng.integers(2, 4))
+                dims = tuple(int(v) for v in rng.integers(max(world + 2, 5), 14, size=d))
+                t.test_distributed_poisson_solve(world, dims)
+                tag = "poisson"
+            elif kind == 1:
+                d = int(rng.integers(2, 4))
+                dims = tuple(int(v) for v in rng.integers(max(world + 1, 4), 13 if d == 2 else 10, size=d))
+                if not serial_newton_converges(dims):
+                    print("skip elliptic", world, dims, "(the serial Newton stalls on this grid too)", flush=True); continue
+                t.test_elliptic_slab_ranks_match_oracle_and_solve(world, dims)
+                tag = "elliptic"
+            else:
+                dims = tuple(int(v) for v in rng.integers(max(world + 1, 5), 10, size=3))
+                t.test_slab_ranks_match_oracle(world, dims)
+                tag = "stokes"
+            print("ok", tag, world, dims, flush=True)
+        except Exception as e:                                   # noqa: BLE001 -- a fuzz driver reports and goes on
+            nfail += 1
+            print("FAIL", kind, world, dims, repr(e), flush=True)
+            traceback.print_exc()
+        ncase += 1
+        if nfail >= 5:
+            break
+    print("cases %d failures %d in %.0f s" % (ncase, nfail, time.time() - t0))
+    sys.exit(min(nfail, 100))
+
+
+# (the rank processes are spawned: they import this file again, and must not start a fuzz run of their own)
+if __name__ == "__main__":
+    main()
