@@ -401,6 +401,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *                            pressure gradient instead of folding each direction's extrapolation into its matrix (read at create)
  *   general_viscous       1: StokesMatMult / StokesMatMultVV take the general viscous block also when the viscosity is uniform and
  *                            eta' = 0 (linear rheology), instead of -eta/2 (sum_j D_j D_j v + grad div v) (read at create)
+ *   poisson_launches      the constant-coefficient MatMult_Elliptic: 0 = by size (one launch of d jobs + a sum below 6 M unknowns,
+ *                            a launch per direction above), 1 = always the d-job launch, 2 = always a launch per direction
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

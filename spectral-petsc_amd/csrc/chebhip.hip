@@ -404,6 +404,18 @@ __global__ void k_flux(long N, const double *__restrict__ eta, const double *__r
   }
 }
 
+// V = (a + b) (+ c): the terms of the one-launch constant-coefficient apply, added in the order of the accumulating chain
+__global__ void k_sum_terms(long n, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, double *__restrict__ V) {
+  const long half = n >> 1;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < half; t += (long)gridDim.x * blockDim.x) {
+    const double2 x = ((const double2 *)a)[t], y = ((const double2 *)b)[t];
+    double2 v = make_double2(x.x + y.x, x.y + y.y);
+    if (c) { const double2 z = ((const double2 *)c)[t]; v.x = v.x + z.x; v.y = v.y + z.y; }
+    ((double2 *)V)[t] = v;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { double v = a[n - 1] + b[n - 1]; if (c) v = v + c[n - 1]; V[n - 1] = v; }
+}
+
 // V = VecScatter(LG)(W): interior nodes of the local vector to the global one (elliptic.C:336)
 __global__ void k_scatter_lg(long N, const int *__restrict__ ixL, const double *__restrict__ W, double *__restrict__ V) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
@@ -457,6 +469,7 @@ struct ell_op {
   std::vector<double *> g;              // d work vectors: gradients / fluxes (c->w[1..d])
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
   unsigned wpad = 0;                    // constant-coefficient path: row pitch of W in its padded interior layout (0: dense)
+  double *Wj[2] = {nullptr, nullptr};   // constant-coefficient path, small grids: the other directions' terms of the one-launch apply (G doubles each)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
   // slab mode (multi-GPU): the handle owns the planes [lo, lo + dims[0]) of a grid whose dimension 0 has
@@ -678,7 +691,7 @@ extern "C" int ell_op_destroy(ell_op *op) {
   for (auto p : op->g) if (p) (void)hipFree(p);
   for (auto p : op->gradu_alloc) if (p) (void)hipFree(p);
   for (auto p : op->cprod_alloc) if (p) (void)hipFree(p);
-  double *singles[] = {op->W, op->w0_alloc, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
+  double *singles[] = {op->W, op->Wj[0], op->Wj[1], op->w0_alloc, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
   for (double *p : singles) if (p) (void)hipFree(p);
   if (op->ixL) (void)hipFree(op->ixL);
   delete op;
@@ -929,6 +942,38 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
     // V = -sum_k D_k D_k w0 restricted to the interior, one launch per direction.
     // The two sweeps of a direction collapse into one product with the interior block of D D (constant coefficient):
     // half the MFMA work of the fused gradient -> flux -> divergence launch the variable-coefficient path needs.
+    // Small grids (2 <= d <= 3, fewer than 6 M unknowns; option "poisson_launches"): the d directions as ONE launch of d
+    // jobs, each storing its term, and a pointwise sum in the order of the chain below (the same bits).  80 B/point instead
+    // of 64, but at these sizes the vectors sit in the Infinity Cache and the apply is bound by its launches, not its bytes:
+    // A/B on one handle (tools/poisson_ab.py): 32^3 14.2 -> 11.6 us, 64^3 15.8 -> 11.4, 96^3 33.1 -> 24.9, 128^3 37.8 -> 36.6,
+    // 160^3 124 -> 106; 192^3 151 -> 160 and 256^3 246 -> 327 are why there is a size limit.  Falls through when the jobs
+    // cannot share a launch (mixed line lengths, odd strides, unaligned vectors).
+    {
+      const int mode = opt(OPT_POISSON_LAUNCHES);
+      const int d = op->d;
+      if (d >= 2 && d <= 3 && mode != 2 && (mode == 1 || op->G < 6000000L) && aligned16(U) && aligned16(V)) {
+        if (!op->Wj[0]) {
+          HIPCHK(hipMalloc((void **)&op->Wj[0], (size_t)(op->G + 2) * sizeof(double)));
+          HIPCHK(hipMalloc((void **)&op->Wj[1], (size_t)(op->G + 2) * sizeof(double)));
+        }
+        const DiffMat *m[3]; SweepParams sp[3];
+        double *term[3] = {op->W, op->Wj[0], op->Wj[1]};
+        for (int k = 0; k < d; k++) {
+          sp[k] = SweepParams{};
+          sp[k].ncols = op->ncols_g[k]; sp[k].inner = op->inner_g[k];
+          sp[k].in0 = U; sp[k].in_mode = IN_PLAIN; sp[k].alpha = -1.0; sp[k].out_mode = OUT_STORE; sp[k].out = term[k];
+          m[k] = &op->laps[op->dims[k]];
+        }
+        bool done = false;
+        HIPCHK(sweep_launch_multi_try(d, m, sp, st, &done));
+        if (done) {
+          hipLaunchKernelGGL(k_sum_terms, dim3(pw_grid((op->G + 1) >> 1)), dim3(256), 0, st, op->G, (const double *)term[0], (const double *)term[1],
+                             (const double *)(d == 3 ? term[2] : nullptr), V);
+          HIPCHK(hipGetLastError());
+          return 0;
+        }
+      }
+    }
     if (op->wpad && aligned16(U) && aligned16(V)) {
       // d = 2, 3 with lines of more than 64 points: the accumulator W keeps its rows padded to a multiple of
       // 128 B (pitch wpad), so that the strided launches read and write whole cache lines of it; U and V stay

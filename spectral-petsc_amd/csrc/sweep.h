@@ -149,6 +149,8 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
 hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *jobs, hipStream_t stream, bool *done);
 // n independent sweeps (plain in, STORE out): one launch when they qualify (sweep_vec.hip), else n launches
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream);
+// ... only if they can share ONE launch (*done = true); otherwise nothing is launched (*done = false)
+hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream, bool *done);
 
 long sweep_launch_count();
 // compute units of the CURRENT device (cached per device id); 0 on error with *err set
@@ -157,7 +159,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_NO_ROCBLAS, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

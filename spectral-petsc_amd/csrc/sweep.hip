@@ -517,6 +517,14 @@ static void sweep_fill(const DiffMat &m, SweepParams &p) {
   p.sym = m.sym; p.longDT = m.longDT; p.longD = m.longD;
 }
 
+hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream, bool *done) {
+  *done = false;
+  if (n < 2 || n > 9 || opt(OPT_SEPARATE_LAUNCHES)) return hipSuccess;
+  SweepParams jobs[9];
+  for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); if (m[j]->KS == 0) return hipSuccess; }
+  return sweep_vec_launch_multi(n, m, jobs, stream, done);
+}
+
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {
   if (n >= 2 && n <= 9 && !opt(OPT_SEPARATE_LAUNCHES)) {
     SweepParams jobs[9];

@@ -291,6 +291,18 @@ def test_options_and_kernel_families_agree():
     torch.cuda.synchronize()
     assert float((y1 - y0).norm() / y0.norm()) < 1e-13
     st.destroy()
+    # the constant-coefficient matvec: one launch of d jobs + a sum in the chain's order against a launch per direction: same bits
+    for dims in ((66, 68, 72), (40, 36, 34), (130, 72), (33, 17, 9)):
+        op = sp.EllipticOp(dims)
+        U = torch.randn(op.global_size, dtype=torch.float64, device="cuda"); Va, Vb = torch.empty_like(U), torch.empty_like(U)
+        try:
+            sp.set_option("poisson_launches", 1); op.mult(U, Va)
+            sp.set_option("poisson_launches", 2); op.mult(U, Vb)
+        finally:
+            sp.set_option("poisson_launches", 0)
+        torch.cuda.synchronize()
+        assert torch.equal(Va, Vb), dims
+        op.destroy()
     # the pressure gradient with each direction's end-point extrapolation folded into its matrix (the default) against the
     # three extrapolation passes of StokesPressureReduceOrder followed by plain D (option pressure_passes, read at create)
     for dims in ((48, 40, 36), (30, 41), (66, 68, 72)):
