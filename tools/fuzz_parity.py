@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep against the CPU oracle (one-off hardening run, not part of the test-suite):
 random ranks, extents, directions and coefficient states for cheb_apply, the elliptic callbacks, the Stokes
-callbacks and the slab-mode drivers at one rank.  usage: fuzz_parity.py [seconds] [seed]"""
+callbacks and the slab-mode drivers at one rank.  usage: python -u fuzz_parity.py [seconds] [seed]   (-u: a progress line per 500 cases must reach the log while the run lasts)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
