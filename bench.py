@@ -172,6 +172,15 @@ def extras(sp, torch):
         xs = rnd(op.global_size); ys = torch.empty_like(xs)
         out[key + "_function_us"] = t_us(lambda: op.function(xs, ys), 60)
         out[key + "_matmult_us"] = t_us(lambda: op.mult(xs, ys), 100)
+        if not power:
+            # config 4 names the Schur apply as well: StokesMatMultSchur = VP, the inner velocity solve on StokesMatMultVV, PV
+            # (stokes.C:523-535).  Priced at a FIXED 20 inner GMRES iterations (built-in solver, no preconditioner, restart 30):
+            # how many a run takes depends on its inner preconditioner and tolerance, the cost per iteration does not
+            xv = rnd(op.velocity_size); yv = torch.empty_like(xv); xp = rnd(op.pressure_size); yp = torch.empty_like(xp)
+            out[key + "_matmult_vv_us"] = t_us(lambda: op.mult_vv(xv, yv), 100)
+            op.mult_schur(xp, yp, restart=30, rtol=1e-300, max_it=20)
+            assert op.inner_iterations == 20
+            out[key + "_schur_apply_20_inner_its_us"] = t_us(lambda: op.mult_schur(xp, yp), 10)
         op.destroy()
     return out
 
