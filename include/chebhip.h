@@ -385,8 +385,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  * environment).  Unknown names are an error.  Set them before creating the handles they concern.
  *   general_kernels       1: every sweep runs the general 8-byte kernel (A/B against the 16-byte kernels)
  *   separate_launches     1: the d sweeps of a Stokes gradient / divergence are d launches instead of one
- *   no_rocblas            1: sweeps that would go to rocBLAS (lines of more than 1024 points; or see long_lines_gemm, force_gemm)
- *                            use the library's own FP64-VALU kernel instead (first use decides)
+ *   vendor_gemm           1: plain sweeps of lines of more than 1024 points go to rocBLAS DGEMM (looked up at run time, never linked)
+ *                            instead of the library's own FP64-VALU kernel.  Default 0: no vendor GEMM on any default path
  *   no_raw_transforms     1: the preconditioner's line transforms take two launches instead of one
  *   equal_shares          1: multi-job launches give every job min(tiles, CUs) workgroups instead of proportional shares
  *   force_gemm            1: every extent of 4 .. 256 points takes the library-DGEMM route of the longest lines (read at operator create)

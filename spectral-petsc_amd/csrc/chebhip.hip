@@ -1184,8 +1184,10 @@ static int ell_state_ptr(ell_op *op, int which, double **p) {
 extern "C" int ell_op_get_state(ell_op *op, int which, double *dst) {
   if (!op || !dst) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
-  if (which < 2 && (rc = ell_sync_coeffs(op, nullptr))) return rc;
+  // a FormFunction still queued on a non-blocking stream must have written w0 before the null-stream rebuild of eta / deta reads it
   HIPCHK(hipDeviceSynchronize());
+  if (which < 2 && (rc = ell_sync_coeffs(op, nullptr))) return rc;
+  HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipMemcpy(dst, p, (size_t)op->N * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1193,8 +1195,9 @@ extern "C" int ell_op_get_state(ell_op *op, int which, double *dst) {
 extern "C" int ell_op_set_state(ell_op *op, int which, const double *src) {
   if (!op || !src) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   double *p; int rc = ell_state_ptr(op, which, &p); if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());                               // as in ell_op_get_state: callbacks on non-blocking streams first
   if ((rc = ell_sync_coeffs(op, nullptr))) return rc;           // the untouched one of eta / deta must be current
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipMemcpy(p, src, (size_t)op->N * sizeof(double), hipMemcpyHostToDevice));
   if (which >= 2) op->bdy_lines_dirty = true;
   op->mode = COEFF_FULL; op->cdirty = true;

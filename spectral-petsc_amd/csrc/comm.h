@@ -12,6 +12,9 @@ struct XSeg { int peer; const double *send; long nsend; double *recv; long nrecv
 
 // All segments of one exchange, ordered on `st`.  Segments whose peer is the calling rank are device copies.
 int comm_exchange(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st);
+// A rank that fails between two exchanges of a collective call releases the thread ranks waiting for it (LOCAL transport:
+// their barriers fail at once instead of after local_timeout_s); nothing to do for the other transports.
+void comm_abort(chebhip_comm *c);
 int comm_size(const chebhip_comm *c);
 int comm_rank(const chebhip_comm *c);
 

@@ -163,12 +163,21 @@ extern "C" int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebh
     std::lock_guard<std::mutex> lk(g->mu);
     s.device = dev; s.bound = true;
     // ranks on other devices of this process: the pulls read their buffers directly (xGMI peer access)
+    // (multi-device LOCAL groups are untested on hardware: every test box has one GPU)
+    int no_peer = -1;
     for (int r = 0; r < g->G; r++)
       if (g->slot[r].bound && g->slot[r].device != dev) {
+        int can_a = 0, can_b = 0;
+        if (hipDeviceCanAccessPeer(&can_a, dev, g->slot[r].device) != hipSuccess || hipDeviceCanAccessPeer(&can_b, g->slot[r].device, dev) != hipSuccess || !can_a || !can_b) { no_peer = g->slot[r].device; break; }
         (void)hipDeviceEnablePeerAccess(g->slot[r].device, 0);                                  // "already enabled" is fine
         int cur = dev; (void)hipSetDevice(g->slot[r].device); (void)hipDeviceEnablePeerAccess(cur, 0); (void)hipSetDevice(cur);
         (void)hipGetLastError();
       }
+    if (no_peer >= 0) {
+      s.bound = false;
+      (void)hipFree(c->scratch); delete c;
+      return chebhip_fail(CHEBHIP_ERR_DEVICE, "local comm: devices %d and %d cannot access each other's memory (the pulls of the LOCAL transport read peers' buffers directly)", dev, no_peer);
+    }
   }
   *out = c;
   return 0;
@@ -227,6 +236,7 @@ extern "C" int chebhip_comm_rank(const chebhip_comm *c) { return c ? c->rank : -
 namespace chebhip {
 int comm_size(const chebhip_comm *c) { return c ? c->G : 1; }
 int comm_rank(const chebhip_comm *c) { return c ? c->rank : 0; }
+void comm_abort(chebhip_comm *c) { if (c && c->kind == KIND_LOCAL && c->lg) c->lg->abort(); }
 
 static int self_copies(const chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
   for (int i = 0; i < nseg; i++)
@@ -344,6 +354,7 @@ extern "C" int chebhip_comm_reduce(void *comm, double *vals_dev, int count, void
     if (r != c->rank && (e = hipStreamWaitEvent(st, g->slot[r].ready, 0)) != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipStreamWaitEvent: %s", hipGetErrorString(e)); }
   }
   hipLaunchKernelGGL(k_local_reduce, dim3(1), dim3(64), 0, st, in, g->G, count, c->scratch);
+  if ((e = hipGetLastError()) != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "k_local_reduce: %s", hipGetErrorString(e)); }
   e = hipEventRecord(me.done, st);
   if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
   rc = g->barrier(); if (rc) return rc;

@@ -164,11 +164,13 @@ struct chebhip_dist_stokes { SlabX x; stokes_op *op = nullptr; };
 static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const double *acc, double alpha, double *out, void *stream) {
   chebhip_dist_stokes *D = (chebhip_dist_stokes *)ctx;
   hipStream_t st = (hipStream_t)stream;
-  int rc = D->x.to_pencil(nf, in, st); if (rc) return rc;
+  // a failure between the two exchanges must not leave the peers of a thread-rank group waiting for this rank
+  int rc = D->x.to_pencil(nf, in, st); if (rc) { chebhip::comm_abort(D->x.comm); return rc; }
   if (kind == 0) rc = stokes_op_pencil_sweep(D->op, nf, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);     // DV[0] / DP[0]
   else rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);                // x-line extrapolation + DP[0]
-  if (rc) return rc;
-  return D->x.to_slab(nf, acc, alpha, out, st);
+  if (!rc) rc = D->x.to_slab(nf, acc, alpha, out, st);
+  if (rc) chebhip::comm_abort(D->x.comm);
+  return rc;
 }
 
 extern "C" int chebhip_dist_stokes_destroy(chebhip_dist_stokes *D) {
@@ -203,9 +205,11 @@ static int dell_dim0(void *ctx, int kind, int nf, const double *in, const double
   chebhip_dist_ell *D = (chebhip_dist_ell *)ctx;
   (void)kind;
   hipStream_t st = (hipStream_t)stream;
-  int rc = D->x.to_pencil(nf, in, st); if (rc) return rc;
-  if ((rc = ell_op_pencil_sweep(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream))) return rc;           // D_0 on the pencil
-  return D->x.to_slab(nf, acc, alpha, out, st);
+  int rc = D->x.to_pencil(nf, in, st);
+  if (!rc) rc = ell_op_pencil_sweep(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);                   // D_0 on the pencil
+  if (!rc) rc = D->x.to_slab(nf, acc, alpha, out, st);
+  if (rc) chebhip::comm_abort(D->x.comm);
+  return rc;
 }
 
 extern "C" int chebhip_dist_ell_destroy(chebhip_dist_ell *D) {

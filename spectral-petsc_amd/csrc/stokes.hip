@@ -527,7 +527,8 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
   if (!slab) for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
   for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
   OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
-  if (!slab && d == 3 && (N & 1) == 0 && (size_t)N * 9 * 8 < 0x38000000ull && !opt(OPT_FULL_STRESS)) {
+  // (the spaced-out input fields of the six-component storage exist in the 16-byte kernels only: not with "general_kernels")
+  if (!slab && d == 3 && (N & 1) == 0 && (size_t)N * 9 * 8 < 0x38000000ull && !opt(OPT_FULL_STRESS) && !opt(OPT_GENERAL_KERNELS)) {
     bool ok = true;
     for (int k = 0; k < d; k++) ok = ok && op->mats[dims[k]].KS >= 16 && (dims[k] & 1) == 0;       // the long-line 16-byte kernel, both tilings
     const int nt_last = op->mats[dims[d - 1]].KS == 16 ? 64 : 32;                                   // lines per tile of the contiguous direction

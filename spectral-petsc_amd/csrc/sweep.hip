@@ -394,9 +394,9 @@ __global__ __launch_bounds__(256) void cheb_sweep_long_kernel(const SweepParams 
 }
 
 // Plain sweeps (IN_PLAIN, STORE / ACC) of long lines are plain strided-batched DGEMMs: Y_o = D X_o per outer block.
-// That is the one place where a library GEMM is the right tool: rocBLAS is looked up at run time (the copy the
-// process already has, e.g. PyTorch's, else the system one) and never linked; without it, or for the gather /
-// flux / scatter modes, cheb_sweep_long_kernel above runs.
+// Behind the options "vendor_gemm" (lines beyond 1024 points) and "long_lines_gemm" / "force_gemm" (A/B routes) they can go
+// to rocBLAS, looked up at run time (the copy the process already has, e.g. PyTorch's, else the system one) and never
+// linked.  By default no vendor GEMM runs: cheb_sweep_long_kernel above takes every line beyond 1024 points.
 namespace {
 struct RocblasApi {
   void *lib = nullptr;
@@ -413,7 +413,6 @@ RocblasApi g_rb;
 
 bool rocblas_ready() {
   std::call_once(g_rb.once, [] {
-    if (opt(OPT_NO_ROCBLAS)) return;                     // "no_rocblas": set before the first long-line launch
     const char *names[] = {"librocblas.so.5", "librocblas.so.4", "librocblas.so"};
     for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // already in the process?
     for (const char *n : names) if (!g_rb.lib) g_rb.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -445,6 +444,9 @@ void *rocblas_handle_for(hipStream_t stream) {
 
 static hipError_t launch_long_gemm(const SweepParams &p, hipStream_t stream, bool *done) {
   *done = false;
+  // No vendor GEMM on a default path: rocBLAS is touched only when an option asks for it ("vendor_gemm": lines beyond 1024
+  // points; "long_lines_gemm" / "force_gemm": the A/B routes of shorter lines)
+  if (!opt(OPT_VENDOR_GEMM) && !opt(OPT_LONG_LINES_GEMM) && !opt(OPT_FORCE_GEMM)) return hipSuccess;
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC) || !p.longD || !rocblas_ready()) return hipSuccess;
   constexpr int OP_N = 111, OP_T = 112;                     // rocblas_operation_none / _transpose
   if (p.out_mode == OUT_ACC && p.acc != p.out) {
@@ -519,14 +521,14 @@ static void sweep_fill(const DiffMat &m, SweepParams &p) {
 
 hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream, bool *done) {
   *done = false;
-  if (n < 2 || n > 9 || opt(OPT_SEPARATE_LAUNCHES)) return hipSuccess;
+  if (n < 2 || n > 9 || opt(OPT_SEPARATE_LAUNCHES) || opt(OPT_GENERAL_KERNELS)) return hipSuccess;
   SweepParams jobs[9];
   for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); if (m[j]->KS == 0) return hipSuccess; }
   return sweep_vec_launch_multi(n, m, jobs, stream, done);
 }
 
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {
-  if (n >= 2 && n <= 9 && !opt(OPT_SEPARATE_LAUNCHES)) {
+  if (n >= 2 && n <= 9 && !opt(OPT_SEPARATE_LAUNCHES) && !opt(OPT_GENERAL_KERNELS)) {      // "general_kernels": EVERY sweep runs the general kernel
     SweepParams jobs[9];
     bool ok = true;
     for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); ok = ok && m[j]->KS != 0; }

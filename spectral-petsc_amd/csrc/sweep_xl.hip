@@ -167,6 +167,7 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_xl_kernel   // (4 waves per
 bool sweep_xl_eligible(const DiffMat &m, const SweepParams &p) {
   if (m.KS != 0 || !m.fragE || !m.fragO || m.xl_ks <= 0 || m.P <= 256 || m.P > 1024) return false;   // (P <= 256 with KS == 0: option force_gemm)
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC) || p.raw || p.in_fblocks || p.qmax || p.in_os) return false;
+  if ((unsigned long long)p.ncols * (unsigned long long)m.P >= 0x100000000ull) return false;   // element offsets are 32-bit in the kernel
   if (p.inner >= 16) return true;
   return p.inner == 1;                          // JFAST needs contiguous lines; other small strides stay with the VALU kernel
 }

@@ -209,6 +209,32 @@ def test_first_call_on_a_non_blocking_stream_while_the_null_stream_is_busy():
     assert np.abs(ref_state[2]).max() > 0 and ref_state[0].min() > 1.0
 
 
+def test_get_state_after_formfunction_still_queued_on_a_non_blocking_stream():
+    """The interior-line FormFunction leaves eta / eta' to be rebuilt from w0 on demand (ell_sync_coeffs, a null-stream kernel).
+    ell_op_get_state must wait for a FormFunction that is still queued on the caller's non-blocking stream BEFORE that rebuild
+    reads w0 (round-3 advisor finding): the side stream is held up by a sleep so that a missing wait shows every time."""
+    import numpy as np
+    import torch
+    dims = (72, 68, 66)                                     # the interior-line path: even extents of 66..256, homogeneous rows, exponent 2
+    op = sp.EllipticOp(dims)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    u = torch.rand(op.global_size, dtype=torch.float64, device="cuda", generator=g) + 0.5
+    r = torch.empty_like(u)
+    op.function(u, None, r, 1.0, 2.0); torch.cuda.synchronize()      # allocate the state; a first, different coefficient state
+    u2 = u * 1.5
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(400_000_000)                      # ~0.2 s: FormFunction below is still queued when get_state is called
+        op.function(u2, None, r, 4.0, 2.0)
+    eta = op.get_state(0); deta = op.get_state(1)           # no synchronisation by the caller
+    torch.cuda.synchronize()
+    interior = np.zeros(dims); interior[1:-1, 1:-1, 1:-1] = u2.cpu().numpy().reshape([n - 2 for n in dims])
+    assert np.allclose(eta.reshape(dims), 1.0 + 4.0 * interior ** 2, rtol=1e-14, atol=0)
+    assert np.allclose(deta.reshape(dims), 2.0 * 4.0 * interior, rtol=1e-14, atol=0)
+    op.destroy()
+
+
 def test_two_host_threads_with_their_own_handles():
     """One handle belongs to one host thread at a time, but two threads may drive two handles at once (ctypes releases the GIL):
     the library's shared state -- lazily read environment switches, the CU-count cache, the timer registry, rocBLAS handles --
@@ -291,6 +317,27 @@ def test_options_and_kernel_families_agree():
     torch.cuda.synchronize()
     assert float((y1 - y0).norm() / y0.norm()) < 1e-13
     st.destroy()
+    # "general_kernels" covers the Stokes launches too (round-3 advisor finding): a handle created and driven with the option set
+    # keeps all nine stress components (the six-component storage feeds spaced-out input fields only the 16-byte kernels
+    # read) and runs every sweep of its multi-job launches on the general kernel; same operator to rounding
+    dims = (68, 66, 66)                                  # even extents above 64: the six-component storage by default
+    g = torch.Generator(device="cuda").manual_seed(13)
+    outs = []
+    for general in (0, 1):
+        sp.set_option("general_kernels", general)
+        try:
+            st = sp.StokesOp(dims); st.set_rheology(1, 1.0, 3.0, 1e-3, 1.0)
+            st.set_dirichlet(np.zeros(st.dirichlet_size)); st.set_force(np.zeros(st.global_size))
+            if not outs:
+                x = torch.randn(st.global_size, dtype=torch.float64, device="cuda", generator=g)
+            f, m = torch.empty_like(x), torch.empty_like(x)
+            st.function(x, f); st.mult(x, m); torch.cuda.synchronize()
+            outs.append((f.clone(), m.clone()))
+            st.destroy()
+        finally:
+            sp.set_option("general_kernels", 0)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert float((a_ - b_).norm() / a_.norm()) < 1e-12
     # the constant-coefficient matvec: one launch of d jobs + a sum in the chain's order against a launch per direction: same bits
     for dims in ((66, 68, 72), (40, 36, 34), (130, 72), (33, 17, 9)):
         op = sp.EllipticOp(dims)
