@@ -403,6 +403,10 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *                            eta' = 0 (linear rheology), instead of -eta/2 (sum_j D_j D_j v + grad div v) (read at create)
  *   poisson_launches      the constant-coefficient MatMult_Elliptic: 0 = by size (one launch of d jobs + a sum below 6 M unknowns,
  *                            a launch per direction above), 1 = always the d-job launch, 2 = always a launch per direction
+ *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
+ *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array
+ *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read
+ *   stokes_skew           1: the work arrays of a Stokes handle start at different offsets (multiples of 4352 B) of their allocations (A/B, read at create)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

@@ -18,8 +18,9 @@
 // writes it straight into the pencil, the final sum reads it straight from the pencil result.  pack and the final sum
 // work run-wise (one workgroup per (plane, peer): a contiguous run on both sides, 16-byte accesses).
 //
-// The sum runs in the serial order k = 0, 1, 2 (elliptic.C:331-334), so every G reproduces the G = 1 vector to the
-// last bits of the per-line products.  Two exchanges per matvec; the pencil side of the forward exchange and the
+// With option "dist_exact_order" the sum runs in the serial order k = 0, 1, 2 (elliptic.C:331-334), so every G reproduces
+// the G = 1 vector to the last bits of the per-line products; by default the local terms are accumulated by the sweeps
+// (one array less to write and read) and the result equals the serial one to rounding.  Two exchanges per matvec; the pencil side of the forward exchange and the
 // slab-row side of the backward one need no (un)packing.
 //
 // Transport.  chebhip_dist_use_rccl: grouped ncclSend / ncclRecv (one RCCL launch per exchange, G-1 direct xGMI
@@ -58,8 +59,10 @@ __global__ __launch_bounds__(256) void k_pack(Split sp, long m0, long M1, long R
   const long w = sp.c1[s + 1] - sp.c1[s], len = w * R;
   const double *src = slab + (i0 * M1 + sp.c1[s]) * R;
   double *dst = (s == own) ? own_ptr + i0 * len : buf + m0 * sp.c1[s] * R + i0 * len;
-  if (V2) { for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) ((double2 *)dst)[t] = ((const double2 *)src)[t]; }
-  else { for (long t = threadIdx.x; t < len; t += blockDim.x) dst[t] = src[t]; }
+  // gridDim.y workgroups share a run (at G = 2 a run is 32 k values: one workgroup per run left the chip three quarters idle)
+  const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (V2) { for (long t = t0; t < (len >> 1); t += T) ((double2 *)dst)[t] = ((const double2 *)src)[t]; }
+  else { for (long t = t0; t < len; t += T) dst[t] = src[t]; }
 }
 // V = ((T + A_1) + A_2) + ...   T in exchange order: the serial accumulation order k = 0, 1, 2 (elliptic.C:331-334)
 template <bool V2>
@@ -68,14 +71,15 @@ __global__ __launch_bounds__(256) void k_combine(Split sp, long m0, long M1, lon
   const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G;
   const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = (i0 * M1 + sp.c1[s]) * R;
   const double *src = (s == own) ? own_ptr + i0 * len : buf + m0 * sp.c1[s] * R + i0 * len;
+  const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
   if (V2) {
-    for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) {
+    for (long t = t0; t < (len >> 1); t += T) {
       double2 v = ((const double2 *)src)[t];
       for (int k = 0; k < A.n; k++) { const double2 a = ((const double2 *)(A.p[k] + e0))[t]; v.x = v.x + a.x; v.y = v.y + a.y; }
       ((double2 *)(out + e0))[t] = v;
     }
   } else {
-    for (long t = threadIdx.x; t < len; t += blockDim.x) {
+    for (long t = t0; t < len; t += T) {
       double v = src[t];
       for (int k = 0; k < A.n; k++) v = v + A.p[k][e0 + t];
       out[e0 + t] = v;
@@ -125,7 +129,9 @@ extern "C" int chebhip_dist_create(int d, const int *dims, int nranks, int rank,
   *out = nullptr;
   if (!dims || d < 2 || d > 10) return chebhip_fail(CHEBHIP_ERR_DIMS, "slab partitioning needs 2 <= d <= 10");
   if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return chebhip_fail(CHEBHIP_ERR_ARG, "rank %d of %d", rank, nranks);
-  for (int k = 0; k < d; k++) if (dims[k] < 3 || dims[k] > 258) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d must be in 3..258", k, dims[k]);
+  // (3..256: what the interior-layout plans take, cheb_plan_create_trimmed -- the matrix L = (D D)[1..n-1, 1..n-1] lives in the
+  // register file of a workgroup; longer lines have no slab driver)
+  for (int k = 0; k < d; k++) if (dims[k] < 3 || dims[k] > 256) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d must be in 3..256", k, dims[k]);
   if (dims[0] - 2 < nranks || dims[1] - 2 < nranks)
     return chebhip_fail(CHEBHIP_ERR_SIZE, "every rank needs at least one interior plane along dimensions 0 and 1");
   chebhip_dist *D = new (std::nothrow) chebhip_dist;
@@ -211,8 +217,15 @@ extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, vo
   // side stream: the local directions, each into its own array (they overlap both exchanges); U is ready when the
   // caller's stream gets here
   if (!one_stream) { DHIPCHK(hipEventRecord(D->ev_in, st)); DHIPCHK(hipStreamWaitEvent(side, D->ev_in, 0)); }
+  // "dist_exact_order" = 0 (default): the local terms are summed by the sweeps, A_1 = -L_1 U (STORE), A_1 -= L_k U (ACC): the
+  // final sum reads T and ONE array, V = T + (A_1 + A_2 ..) -- the serial vector to rounding (north_star 1e-10);
+  // 1: every term in an array of its own and V = ((T + A_1) + A_2) in the order of elliptic.C:331-334 -- the serial bits.
+  const bool exact = chebhip::opt(chebhip::OPT_DIST_EXACT_ORDER) != 0;
   int rc = 0;
-  for (int k = 1; k < d && !rc; k++) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[k - 1], side);
+  for (int k = 1; k < d && !rc; k++) {
+    if (exact || k == 1) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[exact ? k - 1 : 0], side);
+    else rc = cheb_apply_lap1d(D->slab_plan[k], U, D->A[0], -1.0, D->A[0], side);
+  }
   hipError_t e1 = one_stream ? hipSuccess : hipEventRecord(D->ev_out, side);
   // caller's stream: the exchange chain.  With a chebhip_exchange_fn (the older callback contract moves every block, the
   // own one included) everything goes through the buffers; otherwise the own block bypasses them.
@@ -222,8 +235,12 @@ extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, vo
   // 16-byte accesses: every run (c1[s+1] - c1[s]) R long starting at (i0 M1 + c1[s]) R must be even-aligned
   bool v2 = ((R & 1) == 0 || ((M1 & 1) == 0)) && (((size_t)U | (size_t)V) & 15) == 0;
   if (v2 && (R & 1)) for (int s = 0; s <= D->G; s++) v2 = v2 && (D->s1[s] & 1) == 0;
-  const unsigned grid = (unsigned)(m0 * D->G);
-  if (!rc && grid) {
+  const unsigned grid1 = (unsigned)(m0 * D->G);
+  // workgroups per run: about 2048 values (1024 16-byte pieces) per workgroup pass, at most 64
+  unsigned gy = 1;
+  { long wmax = 0; for (int s = 0; s < D->G; s++) wmax = D->m1[s] > wmax ? D->m1[s] : wmax; const long len = wmax * R; gy = (unsigned)((len + 2047) / 2048); if (gy < 1) gy = 1; if (gy > 64) gy = 64; }
+  const dim3 grid(grid1, gy);
+  if (!rc && grid1) {
     if (v2) hipLaunchKernelGGL((k_pack<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, D->sendbuf, own, own_in);
     else hipLaunchKernelGGL((k_pack<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, D->sendbuf, own, own_in);
     if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pack launch failed");
@@ -233,10 +250,10 @@ extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, vo
   if (!rc) rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), own, st);           // pencil rows -> slab blocks
   // the caller's stream is rejoined with the side stream on every path, errors included
   hipError_t e2 = one_stream ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
-  if (rc) return rc;
+  if (rc) { chebhip::comm_abort(D->comm); return rc; }     // thread ranks waiting for this one fail at once instead of timing out
   if (e1 != hipSuccess || e2 != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream join failed");
-  APtrs A; A.n = d - 1; for (int k = 0; k < 9; k++) A.p[k] = k < d - 1 ? D->A[k] : nullptr;
-  if (grid) {
+  APtrs A; A.n = exact ? d - 1 : 1; for (int k = 0; k < 9; k++) A.p[k] = k < A.n ? D->A[k] : nullptr;
+  if (grid1) {
     if (v2) hipLaunchKernelGGL((k_combine<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, own, own_out, A, V);
     else hipLaunchKernelGGL((k_combine<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, own, own_out, A, V);
   }

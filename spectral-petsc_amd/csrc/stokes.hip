@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -77,6 +78,38 @@ __global__ __launch_bounds__(256) void k_st_local4(long N, const int *__restrict
       xL[N + l] = in ? a[u].y : (dirloc ? dirloc[N + l] : 0.0);
       xL[2 * N + l] = in ? b[u].x : (dirloc ? dirloc[2 * N + l] : 0.0);
       pL[l] = in ? b[u].y : 0.0;
+    }
+  }
+}
+
+// ... and on node PAIRS (N even): the two nodes (l, l+1) of a pair are neighbours in every local field, so each field
+// leaves as one 16-byte store per pair instead of two 8-byte ones (a CU's store path moves 8-byte accesses at ~0.6x the
+// rate of 16-byte ones, sweep_vec.hip); UN pairs in flight per thread.
+template <int UN>
+__global__ __launch_bounds__(256) void k_st_local4p(long N, const int *__restrict__ ixL, const double *__restrict__ src,
+                                                    const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL) {
+  const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
+  for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
+    int2 n[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    double2 a[UN][2], b[UN][2];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const double2 *s0 = (const double2 *)(src + 4L * (n[u].x >= 0 ? n[u].x : 0)), *s1 = (const double2 *)(src + 4L * (n[u].y >= 0 ? n[u].y : 0));
+      a[u][0] = s0[0]; b[u][0] = s0[1]; a[u][1] = s1[0]; b[u][1] = s1[1];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long t = t0 + u * T;
+      if (t >= half) continue;
+      const bool i0 = n[u].x >= 0, i1 = n[u].y >= 0;
+      double2 d0 = make_double2(0.0, 0.0), d1 = d0, d2v = d0;
+      if (dirloc && !(i0 && i1)) { d0 = ((const double2 *)dirloc)[t]; d1 = ((const double2 *)(dirloc + N))[t]; d2v = ((const double2 *)(dirloc + 2 * N))[t]; }
+      ((double2 *)xL)[t] = make_double2(i0 ? a[u][0].x : d0.x, i1 ? a[u][1].x : d0.y);
+      ((double2 *)(xL + N))[t] = make_double2(i0 ? a[u][0].y : d1.x, i1 ? a[u][1].y : d1.y);
+      ((double2 *)(xL + 2 * N))[t] = make_double2(i0 ? b[u][0].x : d2v.x, i1 ? b[u][1].x : d2v.y);
+      ((double2 *)pL)[t] = make_double2(i0 ? b[u][0].y : 0.0, i1 ? b[u][1].y : 0.0);
     }
   }
 }
@@ -381,6 +414,54 @@ __global__ __launch_bounds__(256) void k_st_out4(long N, const int *__restrict__
   }
 }
 
+// ... and on node PAIRS (N even): every term array is read 16 bytes at a time.  Same sums in the same order.
+template <int UN>
+__global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict__ ixL, const double *__restrict__ yL,
+                                                  const double *__restrict__ yL1, const double *__restrict__ yL2,
+                                                  const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
+                                                  const double *__restrict__ p2, const double *__restrict__ force, double *__restrict__ out,
+                                                  const double *__restrict__ G) {
+  const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
+  const double *gp[3] = {gp0, gp1, gp2};
+  for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
+    int2 n[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    double2 v[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long t = (t0 + u * T < half) ? t0 + u * T : 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        double2 s = ((const double2 *)(yL + k * N))[t];
+        const double2 b = ((const double2 *)(yL1 + k * N))[t], c = ((const double2 *)(yL2 + k * N))[t];
+        s.x = s.x + b.x; s.y = s.y + b.y;
+        s.x = s.x + c.x; s.y = s.y + c.y;
+        if (G) { const double2 g = ((const double2 *)(G + k * N))[t]; s.x = s.x + g.x; s.y = s.y + g.y; }
+        const double2 q = ((const double2 *)gp[k])[t];
+        s.x += 1.0 * q.x; s.y += 1.0 * q.y;
+        v[u][k] = s;
+      }
+      v[u][3] = ((const double2 *)p2)[t];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int nn = h ? n[u].y : n[u].x;
+        if (nn < 0) continue;
+        double w0 = h ? v[u][0].y : v[u][0].x, w1 = h ? v[u][1].y : v[u][1].x, w2 = h ? v[u][2].y : v[u][2].x, w3 = h ? v[u][3].y : v[u][3].x;
+        double2 *o2 = (double2 *)(out + 4L * nn);
+        if (force) {
+          const double2 f0 = ((const double2 *)(force + 4L * nn))[0], f1 = ((const double2 *)(force + 4L * nn))[1];
+          w0 += -1.0 * f0.x; w1 += -1.0 * f0.y; w2 += -1.0 * f1.x; w3 += -1.0 * f1.y;
+        }
+        o2[0] = make_double2(w0, w1); o2[1] = make_double2(w2, w3);
+      }
+    }
+  }
+}
+
 __global__ void k_st_fill(long n, double v, double *__restrict__ a) { GS_LOOP(i, n) a[i] = v; }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,6 +479,11 @@ struct stokes_op {
   std::vector<unsigned> innerP, ncolsP, innerV, ncolsV;      // DP[i] / DV[i] geometry
   int *ixL = nullptr;
   double *xL = nullptr, *yL = nullptr;                       // workV[0], workV[1]
+  // StokesFunction with the linear rheology on the uniform-viscosity route (st_viscous_uniform) does not run the node loop
+  // that would leave the symmetrised strain as state (stokes.C:722): it keeps ITS local vector (velocity with Dirichlet
+  // values) in xF instead -- the later callbacks overwrite xL -- and whoever reads the strain (the state accessors, the VTK
+  // writer, a Jacobian apply after eta' has been set by hand) first rebuilds it from xF: st_sync_strain.
+  double *xF = nullptr; bool strain_stale = false;
   double *yLx[3] = {nullptr, nullptr, nullptr};              // serial handles: terms 1, 2 of the stress divergence (summed in the final scatter)
   double *V[3] = {nullptr, nullptr, nullptr};                // workV[2..]
   // d = 3 serial handles on lines of more than 64 points: the stress is symmetric, so the node loops write its 6 distinct
@@ -436,7 +522,25 @@ struct stokes_op {
   int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
 };
 
-static int st_alloc(double **p, size_t n) { SHIPCHK(hipMalloc((void **)p, n * sizeof(double))); SHIPCHK(hipMemset(*p, 0, n * sizeof(double))); return 0; }
+// Work arrays of one handle.  Option "stokes_skew" (A/B, read at create): every array starts a different multiple of 4352 bytes
+// (4 KiB + 256 B) into its allocation, so that the same node of the ~30 arrays a node loop streams does not sit at the same
+// offset of a 16-MiB-aligned allocation in each of them (HBM channel / bank interleave).  g_raw: skewed pointer -> allocation.
+static std::map<const void *, void *> g_raw; static std::mutex g_raw_mu; static int g_skew_next = 0;
+static int st_alloc(double **p, size_t n) {
+  size_t skew = 0;
+  if (opt(OPT_STOKES_SKEW)) { std::lock_guard<std::mutex> lk(g_raw_mu); skew = (size_t)(g_skew_next++ % 29) * 4352; }
+  char *raw = nullptr;
+  SHIPCHK(hipMalloc((void **)&raw, n * sizeof(double) + skew)); SHIPCHK(hipMemset(raw, 0, n * sizeof(double) + skew));
+  *p = (double *)(raw + skew);
+  if (skew) { std::lock_guard<std::mutex> lk(g_raw_mu); g_raw[*p] = raw; }
+  return 0;
+}
+static void st_free(double *p) {
+  if (!p) return;
+  void *raw = p;
+  { std::lock_guard<std::mutex> lk(g_raw_mu); auto it = g_raw.find(p); if (it != g_raw.end()) { raw = it->second; g_raw.erase(it); } }
+  (void)hipFree(raw);
+}
 
 extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
@@ -444,10 +548,9 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   for (auto &kv : op->matsP) diffmat_destroy(&kv.second);
   for (auto &kv : op->matsDD) diffmat_destroy(&kv.second);
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
-                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T};
-  for (double *p : all) if (p) (void)hipFree(p);
-  if (op->sv0) (void)hipFree(op->sv0);
-  if (op->sv1) (void)hipFree(op->sv1);
+                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T, op->xF};
+  for (double *p : all) st_free(p);
+  st_free(op->sv0); st_free(op->sv1);
   if (op->inner) chebhip_fgmres_destroy(op->inner);
   if (op->aux) (void)hipStreamDestroy(op->aux);
   if (op->ev_fork) (void)hipEventDestroy(op->ev_fork);
@@ -524,6 +627,7 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
   }
   const size_t nd = (size_t)N * d;
   OPRC(st_alloc(&op->xL, nd)); OPRC(st_alloc(&op->yL, nd));
+  if (op->uniform_ok) OPRC(st_alloc(&op->xF, nd));
   if (!slab) for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
   for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
   OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
@@ -657,7 +761,10 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
   const int d = op->d;
   // (k_st_local4 loads node 0 of src for boundary nodes too: not for a slab without unknowns, whose src may be NULL)
   if (d == 3 && gs == 4 && go == 3 && xL && pL && op->I > 0 && st_al16(src)) {
-    hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
+    if ((op->N & 1) == 0 && st_al16(xL) && st_al16(pL) && (!dirloc || st_al16(dirloc)))
+      hipLaunchKernelGGL((k_st_local4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
+    else
+      hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
     return;
   }
   ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL);
@@ -669,8 +776,12 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
   const int d = op->d;
   if (!y0) { y0 = op->yL; y1 = op->yLx[1]; y2 = op->yLx[2]; }
   if (d == 3 && y1 && y2 && st_al16(out) && (!force || st_al16(force))) {
-    hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
-                       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
+    if ((op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G)))      // (the handle's own arrays: always)
+      hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
+                         (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
+    else
+      hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
+                         (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
     return;
   }
   ST_D(k_st_out, d + 1, (const int *)op->ixL, y0, y1, y2,
@@ -757,9 +868,10 @@ __global__ void k_st_sum_fields(long N, int d, const double *__restrict__ t, dou
   GS_LOOP(i, N) { double v = t[i] + t[N + i]; if (d == 3) v = v + t[2 * N + i]; out[i] = v; }
 }
 static inline bool st_uniform(const stokes_op *op) { return op->uniform_ok && op->eta_uniform && !op->deta_nonzero; }
-static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st) {
+static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st, const double *xloc = nullptr, double eta_value = 0.0) {
   const int d = op->d; const long N = op->N;
-  const double a = -0.5 * op->eta_value;
+  if (!xloc) { xloc = op->xL; eta_value = op->eta_value; }             // StokesFunction: its own local vector (xF), eta = 1
+  const double a = -0.5 * eta_value;
   const DiffMat *m[9]; SweepParams sp[9];
   int n = 0;
   auto job = [&](const DiffMat &mat, bool vec, int k, const double *in, double *out, double alpha) {
@@ -768,14 +880,37 @@ static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st)
     sp[n].in0 = in; sp[n].in_mode = IN_PLAIN; sp[n].out = out; sp[n].out_mode = OUT_STORE; sp[n].alpha = alpha;
     m[n++] = &mat;
   };
-  for (int k = 0; k < d; k++) job(op->matsDD[op->dims[k]], true, k, op->xL, op->V[k], a);
-  for (int k = 0; k < d; k++) job(op->mats[op->dims[k]], false, k, op->xL + (size_t)k * N, op->yL + (size_t)k * N, 1.0);
+  for (int k = 0; k < d; k++) job(op->matsDD[op->dims[k]], true, k, xloc, op->V[k], a);
+  for (int k = 0; k < d; k++) job(op->mats[op->dims[k]], false, k, xloc + (size_t)k * N, op->yL + (size_t)k * N, 1.0);
   if (with_pressure) for (int k = 0; k < d; k++) job(op->matsP[op->dims[k]], false, k, op->pL, op->gp[k], 1.0);
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
   hipLaunchKernelGGL(k_st_sum_fields, dim3(sgrid(N)), dim3(256), 0, st, N, d, (const double *)op->yL, op->p2);
   n = 0;
   for (int c = 0; c < d; c++) job(op->mats[op->dims[c]], false, c, op->p2, op->yLx[1] + (size_t)c * N, a);
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  return 0;
+}
+
+// The strain state of a StokesFunction that took the uniform-viscosity route (stokes_op::xF), rebuilt on demand:
+// strain[j] = DV[j] xF (stokes.C:701), symmetrised per node (:711-716, :722).  eta = 1, eta' = 0 were written by that call.
+template <int D>
+__global__ void k_st_symmetrise(long N, double *__restrict__ S0, double *__restrict__ S1, double *__restrict__ S2) {
+  double *S[3] = {S0, S1, S2};
+  GS_LOOP(i, N) {
+#pragma unroll
+    for (int j = 0; j < D; j++)
+#pragma unroll
+      for (int k = j + 1; k < D; k++) { const double s = 0.5 * (S[j][k * N + i] + S[k][j * N + i]); S[j][k * N + i] = s; S[k][j * N + i] = s; }
+  }
+}
+static int st_sync_strain(stokes_op *op, hipStream_t st) {
+  if (!op->strain_stale) return 0;
+  const double *x[3] = {op->xF, op->xF, op->xF};
+  int rc = sweeps_multi(op, true, 0, x, op->strain, 1.0, st); if (rc) return rc;
+  const int d = op->d;
+  ST_D(k_st_symmetrise, op->strain[0], op->strain[1], op->strain[2]);
+  SHIPCHK(hipGetLastError());
+  op->strain_stale = false;
   return 0;
 }
 
@@ -940,6 +1075,21 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_FUNCTION, stream);
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
+  if (op->rh_kind == 0 && op->uniform_ok) {
+    // Linear rheology (stokes.C:1920-1926: eta = 1, eta' = 0): the residual's viscous part is -1/2 (sum_j D_j D_j v + grad div v)
+    // of the velocity WITH its Dirichlet values (sweeps along different directions commute on the full grid), so the node
+    // loop and the second set of d^2 sweeps are not needed (st_viscous_uniform); the symmetrised strain it would leave as
+    // state is rebuilt from xF by whoever asks for it (st_sync_strain).  Option "general_viscous" keeps the general route.
+    st_local(op, d + 1, d, xG, op->dirloc, op->xF, op->pL, st);
+    if (!(op->eta_uniform && op->eta_value == 1.0)) hipLaunchKernelGGL(k_st_fill, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 1.0, op->eta);
+    if (op->deta_nonzero) hipLaunchKernelGGL(k_st_fill, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 0.0, op->deta);
+    op->eta_uniform = true; op->eta_value = 1.0; op->deta_nonzero = false; op->strain_stale = true;
+    int rc = st_viscous_uniform(op, true, st, op->xF, 1.0); if (rc) return rc;
+    st_out_full(op, op->force, yG, st, op->V[0], op->V[1], op->V[2], op->yLx[1]);                                                  // :750-756
+    SHIPCHK(hipGetLastError());
+    return 0;
+  }
+  op->strain_stale = false;                               // the node loop below leaves the strain as state
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
   if (st_one_launch_gradients(op)) {
@@ -1058,6 +1208,7 @@ extern "C" int stokes_op_get_state(stokes_op *op, int which, double *dst) {
   ARGCHK(op && dst);
   double *p; size_t n; bool soa; int rc = st_state_ptr(op, which, &p, &n, &soa); if (rc) return rc;
   SHIPCHK(hipDeviceSynchronize());
+  if (soa && op->strain_stale) { if ((rc = st_sync_strain(op, nullptr))) return rc; SHIPCHK(hipStreamSynchronize(nullptr)); }
   if (!soa) { SHIPCHK(hipMemcpy(dst, p, n * sizeof(double), hipMemcpyDeviceToHost)); return 0; }
   std::vector<double> tmp(n);
   const size_t N = (size_t)op->N; const int d = op->d;
@@ -1075,6 +1226,8 @@ extern "C" int stokes_op_set_state(stokes_op *op, int which, const double *src) 
   ARGCHK(op && src);
   double *p; size_t n; bool soa; int rc = st_state_ptr(op, which, &p, &n, &soa); if (rc) return rc;
   SHIPCHK(hipDeviceSynchronize());
+  // a state set by hand starts from the complete state of the last StokesFunction (an eta' given here will meet the strain)
+  if (op->strain_stale) { if ((rc = st_sync_strain(op, nullptr))) return rc; SHIPCHK(hipStreamSynchronize(nullptr)); }
   if (!soa) {
     SHIPCHK(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
     if (which == 1) { bool nz = false; for (size_t i = 0; i < n && !nz; i++) nz = (src[i] != 0.0); op->deta_nonzero = nz; }
@@ -1129,6 +1282,7 @@ extern "C" int stokes_op_write_vtk(stokes_op *op, const double *state_dev, const
   if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "stokes_op_write_vtk: serial handles only");
   const int d = op->d; const long N = op->N;
   SHIPCHK(hipDeviceSynchronize());
+  { int rc = st_sync_strain(op, nullptr); if (rc) return rc; }
   std::vector<double> v(N * d), p(N), fv(N * d, 0.0), fp(N, 0.0), eta(N), deta(N), strain((size_t)d * N * d);
   auto fetch = [&](const double *src, std::vector<double> &vel, std::vector<double> &pre) -> int {
     st_local(op, d + 1, d, src, op->dirloc, op->xL, op->pL, nullptr);                 // scatters + dirichlet (:1827-1838)

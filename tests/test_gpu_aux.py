@@ -430,6 +430,54 @@ def test_uniform_viscosity_jacobian_path(dims):
         op.destroy()
 
 
+@pytest.mark.parametrize("dims", [(48, 40, 36), (30, 41), (66, 68, 72), (33, 17, 9)], ids=lambda d: "x".join(map(str, d)))
+def test_linear_stokes_function_on_the_uniform_route(dims):
+    """StokesFunction with the linear rheology (stokes.C:1920-1926) runs -1/2 (sum_j D_j D_j v + grad div v) on the velocity with
+    its Dirichlet values instead of the node loop; the symmetrised strain it would leave as state (stokes.C:722) is rebuilt
+    on demand from the handle's copy of that velocity.  Against the general route (option general_viscous), against the
+    oracle, with the state read back after later callbacks have overwritten the work vectors, and with an eta' set by
+    hand afterwards (the Jacobian apply must then meet the strain of THAT residual)."""
+    d = len(dims)
+    rng = np.random.default_rng(SEED + 7)
+    ops = []
+    for general in (0, 1):
+        sp.set_option("general_viscous", general)
+        try:
+            ops.append(sp.StokesOp(dims))
+        finally:
+            sp.set_option("general_viscous", 0)
+    x = rng.standard_normal(ops[0].global_size); x2 = rng.standard_normal(ops[0].global_size)
+    dv = rng.standard_normal(ops[0].dirichlet_size); f = rng.standard_normal(ops[0].global_size)
+    N = ops[0].local_nodes
+    ref_y, ref_eta, ref_deta, ref_strain = orc.stokes_function(dims, x, dv, f, mode=orc.DIRECT)
+    deta_hand = rng.uniform(0.1, 0.5, N)
+    ref_j = orc.stokes_mult(dims, x2, eta=ref_eta, deta=deta_hand, strain=ref_strain, mode=orc.DIRECT)
+    outs = []
+    for op in ops:
+        op.set_dirichlet(dv); op.set_force(f)
+        op.set_rheology(1, 1.0, 3.0, 1e-3, 1.0)                # a power-law state first: eta, eta' must be reset by the linear call
+        y = torch.empty(op.global_size, dtype=torch.float64, device="cuda"); m = torch.empty_like(y)
+        op.function(dev(x2), y)
+        op.set_rheology(0, 1.0, 1.0, 1.0, 1.0)
+        op.function(dev(x), y)
+        op.mult(dev(x2), m)                                    # overwrites the work vectors of the callbacks
+        torch.cuda.synchronize()
+        y = y.cpu().numpy()
+        assert relerr(y, ref_y) < 1e-10
+        assert np.array_equal(op.get_state(0), np.ones(N)) and np.array_equal(op.get_state(1), np.zeros(N))
+        for j in range(d):
+            assert relerr(op.get_state(2 + j), ref_strain[j]) < 1e-10
+        assert relerr(m.cpu().numpy(), orc.stokes_mult(dims, x2, mode=orc.DIRECT)) < 1e-10
+        # a fresh residual, then eta' by hand: the Jacobian apply needs the strain of this residual
+        op.function(dev(x), torch.empty_like(m))
+        op.set_state(1, deta_hand)
+        op.mult(dev(x2), m); torch.cuda.synchronize()
+        assert relerr(m.cpu().numpy(), ref_j) < 1e-10
+        outs.append(y)
+        op.destroy()
+    assert relerr(outs[0], outs[1]) < 1e-12
+
+
 def test_cheb_apply_on_an_array_of_a_gigabyte():
     """Arrays of 0.94 GB and more are beyond the 32-bit buffer offsets of the long-line kernel: the general kernel takes
     them (sweep_vec_eligible).  Checked against the same plan applied to the two halves of the tensor (dimension 0 is not
