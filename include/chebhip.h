@@ -294,14 +294,20 @@ int chebhip_dist_use_comm(chebhip_dist *D, chebhip_comm *comm);
 /* serial reference (stokes.C:121 VecCreateSeq).                               */
 /* ------------------------------------------------------------------------- */
 typedef struct chebhip_dist_stokes chebhip_dist_stokes;
+typedef struct chebhip_fdpc chebhip_fdpc;       /* the finite-difference preconditioner, declared below */
 int chebhip_dist_stokes_create(int d, const int *dims, chebhip_comm *comm, chebhip_dist_stokes **out);   /* comm NULL: one rank */
 int chebhip_dist_stokes_destroy(chebhip_dist_stokes *D);
 stokes_op *chebhip_dist_stokes_op(chebhip_dist_stokes *D);        /* owned by D; StokesMatMultSchur's built-in inner solve all-reduces through comm */
+/* The preconditioners on slabs (round 4; SURVEY 8f.1 / 8f.3 over ranks): MatVVPC (stokes.C:1160-1241) / FormJacobian's matrix
+ * (elliptic.C:537-590) for the slab's unknowns -- chebhip_fdpc handles in slab mode, owned by the driver, line transforms along
+ * dimension 0 on pencils through the driver's communicator.  Pass them to chebhip_fdpc_apply / stokes_saddle_create_slab. */
+int chebhip_dist_stokes_pc(chebhip_dist_stokes *D, chebhip_fdpc **out);
 int chebhip_dist_stokes_ranges(const chebhip_dist_stokes *D, long *ranges4);
 typedef struct chebhip_dist_ell chebhip_dist_ell;
 int chebhip_dist_ell_create(int d, const int *dims, chebhip_comm *comm, chebhip_dist_ell **out);
 int chebhip_dist_ell_destroy(chebhip_dist_ell *D);
 ell_op *chebhip_dist_ell_op(chebhip_dist_ell *D);
+int chebhip_dist_ell_pc(chebhip_dist_ell *D, chebhip_fdpc **out);
 int chebhip_dist_ell_ranges(const chebhip_dist_ell *D, long *ranges4);
 
 /* ------------------------------------------------------------------------- */
@@ -337,10 +343,18 @@ int chebhip_fgmres_reason(const chebhip_fgmres *k);
 /* the sweep kernel), used alone or inside `sweeps` inner GMRES steps on P.      */
 /* Vectors: the operator's global vectors (scalar: g; Stokes: velocity gv).     */
 /* ------------------------------------------------------------------------- */
-typedef struct chebhip_fdpc chebhip_fdpc;
 int ell_pc_create(ell_op *op, chebhip_fdpc **out);          /* MatCreateSeqAIJ(.., 1+2d, ..) + PCILU, elliptic.C:163,184 */
 int stokes_pc_create(stokes_op *op, chebhip_fdpc **out);    /* MatVVPC, stokes.C:1160-1241 (-pcvel 0)                    */
 int chebhip_fdpc_destroy(chebhip_fdpc *pc);
+/* Slab mode (the serial reference has no counterpart): the handle preconditions the unknowns of ONE slab of planes of
+ * dimension 0; its approximate solve is z = P_1^-1 (r / eta) by fast diagonalisation (sweeps = 0), whose line transforms along
+ * dimension 0 run on pencils: `dim0` (collective over the ranks) moves `nfields` stacked interior fields of the slab at in_dev to
+ * pencils, applies chebhip_fdpc_pencil_transform and moves the result back to out_dev.  Made by chebhip_dist_stokes_pc_create /
+ * chebhip_dist_ell_pc_create (csrc/slabx.hip), which supply the callback; i0_offset = interior planes owned by lower ranks. */
+typedef int (*chebhip_fdpc_dim0_fn)(void *ctx, int backward, int nfields, const double *in_dev, double *out_dev, void *stream);
+int stokes_pc_create_slab(stokes_op *slab_op, long i0_offset, chebhip_fdpc_dim0_fn dim0, void *ctx, chebhip_fdpc **out);
+int ell_pc_create_slab(ell_op *slab_op, long i0_offset, chebhip_fdpc_dim0_fn dim0, void *ctx, chebhip_fdpc **out);
+int chebhip_fdpc_pencil_transform(chebhip_fdpc *pc, int backward, int nfields, long ncol, const double *in_dev, double *out_dev, void *stream);
 /* FormJacobian / StokesPCSetUp0: (re)assemble P from the operator's current eta, deta (and gradu): call after
  * ell_op_function / stokes_op_function or set_state.  Done implicitly on first use. */
 int chebhip_fdpc_update(chebhip_fdpc *pc, void *stream);
@@ -357,6 +371,10 @@ int chebhip_fdpc_apply(void *pc, const double *r_dev, double *z_dev, void *strea
 /* ------------------------------------------------------------------------- */
 typedef struct stokes_saddle stokes_saddle;
 int stokes_saddle_create(stokes_op *op, stokes_saddle **out);
+/* On slabs: slab_op = chebhip_dist_stokes_op(D), slab_pc = chebhip_dist_stokes_pc(D) (borrowed), reduce / reduce_ctx =
+ * chebhip_comm_reduce with the driver's communicator.  The inner solves and the removal of the constant pressure mode complete
+ * their sums over the ranks; stokes_saddle_apply is then collective.  The serial reference has no counterpart. */
+int stokes_saddle_create_slab(stokes_op *slab_op, chebhip_fdpc *slab_pc, chebhip_reduce_fn reduce, void *reduce_ctx, stokes_saddle **out);
 int stokes_saddle_destroy(stokes_saddle *s);
 /* -pc_saddle_type (stokes.C:177-187): 0 block LU, 1 upper triangular, 2 block diagonal, 3 lower triangular. */
 int stokes_saddle_set_type(stokes_saddle *s, int type);
@@ -406,7 +424,6 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
  *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array
  *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read
- *   stokes_skew           1: the work arrays of a Stokes handle start at different offsets (multiples of 4352 B) of their allocations (A/B, read at create)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

@@ -56,6 +56,8 @@ ABI_SYMBOLS = [
     "chebhip_comm_reduce", "chebhip_dist_use_comm",
     "chebhip_dist_stokes_create", "chebhip_dist_stokes_destroy", "chebhip_dist_stokes_op", "chebhip_dist_stokes_ranges",
     "chebhip_dist_ell_create", "chebhip_dist_ell_destroy", "chebhip_dist_ell_op", "chebhip_dist_ell_ranges",
+    "stokes_pc_create_slab", "ell_pc_create_slab", "chebhip_fdpc_pencil_transform", "chebhip_dist_stokes_pc", "chebhip_dist_ell_pc",
+    "stokes_saddle_create_slab",
 ]
 
 
@@ -196,6 +198,10 @@ def lib():
             getattr(L, "chebhip_dist_%s_op" % nm).argtypes = [vp]
             getattr(L, "chebhip_dist_%s_op" % nm).restype = vp
             getattr(L, "chebhip_dist_%s_ranges" % nm).argtypes = [vp, lp]
+            getattr(L, "chebhip_dist_%s_pc" % nm).argtypes = [vp, C.POINTER(vp)]
+            getattr(L, "%s_pc_create_slab" % nm).argtypes = [vp, C.c_long, vp, vp, C.POINTER(vp)]
+        L.chebhip_fdpc_pencil_transform.argtypes = [vp, C.c_int, C.c_int, C.c_long, vp, vp, vp]
+        L.stokes_saddle_create_slab.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         _lib = L
     return _lib
 
@@ -618,10 +624,15 @@ class FdPc:
     `apply` is an approximate solve with P (fast diagonalisation + `sweeps` defect corrections); pass the object as
     the `M` of Fgmres.solve."""
 
-    def __init__(self, op, sweeps=1):
-        h = C.c_void_p()
+    def __init__(self, op, sweeps=1, handle=None):
+        """handle: a slab-mode handle owned by a slab driver (dist.py: DistStokesC.pc / DistEllipticC.pc) -- borrowed."""
         kind = type(op).__name__
-        _chk((lib().ell_pc_create if kind == "EllipticOp" else lib().stokes_pc_create)(op._h, C.byref(h)))
+        self._owned = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            _chk((lib().ell_pc_create if kind == "EllipticOp" else lib().stokes_pc_create)(op._h, C.byref(h)))
+        else:
+            h = handle
         self._h = h
         self._op = op                     # the handle reads the operator's state: keep it alive
         self.n = op.global_size if kind == "EllipticOp" else op.velocity_size
@@ -641,7 +652,8 @@ class FdPc:
 
     def destroy(self):
         if getattr(self, "_h", None):
-            lib().chebhip_fdpc_destroy(self._h)
+            if self._owned:
+                lib().chebhip_fdpc_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -656,10 +668,17 @@ class StokesSaddlePc:
     saddle-point system, with the inner solves KSPVelocity, KSPSchur, KSPSchurVelocity (stokes.C:328-341).
     Pass the object as the `M` of Fgmres.solve around StokesOp.mult."""
 
-    def __init__(self, op, saddle_type=0, vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, schur_jacobi=True):
-        """schur_jacobi: KSPSchur's PCJACOBI with 1/eta on the diagonal (stokes.C:330-331, 538-553); False = -schur_pc_type none."""
+    def __init__(self, op, saddle_type=0, vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, schur_jacobi=True, slab=None):
+        """schur_jacobi: KSPSchur's PCJACOBI with 1/eta on the diagonal (stokes.C:330-331, 538-553); False = -schur_pc_type none.
+        slab = (slab-mode FdPc, reduce_fn, reduce_ctx): `op` is the slab-mode operator of a slab driver (dist.py); the inner solves
+        and the pressure mean complete their sums over the ranks, and apply() is collective."""
         h = C.c_void_p()
-        _chk(lib().stokes_saddle_create(op._h, C.byref(h)))
+        if slab is None:
+            _chk(lib().stokes_saddle_create(op._h, C.byref(h)))
+        else:
+            pc, rfn, rctx = slab
+            self._slab_pc = pc
+            _chk(lib().stokes_saddle_create_slab(op._h, pc._h, rfn, rctx, C.byref(h)))
         self._h = h
         self._op = op
         self.n = op.global_size
@@ -734,6 +753,10 @@ class Fgmres:
         cb = Fgmres.APPLY_FN(tramp)
         self._keep.append(cb)
         return C.cast(cb, C.c_void_p), None
+
+    def set_reduce_raw(self, fn, ctx):
+        """The same with a chebhip_reduce_fn given as (function pointer, context): Comm.reduce_fn() of dist.py."""
+        _chk(lib().chebhip_fgmres_set_reduce(self._h, fn, ctx))
 
     def set_reduce(self, group=None):
         """Vectors are distributed over the ranks of `group`: complete every inner product with an all-reduce."""

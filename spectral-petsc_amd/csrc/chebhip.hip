@@ -538,7 +538,12 @@ int ell_op_sync_coeffs(ell_op *op, void *stream) { return op ? ell_sync_coeffs(o
 
 int ell_op_fd_view(ell_op *op, chebhip::FdView *v) {
   if (!op || !v) return fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (op->slab) return fail(CHEBHIP_ERR_ARG, "the finite-difference preconditioner is not available in slab mode");
+  if (op->slab) return fail(CHEBHIP_ERR_ARG, "slab-mode handle: the preconditioner comes from chebhip_dist_ell_pc_create");
+  return ell_op_fd_view_any(op, v, nullptr);
+}
+int ell_op_fd_view_any(ell_op *op, chebhip::FdView *v, int *gP0) {
+  if (!op || !v) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (gP0) *gP0 = op->gP0;
   if (op->d > 10) return fail(CHEBHIP_ERR_DIMS, "d > 10");
   int rc = ell_alloc_state(op); if (rc) return rc;
   v->d = op->d; v->dims = op->dims.data(); v->N = op->N; v->G = op->G; v->ixL = op->ixL;

@@ -19,5 +19,8 @@ struct FdView {
 
 int ell_op_sync_coeffs(ell_op *op, void *stream);            // chebhip.hip: makes eta / deta current before the view's arrays are read
 int ell_op_fd_view(ell_op *op, chebhip::FdView *v);          // chebhip.hip (allocates the coefficient state if needed)
+// the same for slab-mode handles too (precond.hip's slab mode; *gP0: global extent of dimension 0, v->dims[0]: planes of the slab)
+int ell_op_fd_view_any(ell_op *op, chebhip::FdView *v, int *gP0);
+int stokes_op_fd_view_any(stokes_op *op, chebhip::FdView *v, int *gP0);
 int stokes_op_fd_view(stokes_op *op, chebhip::FdView *v);    // stokes.hip
 int chebhip_fail(int code, const char *fmt, ...);            // chebhip.hip

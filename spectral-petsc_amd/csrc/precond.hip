@@ -78,6 +78,11 @@ __global__ void k_fd_assemble(Geo geo, long N, long G, const int *__restrict__ i
   }
 }
 
+// slab mode: only the viscosity at the interior nodes is needed (P_1^-1 (r / eta))
+__global__ void k_eta_g(long N, const int *__restrict__ ixL, const double *__restrict__ eta, double *__restrict__ eta_g) {
+  GS_LOOP(l, N) { const int g = ixL[l]; if (g >= 0) eta_g[g] = eta[l]; }
+}
+
 // y = P x on nf stacked fields of G interior values each
 __global__ void k_fd_mult(Geo geo, long G, int nf, const double *__restrict__ cf, const double *__restrict__ x, double *__restrict__ y) {
   GS_LOOP(t, G * nf) {
@@ -154,6 +159,11 @@ struct chebhip_fdpc {
   chebhip_fgmres *inner = nullptr; int inner_m = 0;   // the approximate solve with variable coefficients
   bool assembled = false;
   ell_op *eop = nullptr; stokes_op *sop = nullptr;
+  // Slab mode: the handle holds the interior nodes of a slab of planes of dimension 0; the line transforms along
+  // dimension 0 need whole lines and go through `dim0` (slabx.hip: slab -> pencil, chebhip_fdpc_pencil_transform, back).
+  // geo.dims[0] is the GLOBAL extent (matrices, eigenvalues), i0_off the global index of the slab's first interior plane.
+  // Only the fast-diagonalisation solve z = P_1^-1 (r / eta) (sweeps = 0) exists on slabs: the stencil of P would need halos.
+  bool slab = false; chebhip_fdpc_dim0_fn dim0 = nullptr; void *dim0_ctx = nullptr; long i0_off = 0;
 };
 
 static void fdpc_free(chebhip_fdpc *pc) {
@@ -171,8 +181,11 @@ static void fdpc_free(chebhip_fdpc *pc) {
   delete pc;
 }
 
-static int fdpc_create(const FdView &v, int nf, bool interleaved, chebhip_fdpc **out) {
+static int fdpc_create(const FdView &v0, int nf, bool interleaved, chebhip_fdpc **out, int gP0 = 0) {
   *out = nullptr;
+  FdView v = v0;
+  std::vector<int> gdims(v0.dims, v0.dims + (v0.d >= 1 && v0.d <= MAXD ? v0.d : 0));
+  if (gP0 > 0 && !gdims.empty()) { gdims[0] = gP0; v.dims = gdims.data(); }      // slab mode: matrices of the global extent
   if (v.d < 1 || v.d > MAXD) return chebhip_fail(CHEBHIP_ERR_DIMS, "d = %d out of range", v.d);
   for (int k = 0; k < v.d; k++) {
     if (v.dims[k] < 3) return chebhip_fail(CHEBHIP_ERR_SIZE, "dims[%d] = %d: the preconditioner needs interior nodes", k, v.dims[k]);
@@ -189,7 +202,7 @@ static int fdpc_create(const FdView &v, int nf, bool interleaved, chebhip_fdpc *
   for (int k = 0; k < v.d; k++) {
     const int P = v.dims[k], M = P - 2;
     pc->inner_g[k] = (unsigned)pc->geo.gs[k];
-    pc->ncols_g[k] = (unsigned)(v.G / M);
+    pc->ncols_g[k] = (unsigned)(v.G / M);                      // (dimension 0 of a slab: unused, its transforms run on pencils)
     std::vector<double> x(P);
     for (int i = 0; i < P; i++) x[i] = cos(i * 3.14159265358979323846 / (P - 1));          // elliptic.C:279, stokes.C:296
     PCCHK(hipMalloc((void **)&pc->xs[k], P * sizeof(double)));
@@ -241,10 +254,16 @@ static int fdpc_create(const FdView &v, int nf, bool interleaved, chebhip_fdpc *
 
 static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
   FdView v;
-  int rc = pc->eop ? ell_op_fd_view(pc->eop, &v) : stokes_op_fd_view(pc->sop, &v);
+  int rc = pc->eop ? ell_op_fd_view_any(pc->eop, &v, nullptr) : stokes_op_fd_view_any(pc->sop, &v, nullptr);
   if (!rc && pc->eop) rc = ell_op_sync_coeffs(pc->eop, (void *)st);
   if (rc) return rc;
   if (pc->G == 0) { pc->assembled = true; return 0; }
+  if (pc->slab) {
+    hipLaunchKernelGGL(k_eta_g, dim3(pgrid(pc->N)), dim3(256), 0, st, pc->N, v.ixL, v.eta, pc->eta_g);
+    PHIPCHK(hipGetLastError());
+    pc->assembled = true;
+    return 0;
+  }
   GradPtrs gu; CoordPtrs xs;
   for (int k = 0; k < MAXD; k++) { gu.p[k] = k < v.d ? v.gradu[k] : nullptr; xs.p[k] = pc->xs[k]; }
   hipLaunchKernelGGL(k_fd_assemble, dim3(pgrid(pc->N)), dim3(256), 0, st, pc->geo, pc->N, pc->G, v.ixL, v.eta, v.deta, gu, xs, pc->cf, pc->eta_g);
@@ -255,10 +274,15 @@ static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
 
 // y = S^-1 x (forward) or S x (backward) along dimension k of nf stacked interior fields (x != y): one raw-mode launch
 // where the 16-byte kernels can run it, otherwise the centro-symmetric plus the centro-antisymmetric part (two launches)
+static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st);
 static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st) {
-  LineMats &lm = pc->lines[pc->geo.dims[k]];
+  if (pc->slab && k == 0) return pc->dim0(pc->dim0_ctx, backward ? 1 : 0, pc->nf, x, y, (void *)st);      // collective: every rank of the slab partition
+  return line_transform_g(pc->lines[pc->geo.dims[k]], pc->ncols_g[k] * (unsigned)pc->nf, pc->inner_g[k], backward, x, y, st);
+}
+static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st) {
+  if (ncols == 0) return 0;
   SweepParams sp = {};
-  sp.ncols = pc->ncols_g[k] * (unsigned)pc->nf; sp.inner = pc->inner_g[k];
+  sp.ncols = ncols; sp.inner = inner;
   sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.alpha = 1.0;
   sp.out_mode = OUT_STORE;
   if (sweep_vec_raw_eligible(backward ? lm.Braw : lm.Fraw, sp)) {       // one launch: the parity split is the transform's own
@@ -282,11 +306,14 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
   {
     const int nl = pc->geo.dims[d - 1] - 2;
     const long lines = pc->G / nl;
-    if (d <= 3 && lines <= 65535 && pc->nf <= 65535) {
+    if (pc->slab && d >= 2) lam.p[0] += pc->i0_off;       // the slab's first interior plane is plane i0_off of the global line
+    if (lines == 0) { /* a slab without interior planes: nothing to scale (it still takes part in the transforms along dimension 0) */ }
+    else if (d <= 3 && lines <= 65535 && pc->nf <= 65535) {
       const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
       hipLaunchKernelGGL(k_modal_scale3, dim3((unsigned)((nl + 255) / 256), (unsigned)lines, (unsigned)pc->nf), dim3(256), 0, st, d, n1, nl, pc->G,
                          lam.p[0], lam.p[1], lam.p[2], (double *)src);
-    } else
+    } else if (pc->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode preconditioner: d <= 3 and at most 65535 lines per slab");
+    else
       hipLaunchKernelGGL(k_modal_scale, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, lam, (double *)src);
   }
   for (int k = d - 1; k >= 0; k--) {
@@ -299,6 +326,7 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
 }
 
 static int fdpc_mult(chebhip_fdpc *pc, const double *x, double *y, hipStream_t st) {
+  if (pc->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_fdpc_mult: the stencil of P is not available on slabs (no halo exchange)");
   if (!pc->assembled) { int rc = fdpc_update(pc, st); if (rc) return rc; }
   if (pc->G == 0) return 0;
   const long n = pc->G * pc->nf;
@@ -326,7 +354,8 @@ static int cb_fdm(void *ctx, const double *r, double *z, void *stream) {
 
 static int fdpc_apply(chebhip_fdpc *pc, const double *r, double *z, hipStream_t st) {
   if (!pc->assembled) { int rc = fdpc_update(pc, st); if (rc) return rc; }
-  if (pc->G == 0) return 0;
+  if (pc->slab && pc->sweeps != 0) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode preconditioner: sweeps must be 0 (P_1^-1 (r / eta))");
+  if (pc->G == 0 && !pc->slab) return 0;              // (a slab without unknowns still takes part in the exchanges of dimension 0)
   const long n = pc->G * pc->nf;
   // component-major copies of r and of the iterate where the ABI vectors are node-major (Stokes velocity)
   const double *rin = r; double *zc = z;
@@ -372,10 +401,43 @@ extern "C" int stokes_pc_create(stokes_op *op, chebhip_fdpc **out) {
   return 0;
 }
 
+// ---- slab mode (called by the slab drivers of slabx.hip) -------------------------------------------------------
+static int fdpc_make_slab(chebhip_fdpc *pc, long i0_off, chebhip_fdpc_dim0_fn dim0, void *ctx) {
+  if (!dim0 || i0_off < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode preconditioner: bad arguments");
+  if (pc->geo.d < 2 || pc->geo.d > 3) return chebhip_fail(CHEBHIP_ERR_DIMS, "slab-mode preconditioner: d = 2 or 3");
+  pc->slab = true; pc->dim0 = dim0; pc->dim0_ctx = ctx; pc->i0_off = i0_off; pc->sweeps = 0;
+  return 0;
+}
+extern "C" int stokes_pc_create_slab(stokes_op *op, long i0_offset, chebhip_fdpc_dim0_fn dim0, void *ctx, chebhip_fdpc **out) {
+  if (!op || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  FdView v; int gP0 = 0; int rc = stokes_op_fd_view_any(op, &v, &gP0); if (rc) return rc;
+  rc = fdpc_create(v, v.d, true, out, gP0); if (rc) return rc;
+  (*out)->sop = op;
+  if ((rc = fdpc_make_slab(*out, i0_offset, dim0, ctx))) { fdpc_free(*out); *out = nullptr; }
+  return rc;
+}
+extern "C" int ell_pc_create_slab(ell_op *op, long i0_offset, chebhip_fdpc_dim0_fn dim0, void *ctx, chebhip_fdpc **out) {
+  if (!op || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  FdView v; int gP0 = 0; int rc = ell_op_fd_view_any(op, &v, &gP0); if (rc) return rc;
+  rc = fdpc_create(v, 1, false, out, gP0); if (rc) return rc;
+  (*out)->eop = op;
+  if ((rc = fdpc_make_slab(*out, i0_offset, dim0, ctx))) { fdpc_free(*out); *out = nullptr; }
+  return rc;
+}
+// The line transform along dimension 0 on a pencil: `nfields` stacked arrays (M0, ncol), lines of M0 = dims[0] - 2 interior
+// points with stride ncol.  backward = 0: S^-1 (nodal -> modal), 1: S.
+extern "C" int chebhip_fdpc_pencil_transform(chebhip_fdpc *pc, int backward, int nfields, long ncol, const double *in_dev, double *out_dev, void *stream) {
+  if (!pc || nfields < 1 || ncol < 0 || ((!in_dev || !out_dev) && ncol > 0)) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  if (ncol == 0) return 0;
+  if ((unsigned long long)nfields * (unsigned long long)ncol > 0x7fffffffull) return chebhip_fail(CHEBHIP_ERR_DIMS, "pencil too large");
+  return line_transform_g(pc->lines[pc->geo.dims[0]], (unsigned)(nfields * ncol), (unsigned)ncol, backward != 0, in_dev, out_dev, (hipStream_t)stream);
+}
+
 extern "C" int chebhip_fdpc_destroy(chebhip_fdpc *pc) { fdpc_free(pc); return 0; }
 extern "C" int chebhip_fdpc_update(chebhip_fdpc *pc, void *stream) { if (!pc) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle"); return fdpc_update(pc, (hipStream_t)stream); }
 extern "C" int chebhip_fdpc_set_sweeps(chebhip_fdpc *pc, int sweeps) {
   if (!pc || sweeps < 0 || sweeps > 64) return chebhip_fail(CHEBHIP_ERR_ARG, "sweeps must be in 0..64");
+  if (pc->slab && sweeps != 0) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode preconditioner: sweeps must be 0");
   pc->sweeps = sweeps; return 0;
 }
 extern "C" int chebhip_fdpc_mult(chebhip_fdpc *pc, const double *x, double *y, void *stream) {

@@ -60,6 +60,19 @@ __global__ __launch_bounds__(MEAN_RT) void k_mean_partial(long n, const double *
   for (int o = MEAN_RT / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
+// Slab mode: the mean is over the pressure unknowns of ALL ranks.  tot[0] = this rank's sum (the 256 partials added in a fixed
+// order), tot[1] = its count; after the all-reduce of the two values every rank subtracts tot[0] / tot[1].
+__global__ __launch_bounds__(MEAN_RT) void k_mean_total(long n, const double *__restrict__ part, double *__restrict__ tot) {
+  __shared__ double sh[MEAN_RB];
+  sh[threadIdx.x] = part[threadIdx.x];
+  __syncthreads();
+  for (int o = MEAN_RB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) { tot[0] = sh[0]; tot[1] = (double)n; }
+}
+__global__ void k_mean_subtract_g(long n, const double *__restrict__ tot, const double *in, double *out) {   // in == out allowed
+  const double mean = tot[0] / tot[1];
+  GS_LOOP(q, n) out[q] = in[q] - mean;
+}
 __global__ __launch_bounds__(MEAN_RT) void k_mean_subtract(long n, const double *__restrict__ part, const double *in, double *out) {   // in == out allowed
   __shared__ double sh[MEAN_RB];
   sh[threadIdx.x] = part[threadIdx.x];
@@ -84,6 +97,10 @@ struct stokes_saddle {
   int its_vel = 0, its_schur = 0;                  // operator applies of the last apply, for monitoring
   chebhip::FdView view;                            // ixL and eta of the operator (the Jacobi scaling of KSPSchur)
   bool schur_jacobi = true;
+  // slab mode: the vectors are this rank's pieces; inner products, norms and the pressure mean are completed over
+  // the ranks by `reduce`; MatVVPC is the slab driver's (borrowed: chebhip_dist_stokes_pc)
+  bool slab = false, own_pc = true;
+  chebhip_reduce_fn reduce = nullptr; void *reduce_ctx = nullptr;
 };
 
 static int vv_apply(void *ctx, const double *x, double *y, void *stream) { return stokes_op_mult_vv(((stokes_saddle *)ctx)->op, x, y, stream); }
@@ -97,10 +114,17 @@ static int svel_solve(void *ctx, const double *rhs, double *sol, void *stream) {
 // MatSchur followed by the removal of the constant: KSPSchur carries the constant null space (stokes.C:1020-1021) and
 // PETSc's (left-preconditioned) GMRES removes it from every vector it builds, i.e. it solves  P S x = P b  on
 // zero-mean vectors, P = I - 1 1^T / n.  (S P z = b would be inconsistent: S is singular and not symmetric.)
-static void remove_mean(stokes_saddle *s, const double *in, double *out, hipStream_t st) {
+static int remove_mean(stokes_saddle *s, const double *in, double *out, hipStream_t st) {
   unsigned g = (unsigned)((s->gp + MEAN_RT - 1) / MEAN_RT); if (g < 1) g = 1; if (g > 2048) g = 2048;
   hipLaunchKernelGGL(k_mean_partial, dim3(MEAN_RB), dim3(MEAN_RT), 0, st, s->gp, in, s->red);
+  if (s->slab && s->reduce) {
+    hipLaunchKernelGGL(k_mean_total, dim3(1), dim3(MEAN_RT), 0, st, s->gp, (const double *)s->red, s->red + MEAN_RB);
+    int rc = s->reduce(s->reduce_ctx, s->red + MEAN_RB, 2, (void *)st); if (rc) return rc;
+    hipLaunchKernelGGL(k_mean_subtract_g, dim3(g), dim3(MEAN_RT), 0, st, s->gp, (const double *)(s->red + MEAN_RB), in, out);
+    return 0;
+  }
   hipLaunchKernelGGL(k_mean_subtract, dim3(g), dim3(MEAN_RT), 0, st, s->gp, (const double *)s->red, in, out);
+  return 0;
 }
 static void eta_scale(stokes_saddle *s, const double *in, double *out, hipStream_t st) {
   if (s->schur_jacobi) hipLaunchKernelGGL(k_eta_scale, dim3(sgrid(s->view.N)), dim3(256), 0, st, s->view.N, s->view.ixL, s->view.eta, in, out);
@@ -110,7 +134,7 @@ static int schur_apply(void *ctx, const double *x, double *y, void *stream) {
   stokes_saddle *s = (stokes_saddle *)ctx;
   int rc = stokes_op_mult_schur(s->op, x, y, svel_solve, s, stream); if (rc) return rc;
   eta_scale(s, y, y, (hipStream_t)stream);
-  remove_mean(s, y, y, (hipStream_t)stream);
+  if ((rc = remove_mean(s, y, y, (hipStream_t)stream))) return rc;
   SHIPCHK2(hipGetLastError());
   return 0;
 }
@@ -126,8 +150,8 @@ static int vel_solve(stokes_saddle *s, const double *b, double *x, void *stream)
 // preconditioned residual as PETSc's left-preconditioned GMRES is; b is overwritten by its preconditioned zero-mean part
 static int schur_solve(stokes_saddle *s, double *b, double *x, void *stream) {
   eta_scale(s, b, b, (hipStream_t)stream);
-  remove_mean(s, b, b, (hipStream_t)stream);
-  int rc = chebhip_fgmres_set_tolerances(s->kschur, s->rtol_schur, 1e-50, s->m_schur > 0 ? s->m_schur : 1); if (rc) return rc;
+  int rc = remove_mean(s, b, b, (hipStream_t)stream); if (rc) return rc;
+  rc = chebhip_fgmres_set_tolerances(s->kschur, s->rtol_schur, 1e-50, s->m_schur > 0 ? s->m_schur : 1); if (rc) return rc;
   rc = chebhip_fgmres_solve(s->kschur, schur_apply, s, nullptr, nullptr, b, x, 0, stream);
   s->its_schur += chebhip_fgmres_iterations(s->kschur);
   return rc;
@@ -138,32 +162,47 @@ extern "C" int stokes_saddle_destroy(stokes_saddle *s) {
   if (s->kvel) chebhip_fgmres_destroy(s->kvel);
   if (s->kschur) chebhip_fgmres_destroy(s->kschur);
   if (s->ksvel) chebhip_fgmres_destroy(s->ksvel);
-  if (s->vvpc) chebhip_fdpc_destroy(s->vvpc);
+  if (s->vvpc && s->own_pc) chebhip_fdpc_destroy(s->vvpc);
   double *all[] = {s->v0, s->v1, s->p0, s->p1, s->red};
   for (double *p : all) if (p) (void)hipFree(p);
   delete s;
   return 0;
 }
 
-extern "C" int stokes_saddle_create(stokes_op *op, stokes_saddle **out) {
+static int saddle_create(stokes_op *op, chebhip_fdpc *slab_pc, chebhip_reduce_fn reduce, void *reduce_ctx, stokes_saddle **out);
+extern "C" int stokes_saddle_create(stokes_op *op, stokes_saddle **out) { return saddle_create(op, nullptr, nullptr, nullptr, out); }
+// On a slab-mode operator (chebhip_dist_stokes_op) with the slab driver's MatVVPC (chebhip_dist_stokes_pc; borrowed): the three
+// inner Krylov solves complete their inner products through `reduce` (chebhip_comm_reduce with the driver's communicator), and so
+// does the removal of the constant pressure mode.  Every rank calls stokes_saddle_apply collectively.
+extern "C" int stokes_saddle_create_slab(stokes_op *slab_op, chebhip_fdpc *slab_pc, chebhip_reduce_fn reduce, void *reduce_ctx, stokes_saddle **out) {
+  if (!slab_pc) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  return saddle_create(slab_op, slab_pc, reduce, reduce_ctx, out);
+}
+static int saddle_create(stokes_op *op, chebhip_fdpc *slab_pc, chebhip_reduce_fn reduce, void *reduce_ctx, stokes_saddle **out) {
   if (!op || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   *out = nullptr;
   stokes_saddle *s = new (std::nothrow) stokes_saddle;
   if (!s) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
   s->op = op;
+  if (slab_pc) { s->slab = true; s->own_pc = false; s->vvpc = slab_pc; s->reduce = reduce; s->reduce_ctx = reduce_ctx; }
   s->I = stokes_op_size(op, 1); s->gv = stokes_op_size(op, 2); s->gp = stokes_op_size(op, 3); s->g = stokes_op_size(op, 4);
   s->d = s->I > 0 ? (int)(s->gv / s->I) : 2;
-  int rc = stokes_pc_create(op, &s->vvpc);
-  if (!rc) rc = stokes_op_fd_view(op, &s->view);
+  int rc = s->slab ? 0 : stokes_pc_create(op, &s->vvpc);
+  if (!rc) rc = stokes_op_fd_view_any(op, &s->view, nullptr);
   if (!rc) rc = chebhip_fdpc_set_sweeps(s->vvpc, 0);
   if (!rc) rc = chebhip_fgmres_create(s->gv, 30, &s->kvel);
   if (!rc) rc = chebhip_fgmres_create(s->gp, 30, &s->kschur);
   if (!rc) rc = chebhip_fgmres_create(s->gv, 30, &s->ksvel);
+  if (!rc && s->slab && reduce) {
+    rc = chebhip_fgmres_set_reduce(s->kvel, reduce, reduce_ctx);
+    if (!rc) rc = chebhip_fgmres_set_reduce(s->kschur, reduce, reduce_ctx);
+    if (!rc) rc = chebhip_fgmres_set_reduce(s->ksvel, reduce, reduce_ctx);
+  }
   if (rc) { stokes_saddle_destroy(s); return rc; }
   const size_t nv = (size_t)(s->gv > 0 ? s->gv : 1) * sizeof(double), np = (size_t)(s->gp > 0 ? s->gp : 1) * sizeof(double);
   if (hipMalloc((void **)&s->v0, nv) != hipSuccess || hipMalloc((void **)&s->v1, nv) != hipSuccess ||
       hipMalloc((void **)&s->p0, np) != hipSuccess || hipMalloc((void **)&s->p1, np) != hipSuccess ||
-      hipMalloc((void **)&s->red, MEAN_RB * sizeof(double)) != hipSuccess) {
+      hipMalloc((void **)&s->red, (MEAN_RB + 2) * sizeof(double)) != hipSuccess) {
     stokes_saddle_destroy(s); return chebhip_fail(CHEBHIP_ERR_MEMORY, "device allocation failed");
   }
   *out = s;
@@ -206,7 +245,7 @@ extern "C" int stokes_saddle_iterations(const stokes_saddle *s, int which) { ret
 extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *stream) {
   stokes_saddle *s = (stokes_saddle *)ctx;
   if (!s || ((!x || !y) && s->g)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (s->g == 0) return 0;
+  if (s->g == 0 && !s->slab) return 0;               // (a slab without unknowns still takes part in the collectives)
   chebhip::StageTimer tm(CHEBHIP_STAGE_SADDLE_APPLY, stream);
   hipStream_t st = (hipStream_t)stream;
   const long I = s->I; const int d = s->d;
@@ -227,7 +266,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
       if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1           (:1734)
       hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)nullptr);   // v0 <- -v0 (:1735)
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0          (:1736)
-      remove_mean(s, s->p1, s->p1, st);      // KSPSetNullSpace (:1019)
+      if ((rc = remove_mean(s, s->p1, s->p1, st))) return rc;      // KSPSetNullSpace (:1019)
       MERGE(s->v1, 1, s->p1);                                                      // y_v += v1, y_p <- p1   (:1733,1737)
       break;
     case 1:   // block upper triangular (stokes.C:1747-1765)
@@ -236,14 +275,14 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
       if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1
       hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)s->v1);   // v0 <- -v0 + x_v
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
-      remove_mean(s, s->p1, s->p1, st);
+      if ((rc = remove_mean(s, s->p1, s->p1, st))) return rc;
       MERGE(s->v1, 0, s->p1);
       break;
     case 2:   // block diagonal (stokes.C:1772-1790)
       SPLIT(s->v0, s->p0);
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;
-      remove_mean(s, s->p1, s->p1, st);
+      if ((rc = remove_mean(s, s->p1, s->p1, st))) return rc;
       MERGE(s->v1, 0, s->p1);
       break;
     default:  // block lower triangular (stokes.C:1797-1816)
@@ -253,7 +292,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
       hipLaunchKernelGGL(k_scale_add, dim3(gpn), dim3(256), 0, st, s->gp, -1.0, s->p0, (const double *)s->p1);   // p0 <- -p0 + x_p
       MERGE(s->v1, 0, nullptr);                                                    // y_v <- v1 (before v1 is reused by the Schur solve)
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0
-      remove_mean(s, s->p1, s->p1, st);
+      if ((rc = remove_mean(s, s->p1, s->p1, st))) return rc;
       MERGE((const double *)nullptr, 0, s->p1);
       break;
   }

@@ -96,6 +96,32 @@ struct SlabX {
     return 0;
   }
 
+  // The same machinery for fields in the INTERIOR layout (M0, M1, R') = dims - 2 of the global vectors, partitioned like the
+  // operator's slabs: rank r holds the interior planes that fall into its planes [full_s0[r], full_s0[r+1]) of the full grid
+  // (possibly none).  Used by the slab-mode preconditioner (precond.hip), whose vectors are the operator's unknowns.
+  int setup_interior(int d_, const int *dims_, chebhip_comm *c, int nf, const std::vector<long> &full_s0) {
+    if (!dims_ || d_ < 2 || d_ > 10) return chebhip_fail(CHEBHIP_ERR_DIMS, "slab partitioning needs 2 <= d <= 10");
+    comm = c; d = d_; dims.assign(dims_, dims_ + d_); nf_max = nf;
+    G = chebhip::comm_size(c); rank = chebhip::comm_rank(c);
+    if (G < 1 || G > 64 || (int)full_s0.size() != G + 1) return chebhip_fail(CHEBHIP_ERR_ARG, "1..64 ranks");
+    P0 = dims[0] - 2; P1 = dims[1] - 2; R = 1; for (int k = 2; k < d; k++) R *= dims[k] - 2;
+    if (P0 < 1 || P1 < 1 || R < 1) return chebhip_fail(CHEBHIP_ERR_SIZE, "no interior nodes");
+    m0.assign(G, 0);
+    for (int s = 0; s < G; s++) {
+      const long lo = full_s0[s] > 1 ? full_s0[s] : 1, hi = full_s0[s + 1] < dims[0] - 1 ? full_s0[s + 1] : dims[0] - 1;
+      m0[s] = hi > lo ? hi - lo : 0;
+    }
+    split_sizes(P1, G, m1);
+    s0.assign(G + 1, 0); s1.assign(G + 1, 0);
+    for (int s = 0; s < G; s++) { s0[s + 1] = s0[s] + m0[s]; s1[s + 1] = s1[s] + m1[s]; }
+    Ns = m0[rank] * P1 * R; ncol = m1[rank] * R; Np = P0 * ncol;
+    split.G = G; for (int s = 0; s <= G; s++) split.c1[s] = s1[s];
+    const size_t sb = (size_t)nf * (size_t)(Ns > 0 ? Ns : 1) * sizeof(double), pb = (size_t)nf * (size_t)(Np > 0 ? Np : 1) * sizeof(double);
+    XHIPCHK(hipMalloc((void **)&sendbuf, sb)); XHIPCHK(hipMalloc((void **)&recvbuf, sb));
+    XHIPCHK(hipMalloc((void **)&pen_in, pb)); XHIPCHK(hipMalloc((void **)&pen_out, pb));
+    return 0;
+  }
+
   // the peer whose block bypasses the exchange buffers: this rank (none with option rccl_self_messages: one-rank smoke runs of the transport)
   int own() const { return chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES) ? -1 : rank; }
   // 16-byte accesses of the pack / unpack launches: every run must start even-aligned and have even length
@@ -159,7 +185,21 @@ struct SlabX {
 }  // namespace
 
 // ---- Stokes ------------------------------------------------------------------------------------------------------
-struct chebhip_dist_stokes { SlabX x; stokes_op *op = nullptr; };
+struct chebhip_dist_stokes { SlabX x; stokes_op *op = nullptr; SlabX *xi = nullptr; chebhip_fdpc *pc = nullptr; };
+
+// dimension 0 of the slab-mode preconditioner (chebhip_fdpc_dim0_fn): interior fields slab -> pencil, line transform, back
+static int pc_dim0(SlabX *xi, chebhip_fdpc *pc, int backward, int nf, const double *in, double *out, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = xi->to_pencil(nf, in, st);
+  if (!rc) rc = chebhip_fdpc_pencil_transform(pc, backward, nf, xi->ncol, xi->pen_in, xi->pen_out, stream);
+  if (!rc) rc = xi->to_slab(nf, nullptr, 1.0, out, st);
+  if (rc) chebhip::comm_abort(xi->comm);
+  return rc;
+}
+static int dstokes_pc_dim0(void *ctx, int backward, int nf, const double *in, double *out, void *stream) {
+  chebhip_dist_stokes *D = (chebhip_dist_stokes *)ctx;
+  return pc_dim0(D->xi, D->pc, backward, nf, in, out, stream);
+}
 
 static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const double *acc, double alpha, double *out, void *stream) {
   chebhip_dist_stokes *D = (chebhip_dist_stokes *)ctx;
@@ -175,6 +215,8 @@ static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const dou
 
 extern "C" int chebhip_dist_stokes_destroy(chebhip_dist_stokes *D) {
   if (!D) return 0;
+  if (D->pc) chebhip_fdpc_destroy(D->pc);
+  delete D->xi;
   if (D->op) stokes_op_destroy(D->op);
   delete D;
   return 0;
@@ -192,6 +234,24 @@ extern "C" int chebhip_dist_stokes_create(int d, const int *dims, chebhip_comm *
   return 0;
 }
 extern "C" stokes_op *chebhip_dist_stokes_op(chebhip_dist_stokes *D) { return D ? D->op : nullptr; }
+// MatVVPC (stokes.C:1160-1241) for the slab's velocity unknowns: the handle of precond.hip in slab mode, its transforms along
+// dimension 0 on pencils through this driver's communicator.  Owned by the driver (destroyed with it); one per driver.
+extern "C" int chebhip_dist_stokes_pc(chebhip_dist_stokes *D, chebhip_fdpc **out) {
+  if (!D || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  if (!D->pc) {
+    const int d = D->x.d;
+    SlabX *xi = new (std::nothrow) SlabX;
+    if (!xi) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+    int rc = xi->setup_interior(d, D->x.dims.data(), D->x.comm, d, D->x.s0);
+    if (rc) { delete xi; return rc; }
+    D->xi = xi;
+    rc = stokes_pc_create_slab(D->op, xi->s0[xi->rank], dstokes_pc_dim0, D, &D->pc);
+    if (rc) { delete D->xi; D->xi = nullptr; D->pc = nullptr; return rc; }
+  }
+  *out = D->pc;
+  return 0;
+}
 extern "C" int chebhip_dist_stokes_ranges(const chebhip_dist_stokes *D, long *ranges4) {
   if (!D || !ranges4) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   D->x.ranges(ranges4);
@@ -199,7 +259,11 @@ extern "C" int chebhip_dist_stokes_ranges(const chebhip_dist_stokes *D, long *ra
 }
 
 // ---- general-coefficient elliptic operator -----------------------------------------------------------------------
-struct chebhip_dist_ell { SlabX x; ell_op *op = nullptr; };
+struct chebhip_dist_ell { SlabX x; ell_op *op = nullptr; SlabX *xi = nullptr; chebhip_fdpc *pc = nullptr; };
+static int dell_pc_dim0(void *ctx, int backward, int nf, const double *in, double *out, void *stream) {
+  chebhip_dist_ell *D = (chebhip_dist_ell *)ctx;
+  return pc_dim0(D->xi, D->pc, backward, nf, in, out, stream);
+}
 
 static int dell_dim0(void *ctx, int kind, int nf, const double *in, const double *acc, double alpha, double *out, void *stream) {
   chebhip_dist_ell *D = (chebhip_dist_ell *)ctx;
@@ -214,6 +278,8 @@ static int dell_dim0(void *ctx, int kind, int nf, const double *in, const double
 
 extern "C" int chebhip_dist_ell_destroy(chebhip_dist_ell *D) {
   if (!D) return 0;
+  if (D->pc) chebhip_fdpc_destroy(D->pc);
+  delete D->xi;
   if (D->op) ell_op_destroy(D->op);
   delete D;
   return 0;
@@ -230,6 +296,22 @@ extern "C" int chebhip_dist_ell_create(int d, const int *dims, chebhip_comm *com
   return 0;
 }
 extern "C" ell_op *chebhip_dist_ell_op(chebhip_dist_ell *D) { return D ? D->op : nullptr; }
+// FormJacobian's preconditioner (elliptic.C:537-590) for the slab's unknowns, as chebhip_dist_stokes_pc
+extern "C" int chebhip_dist_ell_pc(chebhip_dist_ell *D, chebhip_fdpc **out) {
+  if (!D || !out) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  if (!D->pc) {
+    SlabX *xi = new (std::nothrow) SlabX;
+    if (!xi) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+    int rc = xi->setup_interior(D->x.d, D->x.dims.data(), D->x.comm, 1, D->x.s0);
+    if (rc) { delete xi; return rc; }
+    D->xi = xi;
+    rc = ell_pc_create_slab(D->op, xi->s0[xi->rank], dell_pc_dim0, D, &D->pc);
+    if (rc) { delete D->xi; D->xi = nullptr; D->pc = nullptr; return rc; }
+  }
+  *out = D->pc;
+  return 0;
+}
 extern "C" int chebhip_dist_ell_ranges(const chebhip_dist_ell *D, long *ranges4) {
   if (!D || !ranges4) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   D->x.ranges(ranges4);

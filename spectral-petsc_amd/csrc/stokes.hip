@@ -13,7 +13,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
-#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -522,25 +521,11 @@ struct stokes_op {
   int rh_kind = 0; double rh_hard = 1.0, rh_expo = 1.0, rh_eps = 1.0, rh_g0 = 1.0;   // stokes.C:403
 };
 
-// Work arrays of one handle.  Option "stokes_skew" (A/B, read at create): every array starts a different multiple of 4352 bytes
-// (4 KiB + 256 B) into its allocation, so that the same node of the ~30 arrays a node loop streams does not sit at the same
-// offset of a 16-MiB-aligned allocation in each of them (HBM channel / bank interleave).  g_raw: skewed pointer -> allocation.
-static std::map<const void *, void *> g_raw; static std::mutex g_raw_mu; static int g_skew_next = 0;
-static int st_alloc(double **p, size_t n) {
-  size_t skew = 0;
-  if (opt(OPT_STOKES_SKEW)) { std::lock_guard<std::mutex> lk(g_raw_mu); skew = (size_t)(g_skew_next++ % 29) * 4352; }
-  char *raw = nullptr;
-  SHIPCHK(hipMalloc((void **)&raw, n * sizeof(double) + skew)); SHIPCHK(hipMemset(raw, 0, n * sizeof(double) + skew));
-  *p = (double *)(raw + skew);
-  if (skew) { std::lock_guard<std::mutex> lk(g_raw_mu); g_raw[*p] = raw; }
-  return 0;
-}
-static void st_free(double *p) {
-  if (!p) return;
-  void *raw = p;
-  { std::lock_guard<std::mutex> lk(g_raw_mu); auto it = g_raw.find(p); if (it != g_raw.end()) { raw = it->second; g_raw.erase(it); } }
-  (void)hipFree(raw);
-}
+// Work arrays of one handle.  (Round 4 tried starting every array at a different multiple of 4352 bytes of its allocation, against
+// a suspected HBM channel / bank alignment of the ~30 arrays a node loop streams: 128^3 power-law StokesMatMult 287 -> 305 us,
+// StokesFunction 305 -> 310 us in an A/B in one process -- the 16-MiB-aligned allocations are the better placement.  Removed.)
+static int st_alloc(double **p, size_t n) { SHIPCHK(hipMalloc((void **)p, n * sizeof(double))); SHIPCHK(hipMemset(*p, 0, n * sizeof(double))); return 0; }
+static void st_free(double *p) { if (p) (void)hipFree(p); }
 
 extern "C" int stokes_op_destroy(stokes_op *op) {
   if (!op) return 0;
@@ -688,7 +673,12 @@ extern "C" int stokes_op_create_slab(int d, const int *dims, int lo, int hi, sto
 
 int stokes_op_fd_view(stokes_op *op, chebhip::FdView *v) {
   if (!op || !v) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "the finite-difference preconditioner is not available in slab mode");
+  if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode handle: the preconditioner comes from chebhip_dist_stokes_pc_create");
+  return stokes_op_fd_view_any(op, v, nullptr);
+}
+int stokes_op_fd_view_any(stokes_op *op, chebhip::FdView *v, int *gP0) {
+  if (!op || !v) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (gP0) *gP0 = op->gP0;
   v->d = op->d; v->dims = op->dims.data(); v->N = op->N; v->G = op->I; v->ixL = op->ixL;
   v->eta = op->eta; v->deta = op->deta;                   // StokesPCSetUp0 reads eta only (stokes.C:1217-1222)
   return 0;

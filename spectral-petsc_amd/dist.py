@@ -556,6 +556,16 @@ class Comm:
                 return 5
         return xfn
 
+    def allreduce_sum(self, value):
+        """Sum of one float over the ranks (chebhip_comm_reduce on a device scalar, on torch's current stream)."""
+        t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")
+        self.sp._chk(self.sp.lib().chebhip_comm_reduce(self._h, t.data_ptr(), 1, self.sp._stream()))
+        return float(t.item())
+
+    def norm(self, t):
+        """Global 2-norm of a vector distributed over the ranks."""
+        return self.allreduce_sum(float((t * t).sum())) ** 0.5
+
     def reduce_fn(self):
         """(chebhip_reduce_fn, ctx) for Fgmres.set_reduce-style hooks: chebhip_comm_reduce on this communicator."""
         import ctypes as C
@@ -614,6 +624,22 @@ class DistStokesC(_DistC):
         for name in ("mult", "function", "mult_vv", "mult_pv", "mult_vp", "mult_schur"):
             setattr(self, name, getattr(self.op, name))
 
+    def pc(self):
+        """MatVVPC (stokes.C:1160-1241) for the slab's velocity unknowns: FdPc in slab mode, owned by this driver."""
+        import ctypes as C
+        if getattr(self, "_pc", None) is None:
+            h = C.c_void_p()
+            self.sp._chk(self.sp.lib().chebhip_dist_stokes_pc(self._h, C.byref(h)))
+            self._pc = self.sp.FdPc(self.op, sweeps=0, handle=h)
+        return self._pc
+
+    def saddle(self, saddle_type=0, vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), schur_jacobi=True):
+        """StokesPCApply0..3 on slabs (collective): the block preconditioner of the whole saddle-point system."""
+        if self.comm is None:
+            raise ValueError("slab preconditioner needs a communicator")
+        rfn, rctx = self.comm.reduce_fn()
+        return self.sp.StokesSaddlePc(self.op, saddle_type, vel, schur, svel, 0, schur_jacobi, slab=(self.pc(), rfn, rctx))
+
 
 class DistEllipticC(_DistC):
     """MatMult_Elliptic / FormFunction for any coefficient state on slabs, host in C++ (chebhip_dist_ell_*)."""
@@ -634,3 +660,12 @@ class DistEllipticC(_DistC):
         self._rng = self._ranges(L.chebhip_dist_ell_ranges)
         self.global_size, self.dirichlet_size, self.local_size = self.op.global_size, self.op.dirichlet_size, self.op.local_size
         self.mult, self.function = self.op.mult, self.op.function
+
+    def pc(self):
+        """FormJacobian's preconditioner (elliptic.C:537-590) for the slab's unknowns: FdPc in slab mode, owned by this driver."""
+        import ctypes as C
+        if getattr(self, "_pc", None) is None:
+            h = C.c_void_p()
+            self.sp._chk(self.sp.lib().chebhip_dist_ell_pc(self._h, C.byref(h)))
+            self._pc = self.sp.FdPc(self.op, sweeps=0, handle=h)
+        return self._pc

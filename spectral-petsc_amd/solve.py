@@ -63,7 +63,7 @@ def continuation_schedule(exponent, regularization, cont0=0, cont=1):
 def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, saddle_type=0,
                  snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50, ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000,
                  vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, line_search=True, monitor=None, max_linear_fail=1,
-                 schur_jacobi=True, stats=None):
+                 schur_jacobi=True, stats=None, dist=None):
     """The solve phase of stokes.C:213-235 on device vectors: for every continuation stage, SNESSolve = Newton with a
     backtracking line search around StokesFunction (stokes.C:680-758), each step KSPSolve(KSPFGMRES) on the
     Newton-linearised StokesMatMult (stokes.C:499-519) right-preconditioned by StokesPCApply<saddle_type>
@@ -72,12 +72,20 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
     `max_linear_fail`: linear solves that may end on their iteration limit before the Newton iteration gives up
     (-snes_max_linear_solve_fail, PETSc's default 1); the step of such a solve is still tried by the line search.
     `stats` (a dict) receives "linear_fails": the number of linear solves that ended on their iteration limit.
+    `dist`: a slab driver of dist.py (DistStokesC) whose slab-mode operator `op` is: the vectors are this rank's pieces, every
+    rank calls collectively; norms, the Krylov inner products and the block preconditioner's sums go through its communicator.
     Returns a list of (exponent, regularization, newton_its, ksp_its, |F|) per stage."""
     kind, hardness, exponent, regularization, gamma0 = rheology
     n = op.global_size
     F = torch.empty_like(x); dx = torch.empty_like(x)
     ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
-    pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps, schur_jacobi)
+    if dist is not None:
+        ks.set_reduce_raw(*dist.comm.reduce_fn())
+        pc = dist.saddle(saddle_type, vel, schur, svel, schur_jacobi)
+        gnorm = dist.comm.norm
+    else:
+        pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps, schur_jacobi)
+        gnorm = lambda t: float(t.norm())
     stages = continuation_schedule(exponent, regularization, cont0, cont) if kind == 1 else [(exponent, regularization)]
     out = []
     fails = 0
@@ -85,7 +93,7 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
         for (e_i, r_i) in stages:
             op.set_rheology(kind, hardness, e_i, r_i, gamma0)                  # stokes.C:219-220
             op.function(x, F)
-            f0 = fn = float(F.norm()); it = 0; total = 0
+            f0 = fn = gnorm(F); it = 0; total = 0
             while it < snes_max_it and fn > max(snes_rtol * f0, snes_atol):
                 pc.setup()                                                      # StokesPCSetUp0 after the new viscosity
                 F.neg_()
@@ -98,10 +106,10 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
                                            % (e_i, r_i, it + 1, ks.reason, ks.iterations, ks.residual))
                 lam, fold = 1.0, fn
                 x.add_(dx)
-                op.function(x, F); fn = float(F.norm())
+                op.function(x, F); fn = gnorm(F)
                 while line_search and not (fn <= (1.0 - 1e-4 * lam) * fold) and lam > 1e-6:
                     x.add_(dx, alpha=-0.5 * lam); lam *= 0.5
-                    op.function(x, F); fn = float(F.norm())
+                    op.function(x, F); fn = gnorm(F)
                 it += 1
                 if monitor:
                     monitor(e_i, r_i, it, fn, ks.iterations, lam)
