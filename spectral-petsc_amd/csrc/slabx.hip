@@ -207,7 +207,11 @@ static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const dou
   // a failure between the two exchanges must not leave the peers of a thread-rank group waiting for this rank
   int rc = D->x.to_pencil(nf, in, st); if (rc) { chebhip::comm_abort(D->x.comm); return rc; }
   if (kind == 0) rc = stokes_op_pencil_sweep(D->op, nf, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);     // DV[0] / DP[0]
-  else rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);                // x-line extrapolation + DP[0]
+  else if (kind == 1) rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);  // x-line extrapolation + DP[0]
+  else {                                                     // kind 2: nf - 1 velocity fields and the pressure field in one round trip
+    rc = stokes_op_pencil_sweep(D->op, nf - 1, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);
+    if (!rc) rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in + (size_t)(nf - 1) * D->x.Np, D->x.pen_out + (size_t)(nf - 1) * D->x.Np, stream);
+  }
   if (!rc) rc = D->x.to_slab(nf, acc, alpha, out, st);
   if (rc) chebhip::comm_abort(D->x.comm);
   return rc;
@@ -226,7 +230,7 @@ extern "C" int chebhip_dist_stokes_create(int d, const int *dims, chebhip_comm *
   *out = nullptr;
   chebhip_dist_stokes *D = new (std::nothrow) chebhip_dist_stokes;
   if (!D) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
-  int rc = D->x.setup(d, dims, comm, d);
+  int rc = D->x.setup(d, dims, comm, d + 1);
   if (!rc) rc = stokes_op_create_slab(d, dims, (int)D->x.s0[D->x.rank], (int)D->x.s0[D->x.rank + 1], dstokes_dim0, D, &D->op);
   if (!rc && D->x.G > 1) rc = stokes_op_set_inner_reduce(D->op, chebhip_comm_reduce, comm);
   if (rc) { chebhip_dist_stokes_destroy(D); return rc; }

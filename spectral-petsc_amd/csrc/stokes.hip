@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict_
                                                   const double *__restrict__ yL1, const double *__restrict__ yL2,
                                                   const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
                                                   const double *__restrict__ p2, const double *__restrict__ force, double *__restrict__ out,
-                                                  const double *__restrict__ G) {
+                                                  const double *__restrict__ G, const double *__restrict__ p2b, const double *__restrict__ p2c) {
+  // p2b, p2c (may be null): the pressure rows are (p2 + p2b) + p2c -- the divergence as the sum of its three terms
   const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
   const double *gp[3] = {gp0, gp1, gp2};
   for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict_
         v[u][k] = s;
       }
       v[u][3] = ((const double2 *)p2)[t];
+      if (p2b) { const double2 b = ((const double2 *)p2b)[t], c = ((const double2 *)p2c)[t]; v[u][3].x = (v[u][3].x + b.x) + c.x; v[u][3].y = (v[u][3].y + b.y) + c.y; }
     }
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -532,6 +534,7 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);
   for (auto &kv : op->matsP) diffmat_destroy(&kv.second);
   for (auto &kv : op->matsDD) diffmat_destroy(&kv.second);
+  if (op->slab) { op->pL = nullptr; op->gp[0] = nullptr; }      // parts of xL / V[0] / strain[0] (st_create)
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
                    op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T, op->xF};
   for (double *p : all) st_free(p);
@@ -611,10 +614,18 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     op->innerV[k] = in; op->ncolsV[k] = (unsigned)(N / dims[k]) * d;          // DV[k]: the same lines for d stacked fields
   }
   const size_t nd = (size_t)N * d;
-  OPRC(st_alloc(&op->xL, nd)); OPRC(st_alloc(&op->yL, nd));
+  // Slab mode: the gradient along dimension 0 and the pressure gradient along it share ONE round trip to pencils (d + 1 stacked
+  // fields, see st_gradient_and_pressure_gradient_slab): pL sits right behind xL, and gp[0] is the (d+1)-th field of whichever
+  // array receives the gradient (V[0] in StokesMatMult, strain[0] in StokesFunction) -- set per call, not allocated.
+  const size_t nd1 = slab ? nd + (size_t)N : nd;
+  OPRC(st_alloc(&op->xL, nd1)); OPRC(st_alloc(&op->yL, nd));
   if (op->uniform_ok) OPRC(st_alloc(&op->xF, nd));
-  if (!slab) for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
-  for (int j = 0; j < d; j++) { OPRC(st_alloc(&op->V[j], nd)); OPRC(st_alloc(&op->strain[j], nd)); OPRC(st_alloc(&op->gp[j], (size_t)N)); }
+  for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
+  for (int j = 0; j < d; j++) {
+    OPRC(st_alloc(&op->V[j], j == 0 ? nd1 : nd)); OPRC(st_alloc(&op->strain[j], j == 0 ? nd1 : nd));
+    if (!(slab && j == 0)) OPRC(st_alloc(&op->gp[j], (size_t)N));
+  }
+  if (slab) op->gp[0] = op->V[0] + nd;
   OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
   // (the spaced-out input fields of the six-component storage exist in the 16-byte kernels only: not with "general_kernels")
   if (!slab && d == 3 && (N & 1) == 0 && (size_t)N * 9 * 8 < 0x38000000ull && !opt(OPT_FULL_STRESS) && !opt(OPT_GENERAL_KERNELS)) {
@@ -624,7 +635,8 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     ok = ok && ((N / dims[d - 1]) % nt_last) == 0;
     if (ok) { OPRC(st_alloc(&op->T, (size_t)N * 9)); op->sym = true; }
   }
-  OPRC(st_alloc(&op->pL, (size_t)N)); OPRC(st_alloc(&op->p2, (size_t)N));
+  if (slab) op->pL = op->xL + nd; else OPRC(st_alloc(&op->pL, (size_t)N));
+  OPRC(st_alloc(&op->p2, (size_t)N));
   hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
   // Lagrange weights of the interior nodes x_1..x_{P-2} at x_0 and x_{P-1} (the polyInterp functional)
   op->w0.assign(d, nullptr); op->w1.assign(d, nullptr);
@@ -761,14 +773,23 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
 }
 // final scatter with every term present (StokesMatMult, StokesFunction)
 // y0, y1, y2 (+ G): the velocity terms, summed in this order (the general path: yL, yLx[1], yLx[2]; y1, y2, G may be null)
+static inline bool st_out_pairs(const stokes_op *op, const double *y0, const double *y1, const double *y2, const double *G, const double *force, const double *out) {
+  return op->d == 3 && y1 && y2 && st_al16(out) && (!force || st_al16(force)) && (op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G));
+}
 static void st_out_full(stokes_op *op, const double *force, double *out, hipStream_t st, const double *y0 = nullptr, const double *y1 = nullptr,
-                        const double *y2 = nullptr, const double *G = nullptr) {
+                        const double *y2 = nullptr, const double *G = nullptr, const double *p3 = nullptr) {      // p3: three stacked terms of the pressure rows instead of p2
   const int d = op->d;
+  if (p3) {                                                 // (the caller has checked st_out_pairs)
+    hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
+                       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], p3, force, out, G, p3 + op->N, p3 + 2 * op->N);
+    return;
+  }
   if (!y0) { y0 = op->yL; y1 = op->yLx[1]; y2 = op->yLx[2]; }
   if (d == 3 && y1 && y2 && st_al16(out) && (!force || st_al16(force))) {
     if ((op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G)))      // (the handle's own arrays: always)
       hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
-                         (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
+                         (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G,
+                         (const double *)nullptr, (const double *)nullptr);
     else
       hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                          (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
@@ -799,16 +820,17 @@ static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x,
 }
 
 // yL (+ yLx[1] + yLx[2]) = -sum_j DV[j] V[j]   (stokes.C:668-671, 737-740): one launch, the sum is taken by the final scatter
-// in the order j = 0, 1, 2; slab mode keeps the accumulating chain (the sweep along dimension 0 is the driver's)
+// in the order j = 0, 1, 2 (slab mode: the sweep along dimension 0 is the driver's, the others one launch)
 static int st_div_stress(stokes_op *op, hipStream_t st, bool from_T = false) {
-  if (op->slab) {
-    for (int j = 0; j < op->d; j++) {
-      int rc = sweep_plain(op, true, j, op->V[j], op->yL, j == 0 ? OUT_STORE : OUT_ACC, op->yL, -1.0, st);
-      if (rc) return rc;
-    }
-    return 0;
-  }
   double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
+  if (op->slab) {
+    // dimension 0 through the driver (pencils), the local directions as ONE launch into arrays of their own; the final scatter
+    // adds the terms in the order j = 0, 1, 2 as on one GPU (the same bits).  (Round 3 ran an accumulating chain of d launches here:
+    // at 8 ranks every launch of a 128^3 problem is a 64^3-sized, latency-bound one.)
+    int rc = sweep_plain(op, true, 0, op->V[0], op->yL, OUT_STORE, nullptr, -1.0, st); if (rc) return rc;
+    const double *x[3] = {op->V[0], op->V[1], op->V[2]};
+    return sweeps_multi(op, true, 1, x, y, -1.0, st);
+  }
   if (from_T) {         // the fields (j,0), (j,1), (j,2) of direction j are slots j, 2j+1, 3j+2 of T: base j N, one field every (j+1) N
     const double *x[3] = {op->T, op->T + op->N, op->T + 2 * op->N};
     return sweeps_multi(op, true, 0, x, y, -1.0, st, true);
@@ -819,11 +841,11 @@ static int st_div_stress(stokes_op *op, hipStream_t st, bool from_T = false) {
 
 // V[j] = DV[j] xL (stokes.C:639) / strain[j] = DV[j] xL (:701)
 static int st_gradient(stokes_op *op, double *const *out, hipStream_t st) {
-  if (op->slab) {
-    for (int j = 0; j < op->d; j++) { int rc = sweep_plain(op, true, j, op->xL, out[j], OUT_STORE, nullptr, 1.0, st); if (rc) return rc; }
-    return 0;
-  }
   const double *x[3] = {op->xL, op->xL, op->xL};
+  if (op->slab) {                                           // dimension 0 on pencils (the driver), the local directions in one launch
+    int rc = sweep_plain(op, true, 0, op->xL, out[0], OUT_STORE, nullptr, 1.0, st); if (rc) return rc;
+    return sweeps_multi(op, true, 1, x, out, 1.0, st);
+  }
   return sweeps_multi(op, true, 0, x, out, 1.0, st);
 }
 
@@ -847,6 +869,29 @@ static int st_gradient_and_pressure_gradient(stokes_op *op, double *const *out, 
 }
 static inline bool st_one_launch_gradients(const stokes_op *op) { return !op->aux && !op->slab; }
 
+static void st_pressure_extrapolate(stokes_op *op, double *pL, hipStream_t st);
+// Slab mode: out[j] = DV[j] xL and gp[i] = DP[i] pL with ONE round trip to pencils for everything along dimension 0 (callback
+// kind 2: d velocity fields differentiated with D, the pressure field with its end-point extrapolation) and ONE launch for the
+// 2 (d - 1) local sweeps.  Round 3 made two round trips (gradient, pressure): 4 of the 6 exchanges of a callback, now 2 of 4.
+static int st_gradient_and_pressure_gradient_slab(stokes_op *op, double *const *out, hipStream_t st) {
+  const int d = op->d; const long N = op->N;
+  if (!op->pext) st_pressure_extrapolate(op, op->pL, st);      // z and y lines (the x lines: on the pencils, stokes_op_pencil_pressure)
+  op->gp[0] = out[0] + (size_t)d * N;                          // the (d+1)-th field of the array that receives the gradient
+  int rc = op->dim0(op->dim0_ctx, 2, d + 1, op->xL, nullptr, 1.0, out[0], st); if (rc) return rc;
+  const DiffMat *m[4]; SweepParams sp[4];
+  int n = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int k = 1; k < d; k++, n++) {
+      const bool vec = pass == 0;
+      sp[n] = SweepParams{};
+      sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
+      sp[n].in0 = vec ? op->xL : op->pL; sp[n].in_mode = IN_PLAIN; sp[n].out = vec ? out[k] : op->gp[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = 1.0;
+      m[n] = (!vec && op->pext) ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
+    }
+  SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  return 0;
+}
+
 // Uniform viscosity, eta' = 0 (linear rheology, stokes.C:470-474; the state after create): the viscous block of the Jacobian,
 //   -sum_j D_j eta (D_j v_c + D_c v_j) / 2 = -eta/2 ( sum_j D_j D_j v_c + D_c div v ),   div v = sum_j D_j v_j
 // (sweeps along different directions commute), needs no node loop and no second set of d^2 sweeps: ONE launch of the d
@@ -858,7 +903,7 @@ __global__ void k_st_sum_fields(long N, int d, const double *__restrict__ t, dou
   GS_LOOP(i, N) { double v = t[i] + t[N + i]; if (d == 3) v = v + t[2 * N + i]; out[i] = v; }
 }
 static inline bool st_uniform(const stokes_op *op) { return op->uniform_ok && op->eta_uniform && !op->deta_nonzero; }
-static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st, const double *xloc = nullptr, double eta_value = 0.0) {
+static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st, const double *xloc = nullptr, double eta_value = 0.0, bool *split_div = nullptr) {
   const int d = op->d; const long N = op->N;
   if (!xloc) { xloc = op->xL; eta_value = op->eta_value; }             // StokesFunction: its own local vector (xF), eta = 1
   const double a = -0.5 * eta_value;
@@ -874,6 +919,22 @@ static int st_viscous_uniform(stokes_op *op, bool with_pressure, hipStream_t st,
   for (int k = 0; k < d; k++) job(op->mats[op->dims[k]], false, k, xloc + (size_t)k * N, op->yL + (size_t)k * N, 1.0);
   if (with_pressure) for (int k = 0; k < d; k++) job(op->matsP[op->dims[k]], false, k, op->pL, op->gp[k], 1.0);
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  // Lines of at most 64 points (the launch-bound sizes): the sweeps of grad div v read div v = (t_0 + t_1) + t_2 from its three
+  // terms as they load (IN_SUM3: the same sum in the same order), so the pointwise pass between the two sweep launches -- one
+  // more dependent launch on a chain that is all launch latency -- is not run; *split_div tells the caller that p2 was not formed.
+  if (split_div) {
+    *split_div = false;
+    if (d == 3 && !opt(OPT_SEPARATE_LAUNCHES) && !opt(OPT_GENERAL_KERNELS)) {
+      n = 0;
+      for (int c = 0; c < d; c++) {
+        job(op->mats[op->dims[c]], false, c, op->yL, op->yLx[1] + (size_t)c * N, a);
+        sp[n - 1].in_mode = IN_SUM3; sp[n - 1].in1 = op->yL + N; sp[n - 1].in2 = op->yL + 2 * N;
+      }
+      bool done = false;
+      SHIPCHK(sweep_launch_multi_try(n, m, sp, st, &done));
+      if (done) { *split_div = true; return 0; }
+    }
+  }
   hipLaunchKernelGGL(k_st_sum_fields, dim3(sgrid(N)), dim3(256), 0, st, N, d, (const double *)op->yL, op->p2);
   n = 0;
   for (int c = 0; c < d; c++) job(op->mats[op->dims[c]], false, c, op->p2, op->yLx[1] + (size_t)c * N, a);
@@ -951,7 +1012,6 @@ static void st_pressure_extrapolate(stokes_op *op, double *pL, hipStream_t st) {
 
 // pL (interior filled, boundary zero) -> boundary extrapolation -> gp[i] = DP[i] pL   (stokes.C:609-614)
 static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
-  const int d = op->d;
   // Lines of at most 256 points: gp[i] at an interior node needs the end values of ITS line along i only, and those are a
   // linear functional of the line's interior values (the other directions' extrapolations touch boundary lines, whose
   // gradients the scatter never reads): the extrapolation is part of the matrix (diffmat_create_pext) and the three passes
@@ -962,8 +1022,8 @@ static int st_pressure_gradient(stokes_op *op, hipStream_t st) {
     // (stokes_op_pencil_pressure).  Without pext, the end planes of pL the x pass would have filled only feed DP[1], DP[2]
     // on those planes, which the final scatter never reads.
     int rc = op->dim0(op->dim0_ctx, 1, 1, op->pL, nullptr, 1.0, op->gp[0], st); if (rc) return rc;
-    for (int i = 1; i < d; i++) { rc = sweep_plain(op, false, i, op->pL, op->gp[i], OUT_STORE, nullptr, 1.0, st, op->pext); if (rc) return rc; }
-    return 0;
+    const double *x[3] = {op->pL, op->pL, op->pL};
+    return sweeps_multi(op, false, 1, x, op->gp, 1.0, st, false, op->pext);
   }
   const double *x[3] = {op->pL, op->pL, op->pL};
   return sweeps_multi(op, false, 0, x, op->gp, 1.0, st, false, op->pext);
@@ -996,7 +1056,8 @@ extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, v
   const int d = op->d;
   st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
   if (st_uniform(op)) {
-    int rc = st_viscous_uniform(op, false, st); if (rc) return rc;
+    bool split = false;                                    // (no pressure rows here: whether div v was formed as p2 does not matter)
+    int rc = st_viscous_uniform(op, false, st, nullptr, 0.0, &split); if (rc) return rc;
     ST_OUT(d, (const int *)op->ixL, CDP(op->V[0]), CDP(op->V[1]), CDP(op->V[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(op->yLx[1]));
     SHIPCHK(hipGetLastError());
     return 0;
@@ -1025,6 +1086,7 @@ extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, 
   hipStream_t st = (hipStream_t)stream;
   const int d = op->d;
   st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
+  if (op->slab) op->gp[0] = op->V[0] + (size_t)op->d * op->N;
   int rc = st_pressure_gradient(op, st); if (rc) return rc;
   ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout, CDP(nullptr));
   SHIPCHK(hipGetLastError());
@@ -1041,12 +1103,17 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
   int rc;
   if (st_uniform(op)) {
-    if ((rc = st_viscous_uniform(op, true, st))) return rc;
-    st_out_full(op, nullptr, yG, st, op->V[0], op->V[1], op->V[2], op->yLx[1]);
+    bool split = false;
+    const bool pairs = st_out_pairs(op, op->V[0], op->V[1], op->V[2], op->yLx[1], nullptr, yG);
+    if ((rc = st_viscous_uniform(op, true, st, nullptr, 0.0, pairs ? &split : nullptr))) return rc;
+    st_out_full(op, nullptr, yG, st, op->V[0], op->V[1], op->V[2], op->yLx[1], split ? op->yL : nullptr);
     SHIPCHK(hipGetLastError());
     return 0;
   }
-  if (st_one_launch_gradients(op)) {
+  if (op->slab) {
+    if ((rc = st_gradient_and_pressure_gradient_slab(op, op->V, st))) return rc;                                                 // MatVP (:512) + :639
+    if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
+  } else if (st_one_launch_gradients(op)) {
     if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     if ((rc = st_gradient_and_pressure_gradient(op, op->V, st))) return rc;                                                      // MatVP (:512) + :639
     if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
@@ -1074,15 +1141,19 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
     if (!(op->eta_uniform && op->eta_value == 1.0)) hipLaunchKernelGGL(k_st_fill, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 1.0, op->eta);
     if (op->deta_nonzero) hipLaunchKernelGGL(k_st_fill, dim3(sgrid(op->N)), dim3(256), 0, st, op->N, 0.0, op->deta);
     op->eta_uniform = true; op->eta_value = 1.0; op->deta_nonzero = false; op->strain_stale = true;
-    int rc = st_viscous_uniform(op, true, st, op->xF, 1.0); if (rc) return rc;
-    st_out_full(op, op->force, yG, st, op->V[0], op->V[1], op->V[2], op->yLx[1]);                                                  // :750-756
+    bool split = false;
+    const bool pairs = st_out_pairs(op, op->V[0], op->V[1], op->V[2], op->yLx[1], op->force, yG);
+    int rc = st_viscous_uniform(op, true, st, op->xF, 1.0, pairs ? &split : nullptr); if (rc) return rc;
+    st_out_full(op, op->force, yG, st, op->V[0], op->V[1], op->V[2], op->yLx[1], split ? op->yL : nullptr);                        // :750-756
     SHIPCHK(hipGetLastError());
     return 0;
   }
   op->strain_stale = false;                               // the node loop below leaves the strain as state
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
-  if (st_one_launch_gradients(op)) {
+  if (op->slab) {
+    int rc = st_gradient_and_pressure_gradient_slab(op, op->strain, st); if (rc) return rc;                                      // :747, :701
+  } else if (st_one_launch_gradients(op)) {
     if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     int rc = st_gradient_and_pressure_gradient(op, op->strain, st); if (rc) return rc;                                           // :747, :701
   } else {

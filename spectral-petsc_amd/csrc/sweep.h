@@ -10,7 +10,9 @@ enum InMode : int {
   IN_PLAIN = 0,     // v = in0[a]
   IN_GATHER = 1,    // v = interior ? in0_global[g] : 0            (VecScatter GL + dirichlet0, elliptic.C:305-308)
   IN_FLUX_ETA = 2,  // v = in1[a] * in0[a]                         (eta * g, elliptic.C:511)
-  IN_FLUX_FULL = 3  // v = in1[a]*in0[a] + in2[a]*in3[a]*in4[a]    (eta*g + deta*u*du0, elliptic.C:321)
+  IN_FLUX_FULL = 3, // v = in1[a]*in0[a] + in2[a]*in3[a]*in4[a]    (eta*g + deta*u*du0, elliptic.C:321)
+  IN_SUM3 = 4       // v = (in0[a] + in1[a]) + in2[a]              (lines of at most 64 points, 16-byte kernels only: the
+                    //   divergence of the uniform-viscosity Stokes path as the sum of its three terms, stokes.hip)
 };
 
 // What happens to one element r of the derivative on store.

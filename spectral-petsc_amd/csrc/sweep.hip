@@ -488,6 +488,7 @@ static hipError_t launch_long(const SweepParams &p, hipStream_t stream) {
 }
 
 hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
+  if (p.in_mode == IN_SUM3) return hipErrorInvalidValue;    // exists in the multi-job launch of short lines only (sweep_vec.hip)
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym;
   p.longDT = m.longDT; p.longD = m.longD;
   if (m.KS == 0) {

@@ -45,7 +45,7 @@ constexpr int vec_lds_doubles() {
 }
 
 // Body of cheb_sweep_vec_kernel: workgroup BID of NBLK (the launch's, or those of one job of a multi-job launch)
-template <int KS, bool JFAST>
+template <int KS, bool JFAST, bool SUM3 = false>
 __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
@@ -117,6 +117,11 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
         const bool ok = cv && jp < H;
         rj[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
         rm[s] = *((ok && nn - jp != jp) ? (const d2 *)(p.in0 + (top - rel)) : zero2);
+        if (SUM3) {                                           // IN_SUM3: (in0 + in1) + in2, the order of the pointwise sum it replaces
+          const d2 j1 = *(ok ? (const d2 *)(p.in1 + (base + rel)) : zero2), m1 = *((ok && nn - jp != jp) ? (const d2 *)(p.in1 + (top - rel)) : zero2);
+          const d2 j2 = *(ok ? (const d2 *)(p.in2 + (base + rel)) : zero2), m2 = *((ok && nn - jp != jp) ? (const d2 *)(p.in2 + (top - rel)) : zero2);
+          rj[s] = (rj[s] + j1) + j2; rm[s] = (rm[s] + m1) + m2;
+        }
       }
     } else {
       const int j = 2 * ld_a;                               // points j, j+1 and their mirrors n-j-1, n-j
@@ -127,6 +132,11 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
         const u32 base = (ok ? c : 0u) * lineLen;
         rj[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
         rm[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
+        if (SUM3) {
+          const d2 j1 = *(ok ? (const d2 *)(p.in1 + (base + (u32)j)) : zero2), m1 = *(ok ? (const d2 *)(p.in1 + (base + (u32)(nn - j - 1))) : zero2);
+          const d2 j2 = *(ok ? (const d2 *)(p.in2 + (base + (u32)j)) : zero2), m2 = *(ok ? (const d2 *)(p.in2 + (base + (u32)(nn - j - 1))) : zero2);
+          rj[s] = (rj[s] + j1) + j2; rm[s] = (rm[s] + m1) + m2;
+        }
       }
     }
   };
@@ -724,7 +734,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
 constexpr int MULTI_MAX = 9;
 struct MultiParams { int njobs; unsigned bstart[MULTI_MAX + 1]; SweepParams job[MULTI_MAX]; };
 
-template <int KS>
+template <int KS, bool SUM3 = false>
 __global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams mp) {
   constexpr int LDS = vec_lds_doubles<KS, true>() > vec_lds_doubles<KS, false>() ? vec_lds_doubles<KS, true>() : vec_lds_doubles<KS, false>();
   __shared__ double smem[LDS];
@@ -733,9 +743,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams
   const SweepParams &p = mp.job[j];
   const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
   if (p.inner < 16) {
-    if constexpr (KS >= 16) vec4_body<KS, true, false>(p, smem, bid, nblk); else vec1_body<KS, true>(p, smem, bid, nblk);
+    if constexpr (KS >= 16) vec4_body<KS, true, false>(p, smem, bid, nblk); else vec1_body<KS, true, SUM3>(p, smem, bid, nblk);
   } else {
-    if constexpr (KS >= 16) vec4_body<KS, false, false>(p, smem, bid, nblk); else vec1_body<KS, false>(p, smem, bid, nblk);
+    if constexpr (KS >= 16) vec4_body<KS, false, false>(p, smem, bid, nblk); else vec1_body<KS, false, SUM3>(p, smem, bid, nblk);
   }
 }
 
@@ -823,6 +833,10 @@ static bool prepare_ok_t(SweepParams p, bool jfast) { return (jfast ? prepare_v<
 
 bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   const SweepParams &p = p0;
+  if (p.in_mode == IN_SUM3) {                            // multi-job launches of short lines only (launch_multi_t)
+    auto al16 = [](const void *q) { return q && ((size_t)q & 15) == 0; };
+    if (m.KS > 8 || p.out_mode != OUT_STORE || p.raw || p.in_fblocks || p.qmax || p.in_os || !al16(p.in1) || !al16(p.in2)) return false;
+  } else
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
   const bool jfast = p.inner < 16;
   if (p.in_fblocks && (m.KS < 16 || (p.in_fskip & 1))) return false;
@@ -853,6 +867,7 @@ bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p0) {
 }
 
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
+  if (p.in_mode == IN_SUM3) return hipErrorInvalidValue;   // exists in the multi-job launch only
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_v<4, true>(p, stream) : launch_v<4, false>(p, stream);
@@ -868,6 +883,9 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
 template <int KS>
 static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done) {
   for (int j = 0; j < n; j++) if (jobs[j].raw) { *done = false; return hipSuccess; }
+  bool sum3 = jobs[0].in_mode == IN_SUM3;                  // all jobs or none (stokes.hip: the three sweeps of grad div v)
+  for (int j = 1; j < n; j++) if ((jobs[j].in_mode == IN_SUM3) != sum3) { *done = false; return hipSuccess; }
+  if (sum3 && KS > 8) { *done = false; return hipSuccess; }
   MultiParams mp = {};
   mp.njobs = n;
   hipError_t cu_err; int ncu = sweep_num_cus(&cu_err);
@@ -912,7 +930,10 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
   for (int j = 0; j < n; j++) { mp.bstart[j] = b; b += gs[j]; mp.job[j] = jobs[j]; }
   mp.bstart[n] = b;
   if (b == 0) { *done = true; return hipSuccess; }
-  hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
+  if constexpr (KS <= 8) {
+    if (sum3) hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS, true>), dim3(b), dim3(512), 0, stream, mp);
+    else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
+  } else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
   sweep_note_launch();
   *done = true;
   return hipGetLastError();

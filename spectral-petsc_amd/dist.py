@@ -409,7 +409,7 @@ class DistStokesOp(_SlabPencil):
     (1 field there and back)."""
 
     def __init__(self, dims, sp, group=None):
-        self._setup(dims, sp, group, len(dims))
+        self._setup(dims, sp, group, len(dims) + 1)
         r = self.rank
         self.op = sp.StokesOp(self.dims, slab=(self.s0[r], self.s0[r + 1]), dim0=self._dim0)
         for name in ("global_size", "velocity_size", "pressure_size", "dirichlet_size", "local_nodes", "interior_nodes"):
@@ -418,8 +418,12 @@ class DistStokesOp(_SlabPencil):
     def _pencil(self, kind, nf):
         if kind == 0:
             self.op.pencil_sweep(nf, self.ncol, self.pen_in, self.pen_out)
-        else:
+        elif kind == 1:
             self.op.pencil_pressure(self.ncol, self.pen_in, self.pen_out)
+        else:                          # kind 2: nf - 1 velocity fields and the pressure field in one round trip
+            self.op.pencil_sweep(nf - 1, self.ncol, self.pen_in, self.pen_out)
+            off = (nf - 1) * self.Np
+            self.op.pencil_pressure(self.ncol, self.pen_in[off:off + self.Np], self.pen_out[off:off + self.Np])
 
     def mult(self, x, y):
         return self.op.mult(x, y)
