@@ -202,6 +202,9 @@ int stokes_op_set_state(stokes_op *op, int which, const double *src_host);
  * pieces, dimension 0 being outermost).  Everything along dimension 0 is delegated to `dim0`:
  *   kind 0: out = (acc ? acc : 0) + alpha * D_0 in   for nfields stacked slab fields of N nodes each
  *   kind 1: out = D_0 (x-line pressure extrapolation of in)              (one field; stokes.C:1064-1074, :611)
+ *   kind 2: the first nfields - 1 fields as kind 0 (acc NULL, alpha 1), the LAST field as kind 1: the velocity gradient and the
+ *           pressure gradient of a StokesMatMult / StokesFunction along dimension 0 in ONE round trip (the fields are stacked:
+ *           the handle keeps the pressure behind the velocity, and the pressure gradient behind the velocity gradient)
  * The driver (spectral-petsc_amd/dist.py) implements it as transpose -> pencil call below -> transpose.
  * All other entry points (mult, mult_vv/pv/vp, function, set_*, get/set_state) work unchanged on the slab. */
 typedef int (*stokes_dim0_fn)(void *ctx, int kind, int nfields, const double *in_dev, const double *acc_dev,

@@ -15,6 +15,9 @@
 //   * the tile loop is straight-line code, so that hipcc can count vmcnt exactly: coefficient and accumulator loads
 //     are issued inside the chain whose epilogue uses them, the next tile's input rides under three chains.
 // fused.hip stays for short lines (KS < 16), odd extents, d = 1 and the slab mode.
+// (Round 4 tried 16-byte pieces for the stored gradient and w0 of the strided FormFunction launches -- the lane exchange the result
+// stores use, 8 DPP broadcasts + selects per sub-tile in place of 8 of the 16 store instructions: FormFunction 256^3 507-512 us
+// against 494-510 us with the 8-byte stores, A/B in one process.  The stores were not what the launch waits for; removed.)
 #include "sweep.h"
 #include <type_traits>
 
@@ -45,10 +48,7 @@ constexpr int f4_lds_doubles() {
 
 #define AO4(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
 
-// G16 (COLFAST FormFunction launches): the stored gradient -- and, TRIMF, the local copy w0 -- leave as 16-byte pieces after the
-// lane exchange the result stores use, instead of 8 bytes per lane (the x launch of FormFunction writes 24 B/point, two thirds
-// of it through these stores)
-template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ, bool TRIMF, bool G16 = false>
+template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ, bool TRIMF>
 __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) {
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
@@ -74,7 +74,6 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   static_assert(!JFAST || ACC, "the contiguous direction is never the first one");
   static_assert(!ETASQ || !FULL, "eta = 1 + gamma u^2 formed on chip: FormFunction only (the line being differentiated is u)");
   static_assert(!TRIMF || (ETASQ && !WIN && !FULL), "FormFunction on the interior line space: eta on chip, homogeneous Dirichlet rows");
-  static_assert(!G16 || (!JFAST && !FULL), "16-byte gradient stores: the strided FormFunction launches");
 
   __shared__ double smem[f4_lds_doubles<KS, JFAST>()];
   double *inE = smem, *inO = smem + LDS_ELEMS, *fE_ = smem + 2 * LDS_ELEMS, *fO_ = smem + 3 * LDS_ELEMS;
@@ -177,14 +176,6 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
     }
   }
 
-  u32 g_hi[2], g_lo[2];                               // G16: rows i0 + 4 (2 rp + odd) of the gradient, columns (l16e, l16e + 1)
-#pragma unroll
-  for (int rp = 0; rp < 2; rp++) {
-    const int i = i0 + 4 * (2 * rp + (odd ? 1 : 0)); const bool ok = i < H;
-    g_hi[rp] = (G16 && ok) ? (u32)l16e * 8u + (u32)i * c_rs : INVALID;
-    g_lo[rp] = (G16 && ok) ? (u32)l16e * 8u + (u32)(nn - i) * c_rs : INVALID;
-  }
-
   // LDS index of (row, line) of sub-tile 0 for r = 0; r adds 4 NT (COLFAST) / 4 LDJ (JFAST), the sub-tile 16 lines
   const int f_r = JFAST ? 4 * LDJ : 4 * NT;
   auto f_idx0 = [&](int sub) -> int {
@@ -222,21 +213,8 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
       for (int r = 0; r < 4; r++) { ue[r] = inE[f0 + r * f_r]; uo[r] = inO[f0 + r * f_r]; }
     }
   };
-  auto bce = [](double v) {                            // value of the even lane of each pair, in both lanes (DPP quad_perm [0,0,2,2])
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xA0, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xA0, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-  };
-  auto bco = [](double v) {                            // ... of the odd lane ([1,1,3,3])
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-  };
-  // rows (2 rp, 2 rp + 1) of four per-lane values -> the 16-byte piece this lane owns after the exchange (as in epi2)
-  auto pair16 = [&](double a, double b) -> d2 { const double be = bce(b), ao = bco(a); return d2{odd ? be : a, odd ? b : ao}; };
   auto epi1 = [&](int sub, const v4d &ce, const v4d &co) {
     const int f0 = f_idx0(sub);
-    double g_i[G16 ? 4 : 1], g_m[G16 ? 4 : 1], w_i[(G16 && TRIMF) ? 4 : 1], w_m[(G16 && TRIMF) ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const double gi = ce[r] + co[r], gm = co[r] - ce[r];              // D is centro-antisymmetric
@@ -246,18 +224,14 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
         fi = __builtin_fma(cv_hi[r].y, ue[r] + uo[r], cv_hi[r].x * gi);
         fm = __builtin_fma(cv_lo[r].y, ue[r] - uo[r], cv_lo[r].x * gm);
       } else {
-        if constexpr (G16) { g_i[r] = gi; g_m[r] = gm; }
-        else {
-          st8(r_gout, k_hi[r] + tv1[JFAST ? r : 0], gi);                // c->gradu[k], elliptic.C:498
-          st8(r_gout, k_lo[r] + tv1[JFAST ? r : 0], gm);
-        }
+        st8(r_gout, k_hi[r] + tv1[JFAST ? r : 0], gi);                  // c->gradu[k], elliptic.C:498
+        st8(r_gout, k_lo[r] + tv1[JFAST ? r : 0], gm);
         if constexpr (ETASQ) {
           // eta = 1 + gamma u^2 (elliptic.C:508 with the default exponent) from the u the tile image holds (2 u_i = e + o,
           // 2 u_{n-i} = e - o): two multiply-adds instead of 8 bytes from HBM per value -- a byte costs the package about
           // twenty times what a flop does
           const double si = ue[r] + uo[r], sm = ue[r] - uo[r];
-          if constexpr (TRIMF && G16) { w_i[r] = 0.5 * si; w_m[r] = 0.5 * sm; }
-          else if constexpr (TRIMF) {                                      // w0 = the line itself (2 u_i = e + o); dropped when w0out is null
+          if constexpr (TRIMF) {                                           // w0 = the line itself (2 u_i = e + o); dropped when w0out is null
             st8(r_w0, k_hi[r] + tv1[JFAST ? r : 0], 0.5 * si);
             st8(r_w0, k_lo[r] + tv1[JFAST ? r : 0], 0.5 * sm);
           }
@@ -266,17 +240,6 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
       }
       fE_[f0 + r * f_r] = fi + fm;
       fO_[f0 + r * f_r] = fi - fm;
-    }
-    if constexpr (G16) {                                               // the exchanges run with every lane active (DPP), the masks are in the offsets
-#pragma unroll
-      for (int rp = 0; rp < 2; rp++) {
-        st16(r_gout, g_hi[rp] + tv1[0], pair16(g_i[2 * rp], g_i[2 * rp + 1]));
-        st16(r_gout, g_lo[rp] + tv1[0], pair16(g_m[2 * rp], g_m[2 * rp + 1]));
-        if constexpr (TRIMF) {
-          st16(r_w0, g_hi[rp] + tv1[0], pair16(w_i[2 * rp], w_i[2 * rp + 1]));
-          st16(r_w0, g_lo[rp] + tv1[0], pair16(w_m[2 * rp], w_m[2 * rp + 1]));
-        }
-      }
     }
   };
 
@@ -482,15 +445,6 @@ bool fused4_eligible(const DiffMat &m) { return (m.KS == 16 || m.KS == 32) && (m
 
 template <int KS, bool JFAST, bool FULL, bool ACC, bool WIN, bool ETASQ = false, bool TRIMF = false>
 static hipError_t launch4(const Fused4Params &p, unsigned grid, hipStream_t stream) {
-  if constexpr (!JFAST && !FULL) {
-    // 16-byte gradient stores where every piece is 16-byte aligned (the arrays of the handle are; see ell_state_layout)
-    auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
-    if (p.gout && al(p.gout) && (!(TRIMF && p.w0out) || al(p.w0out)) && !((p.gc.os | p.gc.rs) & 1) && !(p.qmax & 1)) {
-      hipLaunchKernelGGL((cheb_fused4_kernel<KS, JFAST, FULL, ACC, WIN, ETASQ, TRIMF, true>), dim3(grid), dim3(512), 0, stream, p);
-      sweep_note_launch();
-      return hipGetLastError();
-    }
-  }
   hipLaunchKernelGGL((cheb_fused4_kernel<KS, JFAST, FULL, ACC, WIN, ETASQ, TRIMF>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
