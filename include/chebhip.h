@@ -186,6 +186,16 @@ int stokes_op_mult_vp(stokes_op *op, const double *pG_dev, double *vG_out_dev, v
  * (restart 30, rtol 1e-5, atol 1e-50, max_it 10000, zero initial guess), see chebhip_fgmres_* below. */
 int stokes_op_mult_schur(stokes_op *op, const double *pG_dev, double *pG_out_dev,
                          chebhip_apply_fn inner_solve, void *inner_ctx, void *stream);
+/* The same four applies on COMPONENT-MAJOR velocity vectors (component c of interior node n at c * I + n instead of the
+ * reference's n * d + c): the layout the block preconditioners keep for their inner Krylov solves (stokes_saddle_*), in which a
+ * velocity vector is d stacked scalar fields for MatVVPC's line transforms too -- no (de)interleaving pass per inner iteration.
+ * No counterpart in the reference (its vectors are node-major throughout, stokes.C:284-290); pressure vectors are unaffected.
+ * stokes_op_mult_schur_cm requires inner_solve, which receives and returns component-major vectors. */
+int stokes_op_mult_vv_cm(stokes_op *op, const double *v_cm_dev, double *v_cm_out_dev, void *stream);
+int stokes_op_mult_pv_cm(stokes_op *op, const double *v_cm_dev, double *pG_out_dev, void *stream);
+int stokes_op_mult_vp_cm(stokes_op *op, const double *pG_dev, double *v_cm_out_dev, void *stream);
+int stokes_op_mult_schur_cm(stokes_op *op, const double *pG_dev, double *pG_out_dev,
+                            chebhip_apply_fn inner_solve_cm, void *inner_ctx, void *stream);
 int stokes_op_set_inner_solver(stokes_op *op, int restart, double rtol, double atol, int max_it);
 int stokes_op_inner_iterations(const stokes_op *op);   /* MatVV applies of the last built-in inner solve */
 /* Slab mode: the built-in inner solve runs on distributed velocity vectors (see chebhip_fgmres_set_reduce). */
@@ -366,6 +376,9 @@ int chebhip_fdpc_set_sweeps(chebhip_fdpc *pc, int sweeps);  /* inner GMRES steps
 int chebhip_fdpc_mult(chebhip_fdpc *pc, const double *x_dev, double *y_dev, void *stream);
 /* z ~= P^-1 r.  Shape of chebhip_apply_fn with ctx = the handle: pass as the M of chebhip_fgmres_solve. */
 int chebhip_fdpc_apply(void *pc, const double *r_dev, double *z_dev, void *stream);
+/* The same for a Stokes velocity preconditioner (stokes_pc_create*) on component-major vectors (stokes_op_mult_vv_cm): the fast
+ * diagonalisation z = P_1^-1 (r / eta) (sweeps = 0) only. */
+int chebhip_fdpc_apply_cm(void *pc, const double *r_cm_dev, double *z_cm_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* The block preconditioners of the Stokes saddle-point system:  */
@@ -427,6 +440,11 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
  *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array
  *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read
+ *   saddle_node_major     1: the block preconditioners (stokes_saddle_*) keep the vectors of their inner velocity solves node-major as
+ *                            the reference does, with a (de)interleaving pass around every MatVVPC solve (read at create; A/B)
+ *   modal_scale_pass      1: the fast-diagonalisation solve of the finite-difference preconditioners divides by the modal sums in a
+ *                            pass of its own instead of multiplying by their reciprocals in the store of the last forward line
+ *                            transform (A/B; the two differ in the last bit)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

@@ -38,12 +38,12 @@ ABI_SYMBOLS = [
     "ell_op_create_slab", "ell_op_pencil_sweep",
     "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
     "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
-    "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_function", "stokes_op_get_state",
+    "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_mult_vv_cm", "stokes_op_mult_pv_cm", "stokes_op_mult_vp_cm", "stokes_op_mult_schur_cm", "stokes_op_function", "stokes_op_get_state",
     "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations", "stokes_op_set_inner_reduce",
     "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
     "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason", "chebhip_fgmres_set_reduce",
     "ell_pc_create", "stokes_pc_create", "chebhip_fdpc_destroy", "chebhip_fdpc_update", "chebhip_fdpc_set_sweeps",
-    "chebhip_fdpc_mult", "chebhip_fdpc_apply",
+    "chebhip_fdpc_mult", "chebhip_fdpc_apply", "chebhip_fdpc_apply_cm",
     "stokes_saddle_create", "stokes_saddle_destroy", "stokes_saddle_set_type", "stokes_saddle_set_inner",
     "stokes_saddle_setup", "stokes_saddle_apply", "stokes_saddle_iterations", "stokes_saddle_set_pc_sweeps", "stokes_saddle_set_schur_jacobi",
     "chebhip_timers_enable", "chebhip_timers_reset", "chebhip_timers_read", "chebhip_stage_name",
@@ -126,8 +126,10 @@ def lib():
         L.stokes_op_set_rheology.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.stokes_op_set_dirichlet.argtypes = [vp, dp]
         L.stokes_op_set_force.argtypes = [vp, dp]
-        for f in (L.stokes_op_mult, L.stokes_op_mult_vv, L.stokes_op_mult_pv, L.stokes_op_mult_vp, L.stokes_op_function):
+        for f in (L.stokes_op_mult, L.stokes_op_mult_vv, L.stokes_op_mult_pv, L.stokes_op_mult_vp, L.stokes_op_function,
+                  L.stokes_op_mult_vv_cm, L.stokes_op_mult_pv_cm, L.stokes_op_mult_vp_cm):
             f.argtypes = [vp, vp, vp, vp]
+        L.stokes_op_mult_schur_cm.argtypes = [vp, vp, vp, vp, vp, vp]
         L.stokes_op_get_state.argtypes = [vp, C.c_int, dp]
         L.stokes_op_set_state.argtypes = [vp, C.c_int, dp]
         L.stokes_op_create_slab.argtypes = [C.c_int, ip, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
@@ -153,6 +155,7 @@ def lib():
         L.chebhip_fdpc_set_sweeps.argtypes = [vp, C.c_int]
         L.chebhip_fdpc_mult.argtypes = [vp, vp, vp, vp]
         L.chebhip_fdpc_apply.argtypes = [vp, vp, vp, vp]
+        L.chebhip_fdpc_apply_cm.argtypes = [vp, vp, vp, vp]
         L.stokes_saddle_create.argtypes = [vp, C.POINTER(vp)]
         L.stokes_saddle_destroy.argtypes = [vp]
         L.stokes_saddle_set_type.argtypes = [vp, C.c_int]
@@ -532,6 +535,17 @@ class StokesOp:
     def mult_vp(self, p, vout):
         return self._call(lib().stokes_op_mult_vp, p, self.pressure_size, vout, self.velocity_size)
 
+    # the same on component-major velocity vectors (component c of interior node n at c * I + n): the layout of the block
+    # preconditioners' inner solves
+    def mult_vv_cm(self, v, out):
+        return self._call(lib().stokes_op_mult_vv_cm, v, self.velocity_size, out, self.velocity_size)
+
+    def mult_pv_cm(self, v, pout):
+        return self._call(lib().stokes_op_mult_pv_cm, v, self.velocity_size, pout, self.pressure_size)
+
+    def mult_vp_cm(self, p, vout):
+        return self._call(lib().stokes_op_mult_vp_cm, p, self.pressure_size, vout, self.velocity_size)
+
     def pencil_sweep(self, nfields, ncol, inp, out):
         _chk(lib().stokes_op_pencil_sweep(self._h, nfields, ncol, inp.data_ptr(), out.data_ptr(), _stream()))
         return out
@@ -648,6 +662,11 @@ class FdPc:
 
     def apply(self, r, z):
         _chk(lib().chebhip_fdpc_apply(self._h, _dev_ptr(r, self.n), _dev_ptr(z, self.n), _stream()))
+        return z
+
+    def apply_cm(self, r, z):
+        """MatVVPC solve on component-major velocity vectors (StokesOp.mult_vv_cm), sweeps = 0."""
+        _chk(lib().chebhip_fdpc_apply_cm(self._h, _dev_ptr(r, self.n), _dev_ptr(z, self.n), _stream()))
         return z
 
     def destroy(self):

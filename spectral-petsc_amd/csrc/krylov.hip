@@ -6,7 +6,7 @@
 // stay in HBM, the Hessenberg matrix and its Givens rotations too; per iteration the host reads one double
 // (the residual estimate, from pinned memory) and it does so one iteration late, so the device never idles.
 //   w = A M v_j;  h = V^T w (classical Gram-Schmidt, one pass -- PETSc's default orthogonalisation);
-//   w -= V h;  h_{j+1,j} = |w|;  Givens rotations and the triangular solve on the host.
+//   w -= V h;  h_{j+1,j} = |w|;  Givens rotations and the triangular solve on the device (one thread).
 // Reductions are two-stage with a fixed block order: results do not depend on scheduling.
 #include "../../include/chebhip.h"
 #include "timers.h"
@@ -58,8 +58,12 @@ __global__ __launch_bounds__(RT) void k_multidot(long n, const double *__restric
 
 // The same for k rows with w read once per group of KB rows instead of once per row (the orthogonalisation of restarted
 // GMRES is the largest mover of bytes in a preconditioned solve at 256^3): block (b, g) forms the partial sums of the rows
-// g KB .. g KB + KB - 1 over chunk b.  Every sum runs over the same elements in the same order as in k_multidot.
+// g KB .. g KB + KB - 1 over chunk b, in a fixed order (results do not depend on scheduling).
 constexpr int KB = 8;
+// V2: 16-byte loads (n even, every row and w 16-B aligned: ld is even, the basis allocation aligned).  A thread then carries two
+// partial sums per row, over the even and the odd elements of its stride, added at the end -- a different but equally fixed order.
+// (8-byte loads: the inner solves of the Stokes preconditioners, 2..5 rows of 50 MB at 128^3, ran this kernel at 3.8 TB/s.)
+template <bool V2>
 __global__ __launch_bounds__(ST) void k_multidot_grouped(long n, int k, const double *__restrict__ V, long ldv, const double *__restrict__ w,
                                                          double *__restrict__ part) {
   __shared__ double sh[ST / 64];
@@ -71,7 +75,27 @@ __global__ __launch_bounds__(ST) void k_multidot_grouped(long n, int k, const do
   double s[KB];
 #pragma unroll
   for (int q = 0; q < KB; q++) s[q] = 0.0;
-  if (cnt == KB) {
+  if (V2) {
+    double t[KB];
+#pragma unroll
+    for (int q = 0; q < KB; q++) t[q] = 0.0;
+    const long n2 = n >> 1;
+    if (cnt == KB) {
+      for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n2; i += (long)RB * ST) {
+        const double2 wi = ((const double2 *)w)[i];
+#pragma unroll
+        for (int q = 0; q < KB; q++) { const double2 a = ((const double2 *)v[q])[i]; s[q] += a.x * wi.x; t[q] += a.y * wi.y; }
+      }
+    } else {
+      for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n2; i += (long)RB * ST) {
+        const double2 wi = ((const double2 *)w)[i];
+#pragma unroll
+        for (int q = 0; q < KB; q++) if (q < cnt) { const double2 a = ((const double2 *)v[q])[i]; s[q] += a.x * wi.x; t[q] += a.y * wi.y; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KB; q++) s[q] += t[q];
+  } else if (cnt == KB) {
     for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
       const double wi = w[i];
 #pragma unroll
@@ -129,18 +153,28 @@ __global__ __launch_bounds__(ST) void k_orth_update(long n, int k, const double 
   if (threadIdx.x == 0) npart[blockIdx.x] = r;
 }
 
-// Column j of the Hessenberg matrix on the device: h_{j+1,j} = sqrt(sum npart), the previous Givens rotations,
-// the new one, the rotated right-hand side G_{j+1} (a fresh copy: iterations issued speculatively beyond the
-// converged one must not disturb what the solve reads), the residual estimate for the host (pinned memory)
-// and 1 / h_{j+1,j} for the normalisation of the new basis vector.
-__global__ __launch_bounds__(RT) void k_givens(int j, int m, const double *__restrict__ npart, const double *__restrict__ hcol,
-                                               double *__restrict__ H, double *__restrict__ cs, double *__restrict__ sn,
-                                               double *__restrict__ G, double *__restrict__ inv, double *__restrict__ res,
-                                               const double *__restrict__ nsq) {
+// Column j of the Hessenberg matrix on the device and the normalisation of the new basis vector, ONE launch (round 4: two;
+// the inner solves of the Stokes preconditioners are a few iterations of dependent 5-us kernels each):
+//   every block: h_{j+1,j} = sqrt(sum npart) -- the same 256 partials summed in the same order by every block, so every block
+//   holds the same value -- and w *= 1 / h_{j+1,j} on its share of w (scale = 0: the basis vector will not be used, skip);
+//   block 0, thread 0: the previous Givens rotations, the new one, the rotated right-hand side G_{j+1} (a fresh copy: iterations
+//   issued speculatively beyond the converged one must not disturb what the solve reads), the residual estimate for the host
+//   (pinned memory).  A zero or non-finite h_{j+1,j} (breakdown: the column is dropped by the host) scales by 0.
+__global__ __launch_bounds__(RT) void k_givens_scale(int j, int m, const double *__restrict__ npart, const double *__restrict__ hcol,
+                                                     double *__restrict__ H, double *__restrict__ cs, double *__restrict__ sn,
+                                                     double *__restrict__ G, double *__restrict__ res,
+                                                     const double *__restrict__ nsq, long n, double *__restrict__ w, int scale) {
   __shared__ double sh[RT / 64];
+  __shared__ double hn;
   const double ss = npart ? block_sum(npart[threadIdx.x], sh) : 0.0;
-  if (threadIdx.x != 0) return;
-  const double hnext = sqrt(npart ? ss : nsq[0]);   // nsq: |w|^2 summed over the ranks by the reduction callback
+  if (threadIdx.x == 0) hn = sqrt(npart ? ss : nsq[0]);   // nsq: |w|^2 summed over the ranks by the reduction callback
+  __syncthreads();
+  const double hnext = hn;
+  if (scale) {
+    const double f = (hnext > 0.0 && hnext <= 1.7976931348623157e308) ? 1.0 / hnext : 0.0;
+    for (long i = blockIdx.x * (long)RT + threadIdx.x; i < n; i += (long)gridDim.x * RT) w[i] *= f;
+  }
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double *hc = H + (long)j * (m + 1);
   for (int i = 0; i <= j; i++) hc[i] = hcol[i];
   hc[j + 1] = hnext;
@@ -152,13 +186,12 @@ __global__ __launch_bounds__(RT) void k_givens(int j, int m, const double *__res
   const double *g0 = G + (long)j * (m + 2);
   double *g1 = G + (long)(j + 1) * (m + 2);
   for (int i = 0; i < j; i++) g1[i] = g0[i];
-  if (den == 0.0 || !(den == den)) { res[j] = nan(""); inv[0] = 0.0; return; }
+  if (den == 0.0 || !(den == den)) { res[j] = nan(""); return; }
   const double c = hc[j] / den, s_ = hc[j + 1] / den;
   cs[j] = c; sn[j] = s_;
   hc[j] = den; hc[j + 1] = 0.0;
   g1[j] = c * g0[j]; g1[j + 1] = -s_ * g0[j];
   res[j] = fabs(g1[j + 1]);
-  inv[0] = 1.0 / hnext;
 }
 
 // y = R^{-1} g for the leading kk columns (R upper triangular, column-major with leading dimension m + 1)
@@ -171,12 +204,6 @@ __global__ void k_trisolve(int kk, int m, const double *__restrict__ H, const do
   }
 }
 
-// w *= *a  (a on the device)
-__global__ void k_scale_dev(long n, const double *__restrict__ a, double *__restrict__ w) {
-  const double f = a[0];
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) w[i] *= f;
-}
-
 __global__ void k_set1(double *__restrict__ p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 
 // y = a * x        (a read from the host value)
@@ -184,10 +211,11 @@ __global__ void k_scale(long n, double a, const double *x, double *y) {   // x =
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = a * x[i];
 }
 
-// x += sum_{kk<k} y[kk] Z[kk]
-__global__ void k_multiaxpy(long n, int k, const double *__restrict__ Z, long ldz, const double *__restrict__ y, double *__restrict__ x) {
+// x = (fresh ? 0 : x) + sum_{kk<k} y[kk] Z[kk]      (fresh: x has not been written yet -- a zero initial guess that is never
+// stored: 0 + a is a, so the sum has the bits of the accumulate on a cleared x)
+__global__ void k_multiaxpy(long n, int k, const double *__restrict__ Z, long ldz, const double *__restrict__ y, double *__restrict__ x, int fresh) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    double s = x[i];
+    double s = fresh ? 0.0 : x[i];
     for (int kk = 0; kk < k; kk++) s += y[kk] * Z[(long)kk * ldz + i];
     x[i] = s;
   }
@@ -208,7 +236,7 @@ struct chebhip_fgmres {
   double rtol = 1e-5, atol = 1e-50; // KSP defaults
   int max_it = 10000;
   double *V = nullptr, *Z = nullptr, *part = nullptr, *npart = nullptr, *hcol = nullptr, *ydev = nullptr;
-  double *H = nullptr, *cs = nullptr, *sn = nullptr, *G = nullptr, *inv = nullptr;
+  double *H = nullptr, *cs = nullptr, *sn = nullptr, *G = nullptr;
   double *res = nullptr;            // pinned, written by the device: residual estimate after iteration j
   std::vector<hipEvent_t> ev;
   chebhip_reduce_fn reduce = nullptr;   // several ranks: sums device doubles over the ranks, in place, stream-ordered
@@ -220,7 +248,7 @@ struct chebhip_fgmres {
 
 extern "C" int chebhip_fgmres_destroy(chebhip_fgmres *k) {
   if (!k) return 0;
-  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->inv, k->nsq};
+  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->nsq};
   for (double *p : dev) if (p) (void)hipFree(p);
   if (k->res) (void)hipHostFree(k->res);
   for (hipEvent_t e : k->ev) (void)hipEventDestroy(e);
@@ -252,7 +280,6 @@ extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) 
   KC(hipMalloc((void **)&k->cs, (size_t)m * sizeof(double)));
   KC(hipMalloc((void **)&k->sn, (size_t)m * sizeof(double)));
   KC(hipMalloc((void **)&k->G, (size_t)(m + 1) * (m + 2) * sizeof(double)));
-  KC(hipMalloc((void **)&k->inv, sizeof(double)));
   KC(hipMalloc((void **)&k->nsq, sizeof(double)));
   KC(hipHostMalloc((void **)&k->res, (size_t)(m + 2) * sizeof(double)));
   k->ev.assign(m, nullptr);
@@ -308,25 +335,33 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
   double bnorm = 0.0;
   int rc = dev_norm(k, b, st, &bnorm); if (rc) return rc;
   const double tol = std::fmax(k->rtol * bnorm, k->atol);
-  if (!x_nonzero && n > 0) KHIPCHK(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), st));
+  // A zero initial guess is not written: x stays untouched until the first update stores it (k_multiaxpy, fresh), or until the
+  // solve ends without one -- clear_x on those paths.  One pass over x less per solve; the inner solves of the Stokes
+  // preconditioners (stokes.C:328-341: 1..4 iterations each) are a few dozen vector passes in all.
+  bool x_unset = !x_nonzero;
+  auto clear_x = [&]() -> int {
+    if (x_unset && n > 0) KHIPCHK(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), st));
+    x_unset = false; return 0;
+  };
   bool first = true;
   for (;;) {
     // r = b - A x  into V[0]
     double *r = k->V;
-    if (first && !x_nonzero) { if (n > 0) KHIPCHK(hipMemcpyAsync(r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st)); }
+    double beta = 0.0;
+    const double *rsrc = r;
+    if (first && !x_nonzero) { beta = bnorm; rsrc = b; }      // r = b: its norm is known, and V[0] = b / |b| is formed from b itself
     else {
       if ((rc = A(actx, x, r, st))) return rc;
       hipLaunchKernelGGL(k_residual, dim3(pgrid(n)), dim3(256), 0, st, n, b, r);
+      if ((rc = dev_norm(k, r, st, &beta))) return rc;
     }
-    double beta = 0.0;
-    if ((rc = dev_norm(k, r, st, &beta))) return rc;
     if (first) k->rnorm0 = beta;
     first = false;
     k->rnorm = beta;
-    if (!(beta == beta)) { k->reason = -9; return 0; }                  // NaN: KSP_DIVERGED_NANORINF
-    if (beta <= tol) { k->reason = beta <= k->atol ? 3 : 2; return 0; } // KSP_CONVERGED_ATOL / RTOL
-    if (k->its >= k->max_it) { k->reason = -3; return 0; }              // KSP_DIVERGED_ITS
-    hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / beta, (const double *)r, k->V);
+    if (!(beta == beta)) { k->reason = -9; return clear_x(); }                  // NaN: KSP_DIVERGED_NANORINF
+    if (beta <= tol) { k->reason = beta <= k->atol ? 3 : 2; return clear_x(); } // KSP_CONVERGED_ATOL / RTOL
+    if (k->its >= k->max_it) { k->reason = -3; return clear_x(); }              // KSP_DIVERGED_ITS
+    hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / beta, rsrc, k->V);
     hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, k->G, beta);
 
     // One cycle.  Iteration j is enqueued BEFORE the host looks at the result of iteration j - 1: the device
@@ -347,22 +382,26 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       const double *zj = vj;
       if (M) { double *z = k->Z + (long)j * ld; if ((rc = M(mctx, vj, z, st))) return rc; zj = z; }
       double *w = k->V + (long)(j + 1) * ld;
+      // V[j+1] is a basis vector only if another iteration of this cycle can follow: not at the end of the cycle, not at the
+      // iteration limit (the inner velocity solves stop there every time) -- then its normalisation pass is not run
+      const int use_next = (j + 1 < m && k->its + j + 1 < k->max_it) ? 1 : 0;
+      const unsigned gsgrid = use_next ? pgrid(n) : 1u;
       if ((rc = A(actx, zj, w, st))) return rc;
-      hipLaunchKernelGGL(k_multidot_grouped, dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
+      if ((n & 1) == 0) hipLaunchKernelGGL((k_multidot_grouped<true>), dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
+      else hipLaunchKernelGGL((k_multidot_grouped<false>), dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       if (!k->reduce) {
         hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
-        hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
-                           (const double *)nullptr);
+        hipLaunchKernelGGL(k_givens_scale, dim3(gsgrid), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->res,
+                           (const double *)nullptr, n, w, use_next);
       } else {            // several ranks: local sums -> all-reduce -> update; the same for |w|^2
         hipLaunchKernelGGL(k_rows_finish, dim3(j + 1), dim3(RT), 0, st, (const double *)k->part, k->hcol, 0);
         if ((rc = k->reduce(k->reduce_ctx, k->hcol, j + 1, st))) return rc;
         hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)nullptr, k->hcol, w, k->npart);
         hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->nsq, 0);
         if ((rc = k->reduce(k->reduce_ctx, k->nsq, 1, st))) return rc;
-        hipLaunchKernelGGL(k_givens, dim3(1), dim3(RT), 0, st, j, m, (const double *)nullptr, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->inv, k->res,
-                           (const double *)k->nsq);
+        hipLaunchKernelGGL(k_givens_scale, dim3(gsgrid), dim3(RT), 0, st, j, m, (const double *)nullptr, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->res,
+                           (const double *)k->nsq, n, w, use_next);
       }
-      hipLaunchKernelGGL(k_scale_dev, dim3(pgrid(n)), dim3(256), 0, st, n, (const double *)k->inv, w);
       KHIPCHK(hipEventRecord(k->ev[j], st));
       enq = j + 1;
       if (j >= 1) { KHIPCHK(hipEventSynchronize(k->ev[j - 1])); examine(j - 1); }
@@ -372,12 +411,13 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
     // y = R^{-1} g (leading kk columns, right-hand side G_kk), x += Z y
     if (kk > 0) {
       hipLaunchKernelGGL(k_trisolve, dim3(1), dim3(1), 0, st, kk, m, (const double *)k->H, (const double *)(k->G + (long)kk * (m + 2)), k->ydev);
-      hipLaunchKernelGGL(k_multiaxpy, dim3(pgrid(n)), dim3(256), 0, st, n, kk, (const double *)(M ? k->Z : k->V), ld, (const double *)k->ydev, x);
+      hipLaunchKernelGGL(k_multiaxpy, dim3(pgrid(n)), dim3(256), 0, st, n, kk, (const double *)(M ? k->Z : k->V), ld, (const double *)k->ydev, x, x_unset ? 1 : 0);
+      x_unset = false;
     }
     KHIPCHK(hipStreamSynchronize(st));      // a speculative iteration may still be running: drain before V is reused
-    if (k->reason == -9) return 0;
-    if (k->rnorm <= tol) { k->reason = k->rnorm <= k->atol ? 3 : 2; return 0; }
-    if (k->its >= k->max_it) { k->reason = -3; return 0; }
+    if (k->reason == -9) return clear_x();
+    if (k->rnorm <= tol) { k->reason = k->rnorm <= k->atol ? 3 : 2; return clear_x(); }
+    if (k->its >= k->max_it) { k->reason = -3; return clear_x(); }
     // otherwise restart: the true residual is recomputed at the top
   }
 }

@@ -120,10 +120,25 @@ __global__ __launch_bounds__(256) void k_modal_scale3(int d, int n1, int nl, lon
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nl; i += gridDim.x * 256) row[i] = row[i] / (s + ll[i]);
 }
 
+// w = 1 / (l_0[i_0] + ... + l_{d-1}[i_{d-1}]) on nf stacked copies of the interior grid (d <= 3): the operand of the last forward
+// line transform when it applies the modal scaling itself (OUT_MUL, sweep.h) -- one pass over the nf G values less per solve
+__global__ __launch_bounds__(256) void k_modal_weights3(int d, int n1, int nl, long G, const double *__restrict__ l0, const double *__restrict__ l1,
+                                                        const double *__restrict__ l2, double *__restrict__ w) {
+  const unsigned line = blockIdx.y;
+  double s = 0.0;
+  if (d == 3) { const unsigned i0 = line / (unsigned)n1, i1 = line - i0 * (unsigned)n1; s = l0[i0] + l1[i1]; }
+  else if (d == 2) s = l0[line];
+  const double *ll = d == 3 ? l2 : (d == 2 ? l1 : l0);
+  double *row = w + (long)blockIdx.z * G + (long)line * nl;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nl; i += gridDim.x * 256) row[i] = 1.0 / (s + ll[i]);
+}
+
 // out = (a - (y ? y : 0)) / eta_g  on nf stacked fields
+// (field = blockIdx.y: no 64-bit modulo per element)
 __global__ void k_resid_over_eta(long G, int nf, const double *__restrict__ a, const double *__restrict__ y,
                                  const double *__restrict__ eta_g, double *__restrict__ out) {
-  GS_LOOP(q, G * nf) { const double r = y ? a[q] - y[q] : a[q]; out[q] = r / eta_g[q % G]; }
+  const long f0 = (long)blockIdx.y * G;
+  GS_LOOP(g, G) { const long q = f0 + g; const double r = y ? a[q] - y[q] : a[q]; out[q] = r / eta_g[g]; }
 }
 
 // node-major interleaved (I nodes x d components, the reference's velocity vectors) <-> component-major
@@ -155,6 +170,7 @@ struct chebhip_fdpc {
   double *xs[MAXD] = {nullptr};
   double *cf = nullptr, *eta_g = nullptr;
   double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr, *t5 = nullptr;   // nf * G each
+  double *W = nullptr; bool W_tried = false;   // reciprocal modal weights, nf stacked copies (built on first use: fdm_solve)
   int sweeps = 1;
   chebhip_fgmres *inner = nullptr; int inner_m = 0;   // the approximate solve with variable coefficients
   bool assembled = false;
@@ -176,7 +192,7 @@ static void fdpc_free(chebhip_fdpc *pc) {
     if (kv.second.lam) (void)hipFree(kv.second.lam);
   }
   for (int k = 0; k < MAXD; k++) if (pc->xs[k]) (void)hipFree(pc->xs[k]);
-  double *all[] = {pc->cf, pc->eta_g, pc->t0, pc->t1, pc->t2, pc->t3, pc->t4, pc->t5};
+  double *all[] = {pc->cf, pc->eta_g, pc->t0, pc->t1, pc->t2, pc->t3, pc->t4, pc->t5, pc->W};
   for (double *p : all) if (p) (void)hipFree(p);
   delete pc;
 }
@@ -274,17 +290,27 @@ static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
 
 // y = S^-1 x (forward) or S x (backward) along dimension k of nf stacked interior fields (x != y): one raw-mode launch
 // where the 16-byte kernels can run it, otherwise the centro-symmetric plus the centro-antisymmetric part (two launches)
-static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st);
-static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st) {
+// mul (forward transforms only; may be null): the result is multiplied by this array as it is stored (OUT_MUL) where the one-launch
+// form runs, and *fused says whether it was
+static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st,
+                            const double *mul = nullptr, bool *fused = nullptr);
+static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st, const double *mul = nullptr, bool *fused = nullptr) {
+  if (fused) *fused = false;
   if (pc->slab && k == 0) return pc->dim0(pc->dim0_ctx, backward ? 1 : 0, pc->nf, x, y, (void *)st);      // collective: every rank of the slab partition
-  return line_transform_g(pc->lines[pc->geo.dims[k]], pc->ncols_g[k] * (unsigned)pc->nf, pc->inner_g[k], backward, x, y, st);
+  return line_transform_g(pc->lines[pc->geo.dims[k]], pc->ncols_g[k] * (unsigned)pc->nf, pc->inner_g[k], backward, x, y, st, mul, fused);
 }
-static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st) {
+static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st,
+                            const double *mul, bool *fused) {
+  if (fused) *fused = false;
   if (ncols == 0) return 0;
   SweepParams sp = {};
   sp.ncols = ncols; sp.inner = inner;
   sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.alpha = 1.0;
   sp.out_mode = OUT_STORE;
+  if (mul && fused && !backward) {
+    SweepParams sm = sp; sm.out_mode = OUT_MUL; sm.acc = mul; sm.raw = 1;
+    if (sweep_vec_raw_eligible(lm.Fraw, sm)) { PHIPCHK(sweep_launch(lm.Fraw, sm, st)); *fused = true; return 0; }
+  }
   if (sweep_vec_raw_eligible(backward ? lm.Braw : lm.Fraw, sp)) {       // one launch: the parity split is the transform's own
     sp.raw = backward ? 2 : 1;
     PHIPCHK(sweep_launch(backward ? lm.Braw : lm.Fraw, sp, st));
@@ -301,12 +327,29 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
   const int d = pc->geo.d;
   const double *src = r;
   double *a = pc->t0, *b = pc->t1;
-  for (int k = 0; k < d; k++) { int rc = line_transform(pc, k, false, src, a, st); if (rc) return rc; src = a; std::swap(a, b); }
   LamPtrs lam; for (int k = 0; k < MAXD; k++) lam.p[k] = k < d ? pc->lines[pc->geo.dims[k]].lam : nullptr;
-  {
-    const int nl = pc->geo.dims[d - 1] - 2;
-    const long lines = pc->G / nl;
-    if (pc->slab && d >= 2) lam.p[0] += pc->i0_off;       // the slab's first interior plane is plane i0_off of the global line
+  const int nl = pc->geo.dims[d - 1] - 2;
+  const long lines = pc->G / nl;
+  if (pc->slab && d >= 2) lam.p[0] += pc->i0_off;         // the slab's first interior plane is plane i0_off of the global line
+  // The modal scaling rides on the store of the last forward transform (dimension d-1 > 0: local on slabs too) where that
+  // transform is one launch of the 16-byte kernels: it multiplies by W = 1 / (l_i + l_j + l_k), built here on first use (the
+  // separate pass divides: the two differ in the last bit).  Option "modal_scale_pass" = 1 keeps the pass (A/B).
+  if (!pc->W && !pc->W_tried && d >= 2 && d <= 3 && lines > 0 && lines <= 65535 && pc->nf <= 65535 && !opt(OPT_MODAL_SCALE_PASS)) {
+    pc->W_tried = true;
+    if (hipMalloc((void **)&pc->W, (size_t)pc->nf * pc->G * sizeof(double)) == hipSuccess) {
+      const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
+      hipLaunchKernelGGL(k_modal_weights3, dim3((unsigned)((nl + 255) / 256), (unsigned)lines, (unsigned)pc->nf), dim3(256), 0, st, d, n1, nl, pc->G,
+                         lam.p[0], lam.p[1], lam.p[2], pc->W);
+      PHIPCHK(hipGetLastError());
+    } else { pc->W = nullptr; (void)hipGetLastError(); }
+  }
+  bool scaled = false;
+  for (int k = 0; k < d; k++) {
+    const bool last = k == d - 1 && pc->W && !opt(OPT_MODAL_SCALE_PASS);
+    int rc = line_transform(pc, k, false, src, a, st, last ? pc->W : nullptr, last ? &scaled : nullptr); if (rc) return rc;
+    src = a; std::swap(a, b);
+  }
+  if (!scaled) {
     if (lines == 0) { /* a slab without interior planes: nothing to scale (it still takes part in the transforms along dimension 0) */ }
     else if (d <= 3 && lines <= 65535 && pc->nf <= 65535) {
       const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
@@ -347,7 +390,7 @@ static int cb_fd_mult(void *ctx, const double *x, double *y, void *stream) {
 }
 static int cb_fdm(void *ctx, const double *r, double *z, void *stream) {
   chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
-  hipLaunchKernelGGL(k_resid_over_eta, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, (hipStream_t)stream, pc->G, pc->nf, r, (const double *)nullptr,
+  hipLaunchKernelGGL(k_resid_over_eta, dim3(pgrid(pc->G), (unsigned)pc->nf), dim3(256), 0, (hipStream_t)stream, pc->G, pc->nf, r, (const double *)nullptr,
                      (const double *)pc->eta_g, pc->t3);
   return fdm_solve(pc, pc->t3, z, (hipStream_t)stream);
 }
@@ -444,6 +487,19 @@ extern "C" int chebhip_fdpc_mult(chebhip_fdpc *pc, const double *x, double *y, v
   if (!pc || ((!x || !y) && pc->G)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (x && x == y) return chebhip_fail(CHEBHIP_ERR_ARG, "x and y must be distinct");
   return fdpc_mult(pc, x, y, (hipStream_t)stream);
+}
+// Stokes velocity preconditioner on component-major vectors: r, z are nf = d stacked interior fields, which is the layout the
+// line transforms work in -- z = P_1^-1 (r / eta) with no (de)interleaving pass on either side
+extern "C" int chebhip_fdpc_apply_cm(void *ctx, const double *r, double *z, void *stream) {
+  chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
+  if (!pc || ((!r || !z) && pc->G)) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (r && r == z) return chebhip_fail(CHEBHIP_ERR_ARG, "r and z must be distinct");
+  if (!pc->interleaved || pc->sweeps != 0) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_fdpc_apply_cm: a Stokes velocity preconditioner with sweeps = 0");
+  StageTimer tm(CHEBHIP_STAGE_FDPC_APPLY, stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (!pc->assembled) { int rc = fdpc_update(pc, st); if (rc) return rc; }
+  if (pc->G == 0 && !pc->slab) return 0;
+  return cb_fdm(pc, r, z, st);
 }
 extern "C" int chebhip_fdpc_apply(void *ctx, const double *r, double *z, void *stream) {
   chebhip_fdpc *pc = (chebhip_fdpc *)ctx;

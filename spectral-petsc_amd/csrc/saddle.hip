@@ -12,6 +12,7 @@
 // Everything here goes through the public C ABI of the operator: vectors never leave HBM.
 #include "../../include/chebhip.h"
 #include "ops.h"
+#include "sweep.h"
 #include "timers.h"
 #include <hip/hip_runtime.h>
 #include <new>
@@ -29,14 +30,18 @@ static inline unsigned sgrid(long n) { long g = (n + 255) / 256; return (unsigne
 #define GS_LOOP(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // full global vector (I nodes x [v_0 .. v_{d-1}, p]) <-> velocity (I x d) and pressure (I) parts: scatterGV / GP / VG / PG
-__global__ void k_split(long I, int d, const double *__restrict__ x, double *__restrict__ v, double *__restrict__ p) {
-  GS_LOOP(q, I * (d + 1)) { const long n = q / (d + 1); const int c = (int)(q - n * (d + 1)); if (c < d) { if (v) v[n * d + c] = x[q]; } else if (p) p[n] = x[q]; }
-}
-// y_v = (addv ? y_v : 0) + v,  y_p = p   (either part may be null: left untouched)
-__global__ void k_merge(long I, int d, const double *__restrict__ v, int addv, const double *__restrict__ p, double *__restrict__ y) {
+// cm: the velocity part is component-major (component c of node n at c I + n; the default of the inner solves, see stokes_saddle)
+__global__ void k_split(long I, int d, const double *__restrict__ x, double *__restrict__ v, double *__restrict__ p, int cm) {
   GS_LOOP(q, I * (d + 1)) {
     const long n = q / (d + 1); const int c = (int)(q - n * (d + 1));
-    if (c < d) { if (v) y[q] = addv ? y[q] + v[n * d + c] : v[n * d + c]; }
+    if (c < d) { if (v) v[cm ? c * I + n : n * d + c] = x[q]; } else if (p) p[n] = x[q];
+  }
+}
+// y_v = (addv ? y_v : 0) + v,  y_p = p   (either part may be null: left untouched)
+__global__ void k_merge(long I, int d, const double *__restrict__ v, int addv, const double *__restrict__ p, double *__restrict__ y, int cm) {
+  GS_LOOP(q, I * (d + 1)) {
+    const long n = q / (d + 1); const int c = (int)(q - n * (d + 1));
+    if (c < d) { if (v) { const double w = v[cm ? c * I + n : n * d + c]; y[q] = addv ? y[q] + w : w; } }
     else if (p) y[q] = p[n];
   }
 }
@@ -101,15 +106,25 @@ struct stokes_saddle {
   // the ranks by `reduce`; MatVVPC is the slab driver's (borrowed: chebhip_dist_stokes_pc)
   bool slab = false, own_pc = true;
   chebhip_reduce_fn reduce = nullptr; void *reduce_ctx = nullptr;
+  // The velocity vectors INSIDE an apply (v0, v1, the Krylov bases of the two velocity solves, the work vectors of MatSchur) are
+  // component-major: d stacked scalar fields, the layout MatVVPC's line transforms work in, so that no inner iteration pays a
+  // (de)interleaving pass around its preconditioner solve (stokes_op_mult_*_cm, chebhip_fdpc_apply_cm).  The full vectors at
+  // the interface keep the reference's node-major layout: split / merge convert.  Inner products run over the same values in
+  // another order: the iterates agree with the node-major route to rounding (option "saddle_node_major" = 1 at create: A/B).
+  bool cm = true, cm_opt = true;       // cm_opt: the option at create; cm = cm_opt and MatVVPC without inner sweeps (the only component-major solve)
 };
 
-static int vv_apply(void *ctx, const double *x, double *y, void *stream) { return stokes_op_mult_vv(((stokes_saddle *)ctx)->op, x, y, stream); }
+static int vv_apply(void *ctx, const double *x, double *y, void *stream) {
+  stokes_saddle *s = (stokes_saddle *)ctx;
+  return s->cm ? stokes_op_mult_vv_cm(s->op, x, y, stream) : stokes_op_mult_vv(s->op, x, y, stream);
+}
+static inline chebhip_apply_fn pc_fn(const stokes_saddle *s) { return s->cm ? chebhip_fdpc_apply_cm : chebhip_fdpc_apply; }
 // KSPSolve(KSPSchurVelocity) (stokes.C:531): preonly -> one MatVVPC solve; otherwise GMRES on MatVV with it
 static int svel_solve(void *ctx, const double *rhs, double *sol, void *stream) {
   stokes_saddle *s = (stokes_saddle *)ctx;
-  if (s->m_svel == 0) return chebhip_fdpc_apply(s->vvpc, rhs, sol, stream);
+  if (s->m_svel == 0) return pc_fn(s)(s->vvpc, rhs, sol, stream);
   int rc = chebhip_fgmres_set_tolerances(s->ksvel, s->rtol_svel, 1e-50, s->m_svel); if (rc) return rc;
-  return chebhip_fgmres_solve(s->ksvel, vv_apply, s, chebhip_fdpc_apply, s->vvpc, rhs, sol, 0, stream);
+  return chebhip_fgmres_solve(s->ksvel, vv_apply, s, pc_fn(s), s->vvpc, rhs, sol, 0, stream);
 }
 // MatSchur followed by the removal of the constant: KSPSchur carries the constant null space (stokes.C:1020-1021) and
 // PETSc's (left-preconditioned) GMRES removes it from every vector it builds, i.e. it solves  P S x = P b  on
@@ -132,7 +147,8 @@ static void eta_scale(stokes_saddle *s, const double *in, double *out, hipStream
 // One step of KSPSchur's left-preconditioned GMRES (PETSc's default side): y = P (eta .* (S x))
 static int schur_apply(void *ctx, const double *x, double *y, void *stream) {
   stokes_saddle *s = (stokes_saddle *)ctx;
-  int rc = stokes_op_mult_schur(s->op, x, y, svel_solve, s, stream); if (rc) return rc;
+  int rc = s->cm ? stokes_op_mult_schur_cm(s->op, x, y, svel_solve, s, stream) : stokes_op_mult_schur(s->op, x, y, svel_solve, s, stream);
+  if (rc) return rc;
   eta_scale(s, y, y, (hipStream_t)stream);
   if ((rc = remove_mean(s, y, y, (hipStream_t)stream))) return rc;
   SHIPCHK2(hipGetLastError());
@@ -140,9 +156,9 @@ static int schur_apply(void *ctx, const double *x, double *y, void *stream) {
 }
 // KSPSolve(KSPVelocity, b, x)
 static int vel_solve(stokes_saddle *s, const double *b, double *x, void *stream) {
-  if (s->m_vel == 0) return chebhip_fdpc_apply(s->vvpc, b, x, stream);
+  if (s->m_vel == 0) return pc_fn(s)(s->vvpc, b, x, stream);
   int rc = chebhip_fgmres_set_tolerances(s->kvel, s->rtol_vel, 1e-50, s->m_vel); if (rc) return rc;
-  rc = chebhip_fgmres_solve(s->kvel, vv_apply, s, chebhip_fdpc_apply, s->vvpc, b, x, 0, stream);
+  rc = chebhip_fgmres_solve(s->kvel, vv_apply, s, pc_fn(s), s->vvpc, b, x, 0, stream);
   s->its_vel += chebhip_fgmres_iterations(s->kvel);
   return rc;
 }
@@ -183,7 +199,7 @@ static int saddle_create(stokes_op *op, chebhip_fdpc *slab_pc, chebhip_reduce_fn
   *out = nullptr;
   stokes_saddle *s = new (std::nothrow) stokes_saddle;
   if (!s) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
-  s->op = op;
+  s->op = op; s->cm_opt = s->cm = chebhip::opt(chebhip::OPT_SADDLE_NODE_MAJOR) == 0;
   if (slab_pc) { s->slab = true; s->own_pc = false; s->vvpc = slab_pc; s->reduce = reduce; s->reduce_ctx = reduce_ctx; }
   s->I = stokes_op_size(op, 1); s->gv = stokes_op_size(op, 2); s->gp = stokes_op_size(op, 3); s->g = stokes_op_size(op, 4);
   s->d = s->I > 0 ? (int)(s->gv / s->I) : 2;
@@ -231,7 +247,9 @@ extern "C" int stokes_saddle_setup(stokes_saddle *s, void *stream) {
 // diagonalisation alone, exact for constant viscosity -- raise it when the viscosity varies strongly)
 extern "C" int stokes_saddle_set_pc_sweeps(stokes_saddle *s, int sweeps) {
   if (!s) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL handle");
-  return chebhip_fdpc_set_sweeps(s->vvpc, sweeps);
+  int rc = chebhip_fdpc_set_sweeps(s->vvpc, sweeps); if (rc) return rc;
+  s->cm = s->cm_opt && sweeps == 0;
+  return 0;
 }
 // -schur_pc_type: 1 = jacobi (the reference's hard-wired choice, stokes.C:330-331), 0 = none
 extern "C" int stokes_saddle_set_schur_jacobi(stokes_saddle *s, int on) {
@@ -248,22 +266,24 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
   if (s->g == 0 && !s->slab) return 0;               // (a slab without unknowns still takes part in the collectives)
   chebhip::StageTimer tm(CHEBHIP_STAGE_SADDLE_APPLY, stream);
   hipStream_t st = (hipStream_t)stream;
-  const long I = s->I; const int d = s->d;
+  const long I = s->I; const int d = s->d, cm = s->cm ? 1 : 0;
   const unsigned gg = sgrid(s->g), gpn = sgrid(s->gp), gvn = sgrid(s->gv);
   s->its_vel = s->its_schur = 0;
   int rc;
-#define SPLIT(V, P) hipLaunchKernelGGL(k_split, dim3(gg), dim3(256), 0, st, I, d, x, V, P)
-#define MERGE(V, ADD, P) hipLaunchKernelGGL(k_merge, dim3(gg), dim3(256), 0, st, I, d, (const double *)(V), ADD, (const double *)(P), y)
+#define SPLIT(V, P) hipLaunchKernelGGL(k_split, dim3(gg), dim3(256), 0, st, I, d, x, V, P, cm)
+#define MERGE(V, ADD, P) hipLaunchKernelGGL(k_merge, dim3(gg), dim3(256), 0, st, I, d, (const double *)(V), ADD, (const double *)(P), y, cm)
+  auto mult_pv = [&](const double *v, double *p) { return s->cm ? stokes_op_mult_pv_cm(s->op, v, p, stream) : stokes_op_mult_pv(s->op, v, p, stream); };
+  auto mult_vp = [&](const double *p, double *v) { return s->cm ? stokes_op_mult_vp_cm(s->op, p, v, stream) : stokes_op_mult_vp(s->op, p, v, stream); };
   switch (s->type) {
     case 0:   // block LU (stokes.C:1714-1740)
       SPLIT(s->v0, (double *)nullptr);                                             // scatterGV: v0 <- x_v
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0          (:1723)
       MERGE(s->v1, 0, nullptr);                                                    // y_v <- v1              (:1725)
-      if ((rc = stokes_op_mult_pv(s->op, s->v1, s->p0, stream))) return rc;        // p0 <- B v1             (:1726)
+      if ((rc = mult_pv(s->v1, s->p0))) return rc;        // p0 <- B v1             (:1726)
       SPLIT((double *)nullptr, s->p1);                                             // x_p
       hipLaunchKernelGGL(k_scale_add, dim3(gpn), dim3(256), 0, st, s->gp, -1.0, s->p0, (const double *)s->p1);   // p0 <- -p0 + x_p (:1727-1729)
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0          (:1732)
-      if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1           (:1734)
+      if ((rc = mult_vp(s->p1, s->v0))) return rc;        // v0 <- B^T p1           (:1734)
       hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)nullptr);   // v0 <- -v0 (:1735)
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0          (:1736)
       if ((rc = remove_mean(s, s->p1, s->p1, st))) return rc;      // KSPSetNullSpace (:1019)
@@ -272,7 +292,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
     case 1:   // block upper triangular (stokes.C:1747-1765)
       SPLIT(s->v1, s->p0);
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0
-      if ((rc = stokes_op_mult_vp(s->op, s->p1, s->v0, stream))) return rc;        // v0 <- B^T p1
+      if ((rc = mult_vp(s->p1, s->v0))) return rc;        // v0 <- B^T p1
       hipLaunchKernelGGL(k_scale_add, dim3(gvn), dim3(256), 0, st, s->gv, -1.0, s->v0, (const double *)s->v1);   // v0 <- -v0 + x_v
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;
       if ((rc = remove_mean(s, s->p1, s->p1, st))) return rc;
@@ -288,7 +308,7 @@ extern "C" int stokes_saddle_apply(void *ctx, const double *x, double *y, void *
     default:  // block lower triangular (stokes.C:1797-1816)
       SPLIT(s->v0, s->p1);
       if ((rc = vel_solve(s, s->v0, s->v1, stream))) return rc;                    // v1 <- A^-1 v0
-      if ((rc = stokes_op_mult_pv(s->op, s->v1, s->p0, stream))) return rc;        // p0 <- B v1
+      if ((rc = mult_pv(s->v1, s->p0))) return rc;        // p0 <- B v1
       hipLaunchKernelGGL(k_scale_add, dim3(gpn), dim3(256), 0, st, s->gp, -1.0, s->p0, (const double *)s->p1);   // p0 <- -p0 + x_p
       MERGE(s->v1, 0, nullptr);                                                    // y_v <- v1 (before v1 is reused by the Schur solve)
       if ((rc = schur_solve(s, s->p0, s->p1, stream))) return rc;                  // p1 <- S^-1 p0

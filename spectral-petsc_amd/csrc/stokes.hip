@@ -38,15 +38,17 @@ static inline unsigned pgrid(long nlines) { long g = (nlines + 31) / 32; return 
 // xL <- velocity part, pL <- pressure part of a global vector (node stride gs, pressure offset go); zero or
 // Dirichlet values on the boundary: VecZeroEntries + scatterGV/VL (+ scatterDL) + scatterGP,
 // stokes.C:505-510,575-582,605-608,634-637,695-699.  xL or pL may be null.
+// cs: stride between the components of a node in src -- 1 for the reference's node-major vectors, I (with gs = 1) for the
+// component-major velocity vectors of the block preconditioners' inner solves (saddle.hip)
 template <int D>
 __global__ void k_st_local(long N, int gs, int go, const int *__restrict__ ixL, const double *__restrict__ src,
-                           const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL) {
+                           const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL, long cs) {
   GS_LOOP(l, N) {
     const int n = ixL[l];
     const double *s = src + (long)(n >= 0 ? n : 0) * gs;
     if (xL) {
 #pragma unroll
-      for (int k = 0; k < D; k++) xL[k * N + l] = n >= 0 ? s[k] : (dirloc ? dirloc[k * N + l] : 0.0);
+      for (int k = 0; k < D; k++) xL[k * N + l] = n >= 0 ? s[k * cs] : (dirloc ? dirloc[k * N + l] : 0.0);
     }
     if (pL) pL[l] = n >= 0 ? s[go] : 0.0;
   }
@@ -344,8 +346,8 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
                          const double *__restrict__ yL1, const double *__restrict__ yL2,
                          const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
                          const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out,
-                         const double *__restrict__ G) {                // G (may be null): one more velocity term (d fields), added after yL2
-  GS_LOOP(l, N) {
+                         const double *__restrict__ G, long cs) {       // G (may be null): one more velocity term (d fields), added after yL2
+  GS_LOOP(l, N) {                                                       // cs: component stride of out / force (see k_st_local)
     const int n = ixL[l];
     if (n < 0) continue;
     const long o = (long)n * gs;
@@ -366,7 +368,7 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
         else { v[0] = g0; v[1] = g1; if (D == 3) v[D - 1] = g2; }
       }
 #pragma unroll
-      for (int k = 0; k < D; k++) { if (force) v[k] += -1.0 * force[o + k]; out[o + k] = v[k]; }
+      for (int k = 0; k < D; k++) { if (force) v[k] += -1.0 * force[o + k * cs]; out[o + k * cs] = v[k]; }
     }
     if (p2) { double w = p2[l]; if (force) w += -1.0 * force[o + po]; out[o + po] = w; }
   }
@@ -460,6 +462,62 @@ __global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict_
         o2[0] = make_double2(w0, w1); o2[1] = make_double2(w2, w3);
       }
     }
+  }
+}
+
+// Gather / scatter of the d = 3 velocity blocks on COMPONENT-MAJOR vectors (component c of interior node n at c I + n), on node
+// pairs: the full-grid side moves 16 bytes per access, the interior side 8 bytes with neighbouring lanes on neighbouring
+// addresses (an interior run of the last dimension is contiguous in both).  N even.  The same sums in the same order as k_st_out.
+template <int UN>
+__global__ __launch_bounds__(256) void k_st_local_cm3p(long N, long I, const int *__restrict__ ixL, const double *__restrict__ src, double *__restrict__ xL) {
+  const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
+  for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
+    int2 n[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    double2 v[UN][3];
+#pragma unroll
+    for (int u = 0; u < UN; u++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        v[u][c].x = n[u].x >= 0 ? src[c * I + n[u].x] : 0.0;
+        v[u][c].y = n[u].y >= 0 ? src[c * I + n[u].y] : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long t = t0 + u * T;
+      if (t >= half) continue;
+#pragma unroll
+      for (int c = 0; c < 3; c++) ((double2 *)(xL + c * N))[t] = v[u][c];
+    }
+  }
+}
+struct StTerms3 { const double *p[4][3]; int n; };      // up to four terms of three component fields each, summed in order
+template <int UN>
+__global__ __launch_bounds__(256) void k_st_out_cm3p(long N, long I, const int *__restrict__ ixL, StTerms3 tm, double *__restrict__ out) {
+  const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
+  for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
+    int2 n[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    double2 v[UN][3];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long t = (t0 + u * T < half) ? t0 + u * T : 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double2 s = ((const double2 *)tm.p[0][c])[t];
+        for (int q = 1; q < tm.n; q++) { const double2 b = ((const double2 *)tm.p[q][c])[t]; s.x = s.x + b.x; s.y = s.y + b.y; }
+        v[u][c] = s;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        if (n[u].x >= 0) out[c * I + n[u].x] = v[u][c].x;
+        if (n[u].y >= 0) out[c * I + n[u].y] = v[u][c].y;
+      }
   }
 }
 
@@ -759,7 +817,7 @@ static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *
 // xL / pL <- global vector (either may be null)
 static inline unsigned ugrid(long n, int un) { long g = (n + 256L * un - 1) / (256L * un); return (unsigned)(g < 1 ? 1 : g); }
 static inline bool st_al16(const void *q) { return ((size_t)q & 15) == 0; }
-static void st_local(stokes_op *op, int gs, int go, const double *src, const double *dirloc, double *xL, double *pL, hipStream_t st) {
+static void st_local(stokes_op *op, int gs, int go, const double *src, const double *dirloc, double *xL, double *pL, hipStream_t st, long cs = 1) {
   const int d = op->d;
   // (k_st_local4 loads node 0 of src for boundary nodes too: not for a slab without unknowns, whose src may be NULL)
   if (d == 3 && gs == 4 && go == 3 && xL && pL && op->I > 0 && st_al16(src)) {
@@ -769,7 +827,7 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
       hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
     return;
   }
-  ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL);
+  ST_D(k_st_local, gs, go, (const int *)op->ixL, src, dirloc, xL, pL, cs);
 }
 // final scatter with every term present (StokesMatMult, StokesFunction)
 // y0, y1, y2 (+ G): the velocity terms, summed in this order (the general path: yL, yLx[1], yLx[2]; y1, y2, G may be null)
@@ -796,7 +854,7 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
     return;
   }
   ST_D(k_st_out, d + 1, (const int *)op->ixL, y0, y1, y2,
-       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, force, out, G);
+       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, d, force, out, G, 1L);
 }
 
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
@@ -1049,48 +1107,97 @@ static int st_join(stokes_op *op, hipStream_t st) {
 #define VEC_OK(ptr) ((ptr) != nullptr || op->I == 0)
 #define CDP(x) ((const double *)(x))
 
-extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
-  ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(out));
-  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VV, stream);
-  hipStream_t st = (hipStream_t)stream;
-  const int d = op->d;
-  st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
+// The three blocks on their own.  cm: the velocity vector is component-major (component c of interior node n at c I + n) instead
+// of the reference's node-major layout (n d + c): the layout of the block preconditioners' inner Krylov solves (saddle.hip), whose
+// vectors are then d stacked scalar fields for MatVVPC's line transforms as well -- no (de)interleaving pass per iteration.
+// component-major d = 3 vectors on node pairs (k_st_local_cm3p / k_st_out_cm3p): N even, the handle's arrays are 16-B aligned
+static inline bool st_cm_pairs(const stokes_op *op, bool cm) { return cm && op->d == 3 && (op->N & 1) == 0 && op->I > 0; }
+static void st_local_cm(stokes_op *op, const double *v_cm, hipStream_t st) {
+  hipLaunchKernelGGL((k_st_local_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, v_cm, op->xL);
+}
+static void st_out_cm(stokes_op *op, int nterms, const double *t0, const double *t1, const double *t2, const double *t3, double *out_cm, hipStream_t st,
+                      bool separate_fields = false) {      // separate_fields: t0, t1, t2 are the three component fields of ONE term (gp[])
+  StTerms3 tm = {};
+  const long N = op->N;
+  if (separate_fields) { tm.n = 1; tm.p[0][0] = t0; tm.p[0][1] = t1; tm.p[0][2] = t2; }
+  else {
+    const double *t[4] = {t0, t1, t2, t3};
+    tm.n = nterms;
+    for (int q = 0; q < nterms; q++) for (int c = 0; c < 3; c++) tm.p[q][c] = t[q] + (size_t)c * N;
+  }
+  hipLaunchKernelGGL((k_st_out_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, tm, out_cm);
+}
+
+static int st_mult_vv(stokes_op *op, const double *vG, double *out, hipStream_t st, bool cm) {
+  const int d = op->d, gs = cm ? 1 : d; const long cs = cm ? op->I : 1;
+  const bool pairs = st_cm_pairs(op, cm);
+  if (pairs) st_local_cm(op, vG, st); else
+  st_local(op, gs, 0, vG, nullptr, op->xL, nullptr, st, cs);
   if (st_uniform(op)) {
     bool split = false;                                    // (no pressure rows here: whether div v was formed as p2 does not matter)
     int rc = st_viscous_uniform(op, false, st, nullptr, 0.0, &split); if (rc) return rc;
-    ST_OUT(d, (const int *)op->ixL, CDP(op->V[0]), CDP(op->V[1]), CDP(op->V[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(op->yLx[1]));
+    if (pairs) { st_out_cm(op, 4, op->V[0], op->V[1], op->V[2], op->yLx[1], out, st); SHIPCHK(hipGetLastError()); return 0; }
+    ST_OUT(gs, (const int *)op->ixL, CDP(op->V[0]), CDP(op->V[1]), CDP(op->V[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(op->yLx[1]), cs);
     SHIPCHK(hipGetLastError());
     return 0;
   }
   int rc = st_viscous_jacobian(op, nullptr, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(nullptr));
+  if (pairs) { st_out_cm(op, 3, op->yL, op->yLx[1], op->yLx[2], nullptr, out, st); SHIPCHK(hipGetLastError()); return 0; }
+  ST_OUT(gs, (const int *)op->ixL, CDP(op->yL), CDP(op->yLx[1]), CDP(op->yLx[2]), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), 0, CDP(nullptr), out, CDP(nullptr), cs);
   SHIPCHK(hipGetLastError());
   return 0;
 }
-
-extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, void *stream) {
-  ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(pout));
-  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_PV, stream);
-  hipStream_t st = (hipStream_t)stream;
+static int st_mult_pv(stokes_op *op, const double *vG, double *pout, hipStream_t st, bool cm) {
   const int d = op->d;
-  st_local(op, d, 0, vG, nullptr, op->xL, nullptr, st);
+  if (st_cm_pairs(op, cm)) st_local_cm(op, vG, st); else
+  st_local(op, cm ? 1 : d, 0, vG, nullptr, op->xL, nullptr, st, cm ? op->I : 1);
   int rc = st_divergence(op, st); if (rc) return rc;
-  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout, CDP(nullptr));
+  ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout, CDP(nullptr), 1L);
   SHIPCHK(hipGetLastError());
   return 0;
 }
-
-extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, void *stream) {
-  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(vout));
-  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VP, stream);
-  hipStream_t st = (hipStream_t)stream;
+static int st_mult_vp(stokes_op *op, const double *pG, double *vout, hipStream_t st, bool cm) {
   const int d = op->d;
   st_local(op, 1, 0, pG, nullptr, nullptr, op->pL, st);
   if (op->slab) op->gp[0] = op->V[0] + (size_t)op->d * op->N;
   int rc = st_pressure_gradient(op, st); if (rc) return rc;
-  ST_OUT(d, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout, CDP(nullptr));
+  if (st_cm_pairs(op, cm)) { st_out_cm(op, 1, op->gp[0], op->gp[1], op->gp[2], nullptr, vout, st, true); SHIPCHK(hipGetLastError()); return 0; }
+  ST_OUT(cm ? 1 : d, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->gp[0]), CDP(op->gp[1]), CDP(op->gp[2]), CDP(nullptr), 0, CDP(nullptr), vout, CDP(nullptr),
+         cm ? op->I : 1L);
   SHIPCHK(hipGetLastError());
   return 0;
+}
+
+extern "C" int stokes_op_mult_vv(stokes_op *op, const double *vG, double *out, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(out));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VV, stream);
+  return st_mult_vv(op, vG, out, (hipStream_t)stream, false);
+}
+extern "C" int stokes_op_mult_pv(stokes_op *op, const double *vG, double *pout, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(vG) && VEC_OK(pout));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_PV, stream);
+  return st_mult_pv(op, vG, pout, (hipStream_t)stream, false);
+}
+extern "C" int stokes_op_mult_vp(stokes_op *op, const double *pG, double *vout, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(vout));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VP, stream);
+  return st_mult_vp(op, pG, vout, (hipStream_t)stream, false);
+}
+// ... on component-major velocity vectors (see st_mult_vv)
+extern "C" int stokes_op_mult_vv_cm(stokes_op *op, const double *v_cm, double *out_cm, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(v_cm) && VEC_OK(out_cm));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VV, stream);
+  return st_mult_vv(op, v_cm, out_cm, (hipStream_t)stream, true);
+}
+extern "C" int stokes_op_mult_pv_cm(stokes_op *op, const double *v_cm, double *pout, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(v_cm) && VEC_OK(pout));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_PV, stream);
+  return st_mult_pv(op, v_cm, pout, (hipStream_t)stream, true);
+}
+extern "C" int stokes_op_mult_vp_cm(stokes_op *op, const double *pG, double *vout_cm, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(vout_cm));
+  chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_MULT_VP, stream);
+  return st_mult_vp(op, pG, vout_cm, (hipStream_t)stream, true);
 }
 
 extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void *stream) {
@@ -1201,8 +1308,7 @@ extern "C" int stokes_op_set_inner_reduce(stokes_op *op, chebhip_reduce_fn reduc
   return 0;
 }
 
-extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream) {
-  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(out));
+static int st_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream, bool cm) {
   chebhip::StageTimer tm(CHEBHIP_STAGE_STOKES_SCHUR, stream);
   hipStream_t st = (hipStream_t)stream;
   const size_t gv = (size_t)op->I * op->d;
@@ -1210,19 +1316,29 @@ extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out
     int rc = st_alloc(&op->sv0, gv ? gv : 1); if (rc) return rc; if ((rc = st_alloc(&op->sv1, gv ? gv : 1))) return rc;
     SHIPCHK(hipStreamSynchronize(nullptr));       // st_alloc clears on the null stream, which a non-blocking caller's stream does not wait for
   }
-  int rc = stokes_op_mult_vp(op, pG, op->sv0, st); if (rc) return rc;                        // :530
+  int rc = st_mult_vp(op, pG, op->sv0, st, cm); if (rc) return rc;                            // :530
   if (solve) { if ((rc = solve(solve_ctx, op->sv0, op->sv1, st))) return rc; }               // KSPSolve(KSPSchurVelocity), :531
   else {
+    if (cm) return chebhip_fail(CHEBHIP_ERR_ARG, "the built-in inner solver works on node-major vectors");
     if (!op->inner) { if ((rc = chebhip_fgmres_create((long)gv, op->in_restart, &op->inner))) return rc; }
     if ((rc = chebhip_fgmres_set_tolerances(op->inner, op->in_rtol, op->in_atol, op->in_maxit))) return rc;
     if ((rc = chebhip_fgmres_set_reduce(op->inner, op->in_reduce, op->in_reduce_ctx))) return rc;
     if ((rc = chebhip_fgmres_solve(op->inner, st_vv_apply, op, nullptr, nullptr, op->sv0, op->sv1, 0, st))) return rc;
     op->inner_its = chebhip_fgmres_iterations(op->inner);
   }
-  if ((rc = stokes_op_mult_pv(op, op->sv1, out, st))) return rc;                             // :532
+  if ((rc = st_mult_pv(op, op->sv1, out, st, cm))) return rc;                                // :532
   hipLaunchKernelGGL(k_st_neg, dim3(sgrid(op->I)), dim3(256), 0, st, op->I, out);
   SHIPCHK(hipGetLastError());
   return 0;
+}
+extern "C" int stokes_op_mult_schur(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve, void *solve_ctx, void *stream) {
+  ARGCHK(op); ARGCHK(VEC_OK(pG) && VEC_OK(out));
+  return st_mult_schur(op, pG, out, solve, solve_ctx, stream, false);
+}
+// ... with the inner velocity solve on component-major vectors: `solve` (required) receives and returns them in that layout
+extern "C" int stokes_op_mult_schur_cm(stokes_op *op, const double *pG, double *out, chebhip_apply_fn solve_cm, void *solve_ctx, void *stream) {
+  ARGCHK(op); ARGCHK(solve_cm); ARGCHK(VEC_OK(pG) && VEC_OK(out));
+  return st_mult_schur(op, pG, out, solve_cm, solve_ctx, stream, true);
 }
 
 // ---- pencil side of the slab mode: arrays (nfields, gP0, ncol), lines along dimension 0 with stride ncol ---------

@@ -19,7 +19,9 @@ enum InMode : int {
 enum OutMode : int {
   OUT_STORE = 0,        // out[a] = alpha*r
   OUT_ACC = 1,          // out[a] = acc[a] + alpha*r               (VecAXPY, elliptic.C:333)
-  OUT_ACC_SCATTER = 2   // interior: out_global[g] = (acc ? acc[a] : 0) + alpha*r   (+ VecScatter LG, elliptic.C:336)
+  OUT_ACC_SCATTER = 2,  // interior: out_global[g] = (acc ? acc[a] : 0) + alpha*r   (+ VecScatter LG, elliptic.C:336)
+  OUT_MUL = 3           // out[a] = acc[a] * (alpha*r)               (16-byte kernels with raw = 1 only: the modal scaling of the
+                        //   fast-diagonalisation solve folded into its last forward line transform, precond.hip)
 };
 
 // Pointwise coefficient applied between the two halves of a fused D_k( flux( D_k u ) ) launch.
@@ -161,7 +163,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_VENDOR_GEMM, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_DIST_EXACT_ORDER, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_DIST_EXACT_ORDER, OPT_MODAL_SCALE_PASS, OPT_SADDLE_NODE_MAJOR, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

@@ -170,7 +170,8 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
   const bool grpB = w >= 4;             // second wave of each SIMD
 #define AO(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
   const int i0 = mt * 16 + (JFAST ? l16 : kq);
-  const bool acc_on = (p.out_mode == OUT_ACC);
+  const bool mul_on = (p.out_mode == OUT_MUL);            // out = operand * (alpha r): the operand rides the VecAXPY path
+  const bool acc_on = (p.out_mode == OUT_ACC) || mul_on;
   const double alpha = p.alpha;
 
 #ifdef CHEB_STAMPS
@@ -308,8 +309,8 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
         if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
         else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};  // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
         if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};   // (y_ie, y_{n-ie}) : adjacent when H is odd
-        vh = acc_hi[rp] + alpha * vh;
-        vl = acc_lo[rp] + alpha * vl;
+        if (mul_on) { vh = acc_hi[rp] * (alpha * vh); vl = acc_lo[rp] * (alpha * vl); }
+        else { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha * vl; }
         if (ok_hi[rp]) *(d2 *)(p.out + a_hi[rp]) = vh;
         if (ok_lo[rp]) *(d2 *)(p.out + a_lo[rp]) = vl;
       }
@@ -400,9 +401,13 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #define V4_STORE_AUX 0
 #endif
 
-template <int KS, bool JFAST, bool ACC, int RAW = 0>
+// MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
+// preconditioner's fast diagonalisation folded into its last forward transform -- RAW = 1 only)
+template <int KS, bool JFAST, int MODE, int RAW = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
-  static_assert(RAW == 0 || !ACC, "the raw modes (sweep.h) are STORE-only");
+  constexpr bool ACC = MODE != 0, MUL = MODE == 2;       // ACC: the operand stream exists
+  static_assert(RAW == 0 || MODE != 1, "the raw modes (sweep.h) are STORE / MUL only");
+  static_assert(!MUL || RAW == 1, "OUT_MUL exists for the raw forward transform only");
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
   constexpr int HP = 4 * KS;
@@ -660,7 +665,8 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
       d2 vl;
       if (!JFAST) vl = d2{odd ? lbe : la, odd ? lb : lao};
       else vl = d2{odd ? lb : lao, odd ? lbe : la};                       // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
-      if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha_lo * vl; }
+      if (MUL) { vh = acc_hi[rp] * (alpha * vh); vl = acc_lo[rp] * (alpha_lo * vl); }
+      else if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha_lo * vl; }
       else { vh = alpha * vh; vl = alpha_lo * vl; }
       if (JFAST && (H & 1)) { if (fold[rp]) vh = d2{vh.x, vl.y}; }       // (y_ie, y_{n-ie}): adjacent when H is odd
       st16(r_out, o_hi[rp] + t0v, vh);
@@ -719,10 +725,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
 #endif
 }
 
-template <int KS, bool JFAST, bool ACC, int RAW = 0>
+template <int KS, bool JFAST, int MODE, int RAW = 0>
 __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams p) {
   __shared__ double smem[vec_lds_doubles<KS, JFAST>()];
-  vec4_body<KS, JFAST, ACC, RAW>(p, smem, blockIdx.x, gridDim.x);
+  vec4_body<KS, JFAST, MODE, RAW>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -743,18 +749,22 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams
   const SweepParams &p = mp.job[j];
   const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
   if (p.inner < 16) {
-    if constexpr (KS >= 16) vec4_body<KS, true, false>(p, smem, bid, nblk); else vec1_body<KS, true, SUM3>(p, smem, bid, nblk);
+    if constexpr (KS >= 16) vec4_body<KS, true, 0>(p, smem, bid, nblk); else vec1_body<KS, true, SUM3>(p, smem, bid, nblk);
   } else {
-    if constexpr (KS >= 16) vec4_body<KS, false, false>(p, smem, bid, nblk); else vec1_body<KS, false, SUM3>(p, smem, bid, nblk);
+    if constexpr (KS >= 16) vec4_body<KS, false, 0>(p, smem, bid, nblk); else vec1_body<KS, false, SUM3>(p, smem, bid, nblk);
   }
 }
 
 template <int KS, bool JFAST>
 static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t stream) {
-  if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
-  else if (p.raw == 1) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false, 1>), dim3(grid), dim3(512), 0, stream, p);
-  else if (p.raw == 2) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false, 2>), dim3(grid), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
+  if (p.out_mode == OUT_MUL) {
+    if (p.raw != 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 2, 1>), dim3(grid), dim3(512), 0, stream, p);
+  }
+  else if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 1>), dim3(grid), dim3(512), 0, stream, p);
+  else if (p.raw == 1) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0, 1>), dim3(grid), dim3(512), 0, stream, p);
+  else if (p.raw == 2) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0, 2>), dim3(grid), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0>), dim3(grid), dim3(512), 0, stream, p);
   sweep_note_launch();
   return hipGetLastError();
 }
@@ -821,7 +831,8 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   if (grid == 0) return hipSuccess;
   if constexpr (KS >= 16) return launch_v4<KS, JFAST>(p, grid, stream);
   else {
-    if (p.raw && p.out_mode != OUT_STORE) return hipErrorInvalidValue;
+    if (p.raw && p.out_mode != OUT_STORE && !(p.out_mode == OUT_MUL && p.raw == 1)) return hipErrorInvalidValue;
+    if (p.out_mode == OUT_MUL && p.raw != 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
     sweep_note_launch();
     return hipGetLastError();
@@ -837,7 +848,7 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
     auto al16 = [](const void *q) { return q && ((size_t)q & 15) == 0; };
     if (m.KS > 8 || p.out_mode != OUT_STORE || p.raw || p.in_fblocks || p.qmax || p.in_os || !al16(p.in1) || !al16(p.in2)) return false;
   } else
-  if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC)) return false;
+  if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC && !(p.out_mode == OUT_MUL && p.raw == 1))) return false;
   const bool jfast = p.inner < 16;
   if (p.in_fblocks && (m.KS < 16 || (p.in_fskip & 1))) return false;
   if (p.qmax != 0 || p.in_os != 0) {                     // per-array geometry: the long-line kernel only, every offset must stay 16-B aligned
@@ -848,7 +859,7 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   if (jfast && (p.inner != 1 || (m.P & 1))) return false;
   if (!jfast && (p.inner & 1)) return false;
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
-  if (!al(p.in0) || !al(p.out) || (p.out_mode == OUT_ACC && !al(p.acc))) return false;
+  if (!al(p.in0) || !al(p.out) || ((p.out_mode == OUT_ACC || p.out_mode == OUT_MUL) && (!p.acc || !al(p.acc)))) return false;
   SweepParams q = p0;                                    // sizes: the buffer offsets must reach (prepare_v)
   q.P = m.P; q.H = m.H; q.sink = m.sink;
   switch (m.KS) {
@@ -860,9 +871,10 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   }
 }
 
-// ... and may carry p.raw != 0: the raw modes (sweep.h) are STORE-only
+// ... and may carry p.raw != 0: the raw modes (sweep.h) are STORE-only, but for raw = 1 with OUT_MUL.  Option
+// "general_kernels" (every sweep on the general kernel, which has no raw modes) switches them off as well.
 bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p0) {
-  if (p0.out_mode != OUT_STORE || opt(OPT_NO_RAW_TRANSFORMS)) return false;
+  if ((p0.out_mode != OUT_STORE && !(p0.out_mode == OUT_MUL && p0.raw == 1)) || opt(OPT_NO_RAW_TRANSFORMS) || opt(OPT_GENERAL_KERNELS)) return false;
   return sweep_vec_eligible(m, p0);
 }
 

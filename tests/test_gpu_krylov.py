@@ -88,6 +88,50 @@ def test_fgmres_max_it_and_restart(sp):
     ks.destroy(); op.destroy()
 
 
+@pytest.mark.parametrize("max_it,restart", [(4, 30), (5, 5), (1, 30), (7, 3)])
+def test_fgmres_truncated_solve_is_the_krylov_minimiser(sp, max_it, restart):
+    """A solve cut off by its iteration limit (the inner velocity solves of the Stokes preconditioners: -vel_ksp_max_it 4,
+    README:43) returns the minimiser of |b - A x| over the Krylov space it built -- also when the limit falls inside a cycle,
+    where the last basis vector is never normalised, and with a zero initial guess that is never written (x arrives as NaN).
+    Reference: least squares over the same space in numpy, cycle by cycle."""
+    import torch
+    dims = (9, 8)
+    op = sp.EllipticOp(dims)
+    n = op.global_size
+    A = dense(lambda e: orc.elliptic_mult(dims, e, mode=orc.DIRECT), n)
+    b = np.random.default_rng(SEED + 7).standard_normal(n)
+    x = np.zeros(n); left = max_it
+    while left > 0:                                       # restarted GMRES: each cycle minimises over K_k(A, r)
+        k = min(restart, left); r = b - A @ x
+        K = np.empty((n, k)); v = r.copy()
+        for j in range(k):
+            K[:, j] = v / np.linalg.norm(v); v = A @ K[:, j]
+        Q, _ = np.linalg.qr(K)
+        y = np.linalg.lstsq(A @ Q, r, rcond=None)[0]
+        x = x + Q @ y; left -= k
+    ks = sp.Fgmres(n, restart=restart, rtol=1e-300, max_it=max_it)
+    bd = torch.from_numpy(b).cuda(); xd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    ks.solve(op, bd, xd)
+    assert ks.reason == -3 and ks.iterations == max_it
+    xg = xd.cpu().numpy()
+    assert np.linalg.norm(xg - x) <= 1e-9 * np.linalg.norm(x), np.linalg.norm(xg - x) / np.linalg.norm(x)
+    assert abs(ks.residual - np.linalg.norm(b - A @ xg)) <= 1e-9 * np.linalg.norm(b)
+    ks.destroy(); op.destroy()
+
+
+def test_fgmres_zero_rhs_clears_x(sp):
+    """b = 0 with a zero initial guess: the solve ends before any update, and x (never written on the way) must come back 0."""
+    import torch
+    op = sp.EllipticOp((9, 8))
+    n = op.global_size
+    ks = sp.Fgmres(n, restart=10, rtol=1e-8, max_it=50)
+    bd = torch.zeros(n, dtype=torch.float64, device="cuda"); xd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    ks.solve(op, bd, xd)
+    assert ks.iterations == 0 and ks.reason > 0
+    assert float(xd.abs().max()) == 0.0
+    ks.destroy(); op.destroy()
+
+
 @pytest.mark.parametrize("dims", [(7, 6), (6, 5, 5)], ids=lambda d: "x".join(map(str, d)))
 def test_stokes_schur_vs_dense(sp, dims):
     """StokesMatMultSchur (stokes.C:523-535): y = -PV VV^{-1} VP x with the inner solve driven to 1e-12."""

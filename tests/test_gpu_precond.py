@@ -139,3 +139,30 @@ def test_stokes_velocity_pc(dims):
     assert ks.reason > 0 and ks.iterations <= 80, (ks.reason, ks.iterations)
     assert relerr(x.cpu().numpy(), v) < 1e-6
     ks.destroy(); pc.destroy(); st.destroy()
+
+
+@pytest.mark.parametrize("dims,stokes", [((20, 18, 16), False), ((34, 34, 34), False), ((66, 66, 66), False), ((70, 68, 40), False), ((40, 68, 130), False),
+                                         ((130, 70), False), ((40, 131), False), ((34, 34, 34), True), ((20, 18, 130), True)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("stokes" if v else "scalar"))
+def test_modal_scaling_in_the_last_forward_transform(dims, stokes):
+    """The modal scaling of the fast-diagonalisation solve rides on the store of the last forward line transform (OUT_MUL:
+    multiplication by the reciprocal sums, sweep.h) where that transform is one launch of the 16-byte kernels -- short and long
+    lines, both tilings, one and d stacked fields; odd interior extents keep the pass.  Option `modal_scale_pass` restores the
+    pass that divides: the two agree to rounding, and the solve is still the inverse of the stencil."""
+    op = sp.StokesOp(dims) if stokes else sp.EllipticOp(dims)
+    n = op.velocity_size if stokes else op.global_size
+    x = dev(np.random.default_rng(SEED + 11).standard_normal(n))
+    pc = sp.FdPc(op, sweeps=0)
+    z = pc.apply(x, out(n)).cpu().numpy()
+    back = pc.mult(dev(z), out(n)).cpu().numpy()
+    assert relerr(back, x.cpu().numpy()) < 1e-9
+    pc.destroy()
+    sp.set_option("modal_scale_pass", 1)
+    try:
+        pc = sp.FdPc(op, sweeps=0)
+        z1 = pc.apply(x, out(n)).cpu().numpy()
+        pc.destroy()
+    finally:
+        sp.set_option("modal_scale_pass", 0)
+    assert relerr(z, z1) < 1e-12
+    op.destroy()
