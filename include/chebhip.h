@@ -442,9 +442,9 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read
  *   saddle_node_major     1: the block preconditioners (stokes_saddle_*) keep the vectors of their inner velocity solves node-major as
  *                            the reference does, with a (de)interleaving pass around every MatVVPC solve (read at create; A/B)
- *   modal_scale_pass      1: the fast-diagonalisation solve of the finite-difference preconditioners divides by the modal sums in a
- *                            pass of its own instead of multiplying by their reciprocals in the store of the last forward line
- *                            transform (A/B; the two differ in the last bit)
+ *   fdm_passes            1: the fast-diagonalisation solve z = P_1^-1 (r / eta) of the finite-difference preconditioners divides by eta
+ *                            and by the modal sums in passes of their own, instead of multiplying by the reciprocals in the load of its
+ *                            first and the store of its last forward line transform (A/B; the two differ in the last bits)
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);

@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) void k_modal_weights3(int d, int n1, int nl, l
 }
 
 // out = (a - (y ? y : 0)) / eta_g  on nf stacked fields
+// einv = 1 / eta_g on nf stacked copies: the operand of the first forward line transform when it divides by the viscosity itself (IN_MUL)
+__global__ void k_eta_inverse(long G, const double *__restrict__ eta_g, double *__restrict__ einv) {
+  const long f0 = (long)blockIdx.y * G;
+  GS_LOOP(g, G) einv[f0 + g] = 1.0 / eta_g[g];
+}
 // (field = blockIdx.y: no 64-bit modulo per element)
 __global__ void k_resid_over_eta(long G, int nf, const double *__restrict__ a, const double *__restrict__ y,
                                  const double *__restrict__ eta_g, double *__restrict__ out) {
@@ -171,6 +176,7 @@ struct chebhip_fdpc {
   double *cf = nullptr, *eta_g = nullptr;
   double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr, *t5 = nullptr;   // nf * G each
   double *W = nullptr; bool W_tried = false;   // reciprocal modal weights, nf stacked copies (built on first use: fdm_solve)
+  double *Einv = nullptr; bool Einv_tried = false, Einv_ok = false;   // 1 / eta_g, nf stacked copies (rebuilt by fdpc_update; used by fdm_solve)
   int sweeps = 1;
   chebhip_fgmres *inner = nullptr; int inner_m = 0;   // the approximate solve with variable coefficients
   bool assembled = false;
@@ -192,7 +198,7 @@ static void fdpc_free(chebhip_fdpc *pc) {
     if (kv.second.lam) (void)hipFree(kv.second.lam);
   }
   for (int k = 0; k < MAXD; k++) if (pc->xs[k]) (void)hipFree(pc->xs[k]);
-  double *all[] = {pc->cf, pc->eta_g, pc->t0, pc->t1, pc->t2, pc->t3, pc->t4, pc->t5, pc->W};
+  double *all[] = {pc->cf, pc->eta_g, pc->t0, pc->t1, pc->t2, pc->t3, pc->t4, pc->t5, pc->W, pc->Einv};
   for (double *p : all) if (p) (void)hipFree(p);
   delete pc;
 }
@@ -268,6 +274,24 @@ static int fdpc_create(const FdView &v0, int nf, bool interleaved, chebhip_fdpc 
   return 0;
 }
 
+// 1 / eta for the first forward transform (lines of more than 64 points only: the kernels that take IN_MUL)
+static int fdpc_eta_inverse(chebhip_fdpc *pc, hipStream_t st) {
+  pc->Einv_ok = false;
+  if (opt(OPT_FDM_PASSES) || pc->G == 0) return 0;
+  bool any_long = false;
+  for (int k = 0; k < pc->geo.d; k++) any_long = any_long || pc->geo.dims[k] - 2 > 64;
+  if (!any_long) return 0;
+  if (!pc->Einv && !pc->Einv_tried) {
+    pc->Einv_tried = true;
+    if (hipMalloc((void **)&pc->Einv, (size_t)pc->nf * pc->G * sizeof(double)) != hipSuccess) { pc->Einv = nullptr; (void)hipGetLastError(); }
+  }
+  if (!pc->Einv) return 0;
+  hipLaunchKernelGGL(k_eta_inverse, dim3(pgrid(pc->G), (unsigned)pc->nf), dim3(256), 0, st, pc->G, (const double *)pc->eta_g, pc->Einv);
+  PHIPCHK(hipGetLastError());
+  pc->Einv_ok = true;
+  return 0;
+}
+
 static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
   FdView v;
   int rc = pc->eop ? ell_op_fd_view_any(pc->eop, &v, nullptr) : stokes_op_fd_view_any(pc->sop, &v, nullptr);
@@ -278,31 +302,45 @@ static int fdpc_update(chebhip_fdpc *pc, hipStream_t st) {
     hipLaunchKernelGGL(k_eta_g, dim3(pgrid(pc->N)), dim3(256), 0, st, pc->N, v.ixL, v.eta, pc->eta_g);
     PHIPCHK(hipGetLastError());
     pc->assembled = true;
-    return 0;
+    return fdpc_eta_inverse(pc, st);
   }
   GradPtrs gu; CoordPtrs xs;
   for (int k = 0; k < MAXD; k++) { gu.p[k] = k < v.d ? v.gradu[k] : nullptr; xs.p[k] = pc->xs[k]; }
   hipLaunchKernelGGL(k_fd_assemble, dim3(pgrid(pc->N)), dim3(256), 0, st, pc->geo, pc->N, pc->G, v.ixL, v.eta, v.deta, gu, xs, pc->cf, pc->eta_g);
   PHIPCHK(hipGetLastError());
   pc->assembled = true;
-  return 0;
+  return fdpc_eta_inverse(pc, st);
 }
 
 // y = S^-1 x (forward) or S x (backward) along dimension k of nf stacked interior fields (x != y): one raw-mode launch
 // where the 16-byte kernels can run it, otherwise the centro-symmetric plus the centro-antisymmetric part (two launches)
 // mul (forward transforms only; may be null): the result is multiplied by this array as it is stored (OUT_MUL) where the one-launch
 // form runs, and *fused says whether it was
+// in_mul (forward only; may be null): every input element is multiplied by this array as it is loaded (IN_MUL) -- the caller has
+// asked line_in_mul_ok first
 static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st,
-                            const double *mul = nullptr, bool *fused = nullptr);
-static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st, const double *mul = nullptr, bool *fused = nullptr) {
+                            const double *mul = nullptr, bool *fused = nullptr, const double *in_mul = nullptr);
+static int line_transform(chebhip_fdpc *pc, int k, bool backward, const double *x, double *y, hipStream_t st, const double *mul = nullptr, bool *fused = nullptr,
+                          const double *in_mul = nullptr) {
   if (fused) *fused = false;
   if (pc->slab && k == 0) return pc->dim0(pc->dim0_ctx, backward ? 1 : 0, pc->nf, x, y, (void *)st);      // collective: every rank of the slab partition
-  return line_transform_g(pc->lines[pc->geo.dims[k]], pc->ncols_g[k] * (unsigned)pc->nf, pc->inner_g[k], backward, x, y, st, mul, fused);
+  return line_transform_g(pc->lines[pc->geo.dims[k]], pc->ncols_g[k] * (unsigned)pc->nf, pc->inner_g[k], backward, x, y, st, mul, fused, in_mul);
+}
+static SweepParams line_in_mul_params(unsigned ncols, unsigned inner, const double *x, double *y, const double *in_mul) {
+  SweepParams sm = {};
+  sm.ncols = ncols; sm.inner = inner; sm.in0 = x; sm.in1 = in_mul; sm.in_mode = IN_MUL; sm.out = y; sm.alpha = 1.0; sm.out_mode = OUT_STORE; sm.raw = 1;
+  return sm;
+}
+static bool line_in_mul_ok(chebhip_fdpc *pc, int k, const double *x, double *y, const double *in_mul) {
+  if ((pc->slab && k == 0) || !in_mul) return false;
+  const unsigned ncols = pc->ncols_g[k] * (unsigned)pc->nf;
+  return ncols != 0 && sweep_vec_raw_eligible(pc->lines[pc->geo.dims[k]].Fraw, line_in_mul_params(ncols, pc->inner_g[k], x, y, in_mul));
 }
 static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool backward, const double *x, double *y, hipStream_t st,
-                            const double *mul, bool *fused) {
+                            const double *mul, bool *fused, const double *in_mul) {
   if (fused) *fused = false;
   if (ncols == 0) return 0;
+  if (in_mul && !backward) { PHIPCHK(sweep_launch(lm.Fraw, line_in_mul_params(ncols, inner, x, y, in_mul), st)); return 0; }
   SweepParams sp = {};
   sp.ncols = ncols; sp.inner = inner;
   sp.in0 = x; sp.in_mode = IN_PLAIN; sp.out = y; sp.alpha = 1.0;
@@ -322,19 +360,34 @@ static int line_transform_g(LineMats &lm, unsigned ncols, unsigned inner, bool b
   return 0;
 }
 
-// z = P_1^-1 r (the constant-coefficient part, exactly); r is not modified; t0 / t1 are scratch (r, z must be neither)
-static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t st) {
+// z = P_1^-1 r (the constant-coefficient part, exactly), or z = P_1^-1 (r / eta) with over_eta; r is not modified; t0 / t1 (/ t3 with
+// over_eta) are scratch (r, z must be none of them)
+static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t st, bool over_eta = false) {
   const int d = pc->geo.d;
   const double *src = r;
   double *a = pc->t0, *b = pc->t1;
+  // Forward transforms commute: on slabs the first one is a local direction (1) rather than the collective one (0), so that it
+  // can take the division by eta on its load side; the last one (d-1) takes the modal scaling on its store side.
+  int order[MAXD];
+  for (int k = 0; k < d; k++) order[k] = k;
+  if (pc->slab && d >= 2) { order[0] = 1; order[1] = 0; }
+  const double *in_mul = nullptr;
+  if (over_eta) {
+    if (pc->Einv_ok && !opt(OPT_FDM_PASSES) && d >= 2 && line_in_mul_ok(pc, order[0], r, a, pc->Einv)) in_mul = pc->Einv;
+    else {
+      hipLaunchKernelGGL(k_resid_over_eta, dim3(pgrid(pc->G), (unsigned)pc->nf), dim3(256), 0, st, pc->G, pc->nf, r, (const double *)nullptr,
+                         (const double *)pc->eta_g, pc->t3);
+      src = pc->t3;
+    }
+  }
   LamPtrs lam; for (int k = 0; k < MAXD; k++) lam.p[k] = k < d ? pc->lines[pc->geo.dims[k]].lam : nullptr;
   const int nl = pc->geo.dims[d - 1] - 2;
   const long lines = pc->G / nl;
   if (pc->slab && d >= 2) lam.p[0] += pc->i0_off;         // the slab's first interior plane is plane i0_off of the global line
   // The modal scaling rides on the store of the last forward transform (dimension d-1 > 0: local on slabs too) where that
   // transform is one launch of the 16-byte kernels: it multiplies by W = 1 / (l_i + l_j + l_k), built here on first use (the
-  // separate pass divides: the two differ in the last bit).  Option "modal_scale_pass" = 1 keeps the pass (A/B).
-  if (!pc->W && !pc->W_tried && d >= 2 && d <= 3 && lines > 0 && lines <= 65535 && pc->nf <= 65535 && !opt(OPT_MODAL_SCALE_PASS)) {
+  // separate pass divides: the two differ in the last bit).  Option "fdm_passes" = 1 keeps both pointwise passes (A/B).
+  if (!pc->W && !pc->W_tried && d >= 2 && d <= 3 && lines > 0 && lines <= 65535 && pc->nf <= 65535 && !opt(OPT_FDM_PASSES)) {
     pc->W_tried = true;
     if (hipMalloc((void **)&pc->W, (size_t)pc->nf * pc->G * sizeof(double)) == hipSuccess) {
       const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
@@ -344,9 +397,10 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
     } else { pc->W = nullptr; (void)hipGetLastError(); }
   }
   bool scaled = false;
-  for (int k = 0; k < d; k++) {
-    const bool last = k == d - 1 && pc->W && !opt(OPT_MODAL_SCALE_PASS);
-    int rc = line_transform(pc, k, false, src, a, st, last ? pc->W : nullptr, last ? &scaled : nullptr); if (rc) return rc;
+  for (int q = 0; q < d; q++) {
+    const int k = order[q];
+    const bool last = q == d - 1 && q > 0 && pc->W && !opt(OPT_FDM_PASSES);
+    int rc = line_transform(pc, k, false, src, a, st, last ? pc->W : nullptr, last ? &scaled : nullptr, q == 0 ? in_mul : nullptr); if (rc) return rc;
     src = a; std::swap(a, b);
   }
   if (!scaled) {
@@ -390,9 +444,7 @@ static int cb_fd_mult(void *ctx, const double *x, double *y, void *stream) {
 }
 static int cb_fdm(void *ctx, const double *r, double *z, void *stream) {
   chebhip_fdpc *pc = (chebhip_fdpc *)ctx;
-  hipLaunchKernelGGL(k_resid_over_eta, dim3(pgrid(pc->G), (unsigned)pc->nf), dim3(256), 0, (hipStream_t)stream, pc->G, pc->nf, r, (const double *)nullptr,
-                     (const double *)pc->eta_g, pc->t3);
-  return fdm_solve(pc, pc->t3, z, (hipStream_t)stream);
+  return fdm_solve(pc, r, z, (hipStream_t)stream, true);
 }
 
 static int fdpc_apply(chebhip_fdpc *pc, const double *r, double *z, hipStream_t st) {

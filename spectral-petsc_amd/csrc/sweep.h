@@ -11,8 +11,10 @@ enum InMode : int {
   IN_GATHER = 1,    // v = interior ? in0_global[g] : 0            (VecScatter GL + dirichlet0, elliptic.C:305-308)
   IN_FLUX_ETA = 2,  // v = in1[a] * in0[a]                         (eta * g, elliptic.C:511)
   IN_FLUX_FULL = 3, // v = in1[a]*in0[a] + in2[a]*in3[a]*in4[a]    (eta*g + deta*u*du0, elliptic.C:321)
-  IN_SUM3 = 4       // v = (in0[a] + in1[a]) + in2[a]              (lines of at most 64 points, 16-byte kernels only: the
+  IN_SUM3 = 4,      // v = (in0[a] + in1[a]) + in2[a]              (lines of at most 64 points, 16-byte kernels only: the
                     //   divergence of the uniform-viscosity Stokes path as the sum of its three terms, stokes.hip)
+  IN_MUL = 5        // v = in0[a] * in1[a]                         (lines of more than 64 points, 16-byte kernels with raw = 1 only:
+                    //   the 1 / eta of the fast-diagonalisation solve folded into its first forward line transform, precond.hip)
 };
 
 // What happens to one element r of the derivative on store.
@@ -163,7 +165,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_VENDOR_GEMM, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_DIST_EXACT_ORDER, OPT_MODAL_SCALE_PASS, OPT_SADDLE_NODE_MAJOR, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_DIST_EXACT_ORDER, OPT_FDM_PASSES, OPT_SADDLE_NODE_MAJOR, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

@@ -403,9 +403,12 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 
 // MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
 // preconditioner's fast diagonalisation folded into its last forward transform -- RAW = 1 only)
-template <int KS, bool JFAST, int MODE, int RAW = 0>
+// INM: 1 = IN_MUL, every input element is multiplied by the element of in1 at the same place as it is split into LDS (the 1 / eta
+// of the preconditioner's P_1^-1 (r / eta) folded into its first forward transform -- RAW = 1, STORE only)
+template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
   constexpr bool ACC = MODE != 0, MUL = MODE == 2;       // ACC: the operand stream exists
+  static_assert(INM == 0 || (RAW == 1 && MODE == 0), "IN_MUL exists for the raw forward transform with a plain store only");
   static_assert(RAW == 0 || MODE != 1, "the raw modes (sweep.h) are STORE / MUL only");
   static_assert(!MUL || RAW == 1, "OUT_MUL exists for the raw forward transform only");
   constexpr int MTP = KS / 4;
@@ -440,6 +443,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   const u32 qmax = p.qmax;
 
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in0, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_in1 = __builtin_amdgcn_make_buffer_rsrc((void *)(INM ? p.in1 : p.in0), 0, INM ? p.in_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC ? p.acc : p.in0), 0, ACC ? p.acc_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
@@ -480,10 +484,21 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   };
 
   d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
+  constexpr int ECH = INM ? CH : 1;
+  d2 ejA[ECH], emA[ECH], ejB[ECH], emB[ECH];           // IN_MUL: the multipliers of chunk A / B, in flight beside them
   d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];
 
   auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
     const u32 t0 = in_tile_off(tl);
+    if constexpr (INM != 0) {
+      d2 (&ej)[ECH] = (&rj == &rjA) ? ejA : ejB; d2 (&em)[ECH] = (&rj == &rjA) ? emA : emB;
+#pragma unroll
+      for (int s = 0; s < CH; s++) {
+        const u32 so = (u32)(chunk * CH + s) * slot8;
+        ej[s] = ld16(r_in1, lj + (valid ? t0 + so : T_INVALID));
+        em[s] = ld16(r_in1, lm + (valid ? (JFAST ? t0 + so : t0 - so) : T_INVALID));
+      }
+    }
     if constexpr (V4_ABLATE & 1) { if (tl != p.ntiles + 12345u) {
 #pragma unroll
       for (int s = 0; s < CH; s++) { rj[s] = d2{1.0 + s, 2.0}; rm[s] = d2{0.5, 0.25 * chunk}; }
@@ -502,16 +517,21 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     for (int s = 0; s < CH; s++) {
       const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
       d2 e, o;
+      d2 xj = rj[s], xm = rm[s];
+      if constexpr (INM != 0) {
+        const d2 (&ej)[ECH] = (&rj == &rjA) ? ejA : ejB; const d2 (&em)[ECH] = (&rj == &rjA) ? emA : emB;
+        xj = xj * ej[s]; xm = xm * em[s];
+      }
       if (RAW == 2) {                                  // already split: e_j = x_j, o_j = x_{n-j} (a middle o meets a zero column)
-        e = rj[s];
-        o = JFAST ? d2{rm[s].y, rm[s].x} : rm[s];
+        e = xj;
+        o = JFAST ? d2{xm.y, xm.x} : xm;
       } else if (!JFAST) {
-        e = rj[s] + rm[s];
-        o = rj[s] - rm[s];                             // the middle point of an odd line is its own mirror: o = 0
-        if (oddP) { const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn; if (mid) e = rj[s]; }
+        e = xj + xm;
+        o = xj - xm;                                   // the middle point of an odd line is its own mirror: o = 0
+        if (oddP) { const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn; if (mid) e = xj; }
       } else {
-        e = d2{rj[s].x + rm[s].y, rj[s].y + rm[s].x};
-        o = d2{rj[s].x - rm[s].y, rj[s].y - rm[s].x};
+        e = d2{xj.x + xm.y, xj.y + xm.x};
+        o = d2{xj.x - xm.y, xj.y - xm.x};
       }
       *(d2 *)(dE + idx) = e;
       *(d2 *)(dO + idx) = o;
@@ -725,10 +745,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
 #endif
 }
 
-template <int KS, bool JFAST, int MODE, int RAW = 0>
+template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0>
 __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams p) {
   __shared__ double smem[vec_lds_doubles<KS, JFAST>()];
-  vec4_body<KS, JFAST, MODE, RAW>(p, smem, blockIdx.x, gridDim.x);
+  vec4_body<KS, JFAST, MODE, RAW, INM>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,7 +777,11 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams
 
 template <int KS, bool JFAST>
 static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t stream) {
-  if (p.out_mode == OUT_MUL) {
+  if (p.in_mode == IN_MUL) {
+    if (p.raw != 1 || p.out_mode != OUT_STORE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0, 1, 1>), dim3(grid), dim3(512), 0, stream, p);
+  }
+  else if (p.out_mode == OUT_MUL) {
     if (p.raw != 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 2, 1>), dim3(grid), dim3(512), 0, stream, p);
   }
@@ -833,6 +857,7 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   else {
     if (p.raw && p.out_mode != OUT_STORE && !(p.out_mode == OUT_MUL && p.raw == 1)) return hipErrorInvalidValue;
     if (p.out_mode == OUT_MUL && p.raw != 1) return hipErrorInvalidValue;
+    if (p.in_mode == IN_MUL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
     sweep_note_launch();
     return hipGetLastError();
@@ -847,6 +872,9 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   if (p.in_mode == IN_SUM3) {                            // multi-job launches of short lines only (launch_multi_t)
     auto al16 = [](const void *q) { return q && ((size_t)q & 15) == 0; };
     if (m.KS > 8 || p.out_mode != OUT_STORE || p.raw || p.in_fblocks || p.qmax || p.in_os || !al16(p.in1) || !al16(p.in2)) return false;
+  } else
+  if (p.in_mode == IN_MUL) {                             // lines of more than 64 points, raw forward transform, plain store, dense geometry
+    if (m.KS < 16 || p.raw != 1 || p.out_mode != OUT_STORE || p.in_fblocks || p.qmax || p.in_os || !p.in1 || ((size_t)p.in1 & 15)) return false;
   } else
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC && !(p.out_mode == OUT_MUL && p.raw == 1))) return false;
   const bool jfast = p.inner < 16;
@@ -894,7 +922,7 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
 // *done = false: the caller launches them one by one
 template <int KS>
 static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done) {
-  for (int j = 0; j < n; j++) if (jobs[j].raw) { *done = false; return hipSuccess; }
+  for (int j = 0; j < n; j++) if (jobs[j].raw || jobs[j].in_mode == IN_MUL) { *done = false; return hipSuccess; }
   bool sum3 = jobs[0].in_mode == IN_SUM3;                  // all jobs or none (stokes.hip: the three sweeps of grad div v)
   for (int j = 1; j < n; j++) if ((jobs[j].in_mode == IN_SUM3) != sum3) { *done = false; return hipSuccess; }
   if (sum3 && KS > 8) { *done = false; return hipSuccess; }

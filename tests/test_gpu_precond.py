@@ -141,28 +141,45 @@ def test_stokes_velocity_pc(dims):
     ks.destroy(); pc.destroy(); st.destroy()
 
 
+@pytest.mark.parametrize("visc", ["unit", "variable"])
 @pytest.mark.parametrize("dims,stokes", [((20, 18, 16), False), ((34, 34, 34), False), ((66, 66, 66), False), ((70, 68, 40), False), ((40, 68, 130), False),
-                                         ((130, 70), False), ((40, 131), False), ((34, 34, 34), True), ((20, 18, 130), True)],
+                                         ((130, 70), False), ((40, 131), False), ((131, 40), False), ((34, 34, 34), True), ((20, 18, 130), True), ((70, 20, 18), True)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("stokes" if v else "scalar"))
-def test_modal_scaling_in_the_last_forward_transform(dims, stokes):
-    """The modal scaling of the fast-diagonalisation solve rides on the store of the last forward line transform (OUT_MUL:
-    multiplication by the reciprocal sums, sweep.h) where that transform is one launch of the 16-byte kernels -- short and long
-    lines, both tilings, one and d stacked fields; odd interior extents keep the pass.  Option `modal_scale_pass` restores the
-    pass that divides: the two agree to rounding, and the solve is still the inverse of the stencil."""
+def test_pointwise_steps_inside_the_line_transforms(dims, stokes, visc):
+    """z = P_1^-1 (r / eta): the division by eta rides on the LOAD of the first forward line transform (IN_MUL, lines of more than
+    64 points) and the modal scaling on the STORE of the last one (OUT_MUL) -- multiplications by reciprocals, sweep.h -- where
+    those transforms are one launch of the 16-byte kernels: short and long lines, both tilings, one and d stacked fields; odd
+    interior extents keep the passes.  Option `fdm_passes` restores the two passes that divide: the routes agree to rounding,
+    and with eta == 1 the solve is still the inverse of the stencil."""
     op = sp.StokesOp(dims) if stokes else sp.EllipticOp(dims)
     n = op.velocity_size if stokes else op.global_size
-    x = dev(np.random.default_rng(SEED + 11).standard_normal(n))
+    rng = np.random.default_rng(SEED + 11)
+    if visc == "variable":
+        if stokes:
+            op.set_state(0, np.exp(rng.uniform(np.log(0.5), np.log(10.0), int(np.prod(dims)))))
+        else:                                             # eta = 1 + u^2 of a FormFunction (elliptic.C:507-513, gamma = 1)
+            u = dev(rng.uniform(0.0, 2.0, n))
+            op.function(u, dev(np.zeros(n)), out(n), 1.0, 2.0)
+    x = dev(rng.standard_normal(n))
     pc = sp.FdPc(op, sweeps=0)
     z = pc.apply(x, out(n)).cpu().numpy()
-    back = pc.mult(dev(z), out(n)).cpu().numpy()
-    assert relerr(back, x.cpu().numpy()) < 1e-9
+    if visc == "unit":
+        back = pc.mult(dev(z), out(n)).cpu().numpy()
+        assert relerr(back, x.cpu().numpy()) < 1e-9
+    zc = None
+    if stokes:                                            # ... and on component-major vectors (the block preconditioners' layout)
+        d = len(dims)
+        xc = dev(np.ascontiguousarray(x.cpu().numpy().reshape(-1, d).T).ravel())
+        zc = np.ascontiguousarray(pc.apply_cm(xc, out(n)).cpu().numpy().reshape(d, -1).T).ravel()
     pc.destroy()
-    sp.set_option("modal_scale_pass", 1)
+    sp.set_option("fdm_passes", 1)
     try:
         pc = sp.FdPc(op, sweeps=0)
         z1 = pc.apply(x, out(n)).cpu().numpy()
         pc.destroy()
     finally:
-        sp.set_option("modal_scale_pass", 0)
+        sp.set_option("fdm_passes", 0)
     assert relerr(z, z1) < 1e-12
+    if zc is not None:
+        assert relerr(zc, z1) < 1e-12
     op.destroy()
