@@ -128,7 +128,7 @@ __global__ void k_sqrt1(double *__restrict__ p) { if (threadIdx.x == 0 && blockI
 // w -= sum_{kk<k} h[kk] V[kk];  npart[b] = sum over chunk b of w^2
 __global__ __launch_bounds__(ST) void k_orth_update(long n, int k, const double *__restrict__ V, long ldv,
                                                     const double *__restrict__ dpart, double *hcol,
-                                                    double *__restrict__ w, double *__restrict__ npart) {
+                                                    double *__restrict__ w, double *__restrict__ npart, int store) {   // store = 0: only |w - V h|^2 is wanted
   __shared__ double sh[ST / 64];
   __shared__ double h[ST];
   for (int kk = threadIdx.x; kk < k; kk += ST) {
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(ST) void k_orth_update(long n, int k, const double 
       x -= h[kk] * a0; x -= h[kk + 1] * a1; x -= h[kk + 2] * a2; x -= h[kk + 3] * a3;
     }
     for (; kk < k; kk++) x -= h[kk] * V[(long)kk * ldv + i];
-    w[i] = x; s += x * x;
+    if (store) w[i] = x;
+    s += x * x;
   }
   const double r = block_sum_t<ST>(s, sh);
   if (threadIdx.x == 0) npart[blockIdx.x] = r;
@@ -390,13 +391,13 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       if ((n & 1) == 0) hipLaunchKernelGGL((k_multidot_grouped<true>), dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       else hipLaunchKernelGGL((k_multidot_grouped<false>), dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       if (!k->reduce) {
-        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart);
+        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->part, k->hcol, w, k->npart, use_next);
         hipLaunchKernelGGL(k_givens_scale, dim3(gsgrid), dim3(RT), 0, st, j, m, (const double *)k->npart, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->res,
                            (const double *)nullptr, n, w, use_next);
       } else {            // several ranks: local sums -> all-reduce -> update; the same for |w|^2
         hipLaunchKernelGGL(k_rows_finish, dim3(j + 1), dim3(RT), 0, st, (const double *)k->part, k->hcol, 0);
         if ((rc = k->reduce(k->reduce_ctx, k->hcol, j + 1, st))) return rc;
-        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)nullptr, k->hcol, w, k->npart);
+        hipLaunchKernelGGL(k_orth_update, dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)nullptr, k->hcol, w, k->npart, use_next);
         hipLaunchKernelGGL(k_rows_finish, dim3(1), dim3(RT), 0, st, (const double *)k->npart, k->nsq, 0);
         if ((rc = k->reduce(k->reduce_ctx, k->nsq, 1, st))) return rc;
         hipLaunchKernelGGL(k_givens_scale, dim3(gsgrid), dim3(RT), 0, st, j, m, (const double *)nullptr, (const double *)k->hcol, k->H, k->cs, k->sn, k->G, k->res,

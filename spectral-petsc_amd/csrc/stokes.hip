@@ -346,7 +346,8 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
                          const double *__restrict__ yL1, const double *__restrict__ yL2,
                          const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
                          const double *__restrict__ p2, int po, const double *__restrict__ force, double *__restrict__ out,
-                         const double *__restrict__ G, long cs) {       // G (may be null): one more velocity term (d fields), added after yL2
+                         const double *__restrict__ G, long cs,         // G (may be null): one more velocity term (d fields), added after yL2
+                         const double *__restrict__ p2b = nullptr, const double *__restrict__ p2c = nullptr) {   // pressure rows (p2 + p2b) + p2c
   GS_LOOP(l, N) {                                                       // cs: component stride of out / force (see k_st_local)
     const int n = ixL[l];
     if (n < 0) continue;
@@ -370,7 +371,7 @@ __global__ void k_st_out(long N, int gs, const int *__restrict__ ixL, const doub
 #pragma unroll
       for (int k = 0; k < D; k++) { if (force) v[k] += -1.0 * force[o + k * cs]; out[o + k * cs] = v[k]; }
     }
-    if (p2) { double w = p2[l]; if (force) w += -1.0 * force[o + po]; out[o + po] = w; }
+    if (p2) { double w = p2[l]; if (p2b) w = w + p2b[l]; if (p2c) w = w + p2c[l]; if (force) w += -1.0 * force[o + po]; out[o + po] = w; }
   }
 }
 
@@ -1151,6 +1152,25 @@ static int st_mult_pv(stokes_op *op, const double *vG, double *pout, hipStream_t
   const int d = op->d;
   if (st_cm_pairs(op, cm)) st_local_cm(op, vG, st); else
   st_local(op, cm ? 1 : d, 0, vG, nullptr, op->xL, nullptr, st, cm ? op->I : 1);
+  if (!op->slab && d >= 2) {
+    // the d terms D_i v_i as ONE launch of d jobs into arrays of their own (yL is free here), summed by the scatter in the order of
+    // the accumulating chain, (t_0 + t_1) + t_2: the same bits, two dependent launches less (128^3: 77 -> 57 us)
+    const DiffMat *m[3]; SweepParams sp[3];
+    for (int k = 0; k < d; k++) {
+      sp[k] = SweepParams{};
+      sp[k].ncols = op->ncolsP[k]; sp[k].inner = op->innerP[k];
+      sp[k].in0 = op->xL + (size_t)k * op->N; sp[k].in_mode = IN_PLAIN; sp[k].out = op->yL + (size_t)k * op->N; sp[k].out_mode = OUT_STORE; sp[k].alpha = 1.0;
+      m[k] = &op->mats[op->dims[k]];
+    }
+    bool done = false;
+    SHIPCHK(sweep_launch_multi_try(d, m, sp, st, &done));
+    if (done) {
+      ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->yL), 0, CDP(nullptr), pout, CDP(nullptr), 1L,
+             CDP(op->yL + op->N), CDP(d == 3 ? op->yL + 2 * op->N : nullptr));
+      SHIPCHK(hipGetLastError());
+      return 0;
+    }
+  }
   int rc = st_divergence(op, st); if (rc) return rc;
   ST_OUT(1, (const int *)op->ixL, CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(nullptr), CDP(op->p2), 0, CDP(nullptr), pout, CDP(nullptr), 1L);
   SHIPCHK(hipGetLastError());
