@@ -435,7 +435,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *                            pressure gradient instead of folding each direction's extrapolation into its matrix (read at create)
  *   general_viscous       1: StokesMatMult / StokesMatMultVV take the general viscous block also when the viscosity is uniform and
  *                            eta' = 0 (linear rheology), instead of -eta/2 (sum_j D_j D_j v + grad div v) (read at create)
- *   poisson_launches      the constant-coefficient MatMult_Elliptic: 0 = by size (one launch of d jobs + a sum below 6 M unknowns,
+ *   poisson_launches      the constant-coefficient MatMult_Elliptic: 0 = by size (below 6 M unknowns: from 1.5 M on, in 3-D with lines of at most 128 points, two
+ *                            jobs in one launch and a last direction that adds both terms as it stores, otherwise one launch of d jobs + a sum;
  *                            a launch per direction above), 1 = always the d-job launch, 2 = always a launch per direction
  *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
  *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array

@@ -224,6 +224,25 @@ extern "C" int cheb_apply_lap1d(cheb_plan *p, const double *x, const double *acc
   return 0;
 }
 
+// n trimmed plans on the same tensor (different directions): outs[k] = alpha * (D_k D_k x) as ONE launch of n jobs where the 16-byte
+// kernels allow it (*done), otherwise nothing is launched.  The local directions of a small slab (dist.hip).
+namespace chebhip {
+int lap1d_multi_try(int n, cheb_plan *const *plans, const double *x, double *const *outs, double alpha, hipStream_t st, bool *done) {
+  *done = false;
+  if (n < 2 || n > 9) return 0;
+  const DiffMat *m[9]; SweepParams sp[9];
+  for (int k = 0; k < n; k++) {
+    if (!plans[k] || !plans[k]->trimmed) return 0;
+    sp[k] = SweepParams{};
+    sp[k].ncols = plans[k]->ncols; sp[k].inner = plans[k]->inner;
+    sp[k].in0 = x; sp[k].in_mode = IN_PLAIN; sp[k].alpha = alpha; sp[k].out = outs[k]; sp[k].out_mode = OUT_STORE;
+    m[k] = &plans[k]->lap;
+  }
+  HIPCHK(sweep_launch_multi_try(n, m, sp, st, done));
+  return 0;
+}
+}  // namespace chebhip
+
 extern "C" int cheb_apply(cheb_plan *p, const double *x, double *y, void *stream) {
   if (!p || !x || !y) return fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (x == y) return fail(CHEBHIP_ERR_ARG, "x and y must be distinct (as every ChebMult call site)");
@@ -963,6 +982,27 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
         }
         const DiffMat *m[3]; SweepParams sp[3];
         double *term[3] = {op->W, op->Wj[0], op->Wj[1]};
+        // d = 3, lines of at most 128 points (round 4): the first two directions as one launch of two jobs, and the LAST direction takes
+        // both terms as it stores, V = (t_0 + t_1) - L_2 U (OUT_ACC2: the chain's order, the same bits) -- two launches and 64 B/point
+        // instead of a three-job launch, 80 B/point and a sum pass.  poisson_launches = 1 keeps the three-job route (A/B, one handle,
+        // tools/poisson_ab.py): 128^3 36.5 -> 32.8 us; 96^3 25.4 -> 29.3 and 64^3 10.7 -> 13.3 the other way (there the second launch
+        // costs more than the bytes it saves), hence the lower size limit.
+        if (d == 3 && mode == 0 && op->G >= 1500000L) {
+          SweepParams last = {};
+          last.ncols = op->ncols_g[2]; last.inner = op->inner_g[2];
+          last.in0 = U; last.in_mode = IN_PLAIN; last.alpha = -1.0; last.out_mode = OUT_ACC2; last.acc = term[0]; last.acc2 = term[1]; last.out = V;
+          if (!opt(OPT_GENERAL_KERNELS) && sweep_vec_eligible(op->laps[op->dims[2]], last)) {
+            for (int k = 0; k < 2; k++) {
+              sp[k] = SweepParams{};
+              sp[k].ncols = op->ncols_g[k]; sp[k].inner = op->inner_g[k];
+              sp[k].in0 = U; sp[k].in_mode = IN_PLAIN; sp[k].alpha = -1.0; sp[k].out_mode = OUT_STORE; sp[k].out = term[k];
+              m[k] = &op->laps[op->dims[k]];
+            }
+            bool done2 = false;
+            HIPCHK(sweep_launch_multi_try(2, m, sp, st, &done2));
+            if (done2) { HIPCHK(sweep_launch(op->laps[op->dims[2]], last, st)); return 0; }
+          }
+        }
         for (int k = 0; k < d; k++) {
           sp[k] = SweepParams{};
           sp[k].ncols = op->ncols_g[k]; sp[k].inner = op->inner_g[k];

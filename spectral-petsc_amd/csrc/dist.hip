@@ -220,9 +220,17 @@ extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, vo
   // "dist_exact_order" = 0 (default): the local terms are summed by the sweeps, A_1 = -L_1 U (STORE), A_1 -= L_k U (ACC): the
   // final sum reads T and ONE array, V = T + (A_1 + A_2 ..) -- the serial vector to rounding (north_star 1e-10);
   // 1: every term in an array of its own and V = ((T + A_1) + A_2) in the order of elliptic.C:331-334 -- the serial bits.
-  const bool exact = chebhip::opt(chebhip::OPT_DIST_EXACT_ORDER) != 0;
+  bool exact = chebhip::opt(chebhip::OPT_DIST_EXACT_ORDER) != 0;
   int rc = 0;
-  for (int k = 1; k < d && !rc; k++) {
+  // Small slabs (fewer than 6 M values: 256^3 over 4 ranks and more), d >= 3: the d - 1 local directions are ONE launch of d - 1 jobs
+  // into arrays of their own, and the final sum reads them in the serial order -- at these sizes a launch costs its fixed 10-13 us
+  // (matrix fetch, fill, drain), not its bytes, and the extra array sits in the Infinity Cache.  The one-GPU bits, as with the option.
+  bool local_done = false;
+  if (d >= 3 && D->local > 0 && D->local < 6000000L && !chebhip::opt(chebhip::OPT_SEPARATE_LAUNCHES)) {
+    rc = chebhip::lap1d_multi_try(d - 1, D->slab_plan.data() + 1, U, D->A.data(), -1.0, side, &local_done);
+    if (local_done) exact = true;
+  }
+  for (int k = 1; k < d && !rc && !local_done; k++) {
     if (exact || k == 1) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[exact ? k - 1 : 0], side);
     else rc = cheb_apply_lap1d(D->slab_plan[k], U, D->A[0], -1.0, D->A[0], side);
   }

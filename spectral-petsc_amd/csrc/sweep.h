@@ -22,6 +22,8 @@ enum OutMode : int {
   OUT_STORE = 0,        // out[a] = alpha*r
   OUT_ACC = 1,          // out[a] = acc[a] + alpha*r               (VecAXPY, elliptic.C:333)
   OUT_ACC_SCATTER = 2,  // interior: out_global[g] = (acc ? acc[a] : 0) + alpha*r   (+ VecScatter LG, elliptic.C:336)
+  OUT_ACC2 = 4,         // out[a] = (acc[a] + acc2[a]) + alpha*r      (16-byte kernels, lines of at most 128 points: the last direction of the
+                        //   constant-coefficient MatMult_Elliptic on small grids takes the two earlier terms as they are, chebhip.hip)
   OUT_MUL = 3           // out[a] = acc[a] * (alpha*r)               (16-byte kernels with raw = 1 only: the modal scaling of the
                         //   fast-diagonalisation solve folded into its last forward line transform, precond.hip)
 };
@@ -41,6 +43,7 @@ struct SweepParams {
   const double *in0, *in1, *in2, *in3, *in4;
   double *out;
   const double *acc;
+  const double *acc2; // OUT_ACC2: the second operand, geometry of acc
   const int *gcol;    // [ncols] global index of the (j=1) node of a line, -1 for boundary lines
   long gstride;       // stride of the transform dim in the global (interior) layout
   double alpha;
@@ -159,6 +162,11 @@ hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams 
 hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream, bool *done);
 
 long sweep_launch_count();
+}  // namespace chebhip
+struct cheb_plan;
+namespace chebhip {
+// chebhip.hip: the interior second derivative along n directions of one tensor as ONE launch (see there)
+int lap1d_multi_try(int n, cheb_plan *const *plans, const double *x, double *const *outs, double alpha, hipStream_t st, bool *done);
 // compute units of the CURRENT device (cached per device id); 0 on error with *err set
 int sweep_num_cus(hipError_t *err);
 

@@ -492,7 +492,7 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym;
   p.longDT = m.longDT; p.longD = m.longD;
   if (m.KS == 0) {
-    if (!m.longDT || p.out_mode == OUT_MUL || p.in_mode == IN_MUL) return hipErrorInvalidValue;
+    if (!m.longDT || p.out_mode == OUT_MUL || p.out_mode == OUT_ACC2 || p.in_mode == IN_MUL) return hipErrorInvalidValue;
     // lines of 257 .. 1024 points: the library's own matrix-core kernel; option "long_lines_gemm": the rocBLAS route (A/B)
     if (!opt(OPT_LONG_LINES_GEMM) && sweep_xl_eligible(m, p)) return sweep_xl_launch(m, p, stream);
     return launch_long(p, stream);
@@ -504,7 +504,7 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
       return sweep_vec_launch(m, p, stream);
     }
   }
-  if (p.raw || p.in_fblocks || p.out_mode == OUT_MUL || p.in_mode == IN_MUL) return hipErrorInvalidValue;   // the raw modes, OUT_MUL and spaced-out input fields exist in the 16-byte kernels only
+  if (p.raw || p.in_fblocks || p.out_mode == OUT_MUL || p.out_mode == OUT_ACC2 || p.in_mode == IN_MUL) return hipErrorInvalidValue;   // the raw modes, OUT_MUL and spaced-out input fields exist in the 16-byte kernels only
   const bool jfast = p.inner < 16;
   switch (m.KS) {
     case 4: return jfast ? launch_t<4, true>(p, stream) : launch_t<4, false>(p, stream);

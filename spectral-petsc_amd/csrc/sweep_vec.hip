@@ -171,7 +171,8 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
 #define AO(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
   const int i0 = mt * 16 + (JFAST ? l16 : kq);
   const bool mul_on = (p.out_mode == OUT_MUL);            // out = operand * (alpha r): the operand rides the VecAXPY path
-  const bool acc_on = (p.out_mode == OUT_ACC) || mul_on;
+  const bool acc2_on = (p.out_mode == OUT_ACC2);          // out = (acc + acc2) + alpha r
+  const bool acc_on = (p.out_mode == OUT_ACC) || mul_on || acc2_on;
   const double alpha = p.alpha;
 
 #ifdef CHEB_STAMPS
@@ -242,6 +243,10 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
           for (int rp = 0; rp < 2; rp++) {
             acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
             acc_lo[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
+            if (acc2_on) {
+              acc_hi[rp] = acc_hi[rp] + *(ok_hi[rp] ? (const d2 *)(p.acc2 + a_hi[rp]) : zero2);
+              acc_lo[rp] = acc_lo[rp] + *(ok_lo[rp] ? (const d2 *)(p.acc2 + a_lo[rp]) : zero2);
+            }
           }
         }
       };
@@ -401,13 +406,14 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #define V4_STORE_AUX 0
 #endif
 
-// MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
+// MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 3 = ACC2 (out = (acc + acc2) + alpha r, KS = 16 only), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
 // preconditioner's fast diagonalisation folded into its last forward transform -- RAW = 1 only)
 // INM: 1 = IN_MUL, every input element is multiplied by the element of in1 at the same place as it is split into LDS (the 1 / eta
 // of the preconditioner's P_1^-1 (r / eta) folded into its first forward transform -- RAW = 1, STORE only)
 template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
-  constexpr bool ACC = MODE != 0, MUL = MODE == 2;       // ACC: the operand stream exists
+  constexpr bool ACC = MODE != 0, MUL = MODE == 2, ACC2 = MODE == 3;   // ACC: the operand stream exists; ACC2: two of them, (acc + acc2) + alpha r
+  static_assert(!ACC2 || (KS == 16 && RAW == 0), "OUT_ACC2: lines of 65 .. 128 points (the KS = 32 kernel has no registers for a second operand)");
   static_assert(INM == 0 || (RAW == 1 && MODE == 0), "IN_MUL exists for the raw forward transform with a plain store only");
   static_assert(RAW == 0 || MODE != 1, "the raw modes (sweep.h) are STORE / MUL only");
   static_assert(!MUL || RAW == 1, "OUT_MUL exists for the raw forward transform only");
@@ -445,6 +451,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in0, 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_in1 = __builtin_amdgcn_make_buffer_rsrc((void *)(INM ? p.in1 : p.in0), 0, INM ? p.in_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_acc = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC ? p.acc : p.in0), 0, ACC ? p.acc_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_acc2 = __builtin_amdgcn_make_buffer_rsrc((void *)(ACC2 ? p.acc2 : p.in0), 0, ACC2 ? p.acc_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, u32 off) { return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
   auto st16 = [](__amdgpu_buffer_rsrc_t r, u32 off, d2 v) { if (!(V4_ABLATE & 8) || v.x == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)off, 0, V4_STORE_AUX); };
@@ -487,6 +494,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   constexpr int ECH = INM ? CH : 1;
   d2 ejA[ECH], emA[ECH], ejB[ECH], emB[ECH];           // IN_MUL: the multipliers of chunk A / B, in flight beside them
   d2 accX_hi[2], accX_lo[2], accY_hi[2], accY_lo[2];
+  d2 acc2X_hi[2], acc2X_lo[2], acc2Y_hi[2], acc2Y_lo[2];   // ACC2 only
 
   auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
     const u32 t0 = in_tile_off(tl);
@@ -576,6 +584,11 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     const u32 t0 = tile_off(tl, valid, acc_os8) + ng8_acc + (u32)sub * sub8_acc;
 #pragma unroll
     for (int rp = 0; rp < 2; rp++) { ah[rp] = ld16(r_acc, c_hi[rp] + t0); al[rp] = ld16(r_acc, c_lo[rp] + t0); }
+    if constexpr (ACC2) {
+      d2 (&bh)[2] = (&ah == &accX_hi) ? acc2X_hi : acc2Y_hi; d2 (&bl)[2] = (&ah == &accX_hi) ? acc2X_lo : acc2Y_lo;
+#pragma unroll
+      for (int rp = 0; rp < 2; rp++) { bh[rp] = ld16(r_acc2, c_hi[rp] + t0); bl[rp] = ld16(r_acc2, c_lo[rp] + t0); }
+    }
   };
 
   u32 tile = t_lo + BID / nxcd;
@@ -686,6 +699,10 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
       if (!JFAST) vl = d2{odd ? lbe : la, odd ? lb : lao};
       else vl = d2{odd ? lb : lao, odd ? lbe : la};                       // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
       if (MUL) { vh = acc_hi[rp] * (alpha * vh); vl = acc_lo[rp] * (alpha_lo * vl); }
+      else if (ACC2) {
+        const d2 (&bh)[2] = (&acc_hi == &accX_hi) ? acc2X_hi : acc2Y_hi; const d2 (&bl)[2] = (&acc_hi == &accX_hi) ? acc2X_lo : acc2Y_lo;
+        vh = (acc_hi[rp] + bh[rp]) + alpha * vh; vl = (acc_lo[rp] + bl[rp]) + alpha_lo * vl;
+      }
       else if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha_lo * vl; }
       else { vh = alpha * vh; vl = alpha_lo * vl; }
       if (JFAST && (H & 1)) { if (fold[rp]) vh = d2{vh.x, vl.y}; }       // (y_ie, y_{n-ie}): adjacent when H is odd
@@ -785,6 +802,10 @@ static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t str
     if (p.raw != 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 2, 1>), dim3(grid), dim3(512), 0, stream, p);
   }
+  else if (p.out_mode == OUT_ACC2) {
+    if constexpr (KS == 16) { if (p.raw) return hipErrorInvalidValue; hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 3>), dim3(grid), dim3(512), 0, stream, p); }
+    else return hipErrorInvalidValue;
+  }
   else if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 1>), dim3(grid), dim3(512), 0, stream, p);
   else if (p.raw == 1) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0, 1>), dim3(grid), dim3(512), 0, stream, p);
   else if (p.raw == 2) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0, 2>), dim3(grid), dim3(512), 0, stream, p);
@@ -855,7 +876,7 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
   if (grid == 0) return hipSuccess;
   if constexpr (KS >= 16) return launch_v4<KS, JFAST>(p, grid, stream);
   else {
-    if (p.raw && p.out_mode != OUT_STORE && !(p.out_mode == OUT_MUL && p.raw == 1)) return hipErrorInvalidValue;
+    if (p.raw && p.out_mode != OUT_STORE && !(p.out_mode == OUT_MUL && p.raw == 1)) return hipErrorInvalidValue;   // (OUT_ACC2 with raw: refused by sweep_vec_eligible)
     if (p.out_mode == OUT_MUL && p.raw != 1) return hipErrorInvalidValue;
     if (p.in_mode == IN_MUL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
@@ -876,6 +897,9 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   if (p.in_mode == IN_MUL) {                             // lines of more than 64 points, raw forward transform, plain store, dense geometry
     if (m.KS < 16 || p.raw != 1 || p.out_mode != OUT_STORE || p.in_fblocks || p.qmax || p.in_os || !p.in1 || ((size_t)p.in1 & 15)) return false;
   } else
+  if (p.out_mode == OUT_ACC2) {                          // lines of at most 128 points, plain input, no raw mode
+    if (p.in_mode != IN_PLAIN || m.KS > 16 || p.raw || p.in_fblocks || !p.acc || !p.acc2 || ((size_t)p.acc2 & 15)) return false;
+  } else
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC && !(p.out_mode == OUT_MUL && p.raw == 1))) return false;
   const bool jfast = p.inner < 16;
   if (p.in_fblocks && (m.KS < 16 || (p.in_fskip & 1))) return false;
@@ -887,7 +911,7 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   if (jfast && (p.inner != 1 || (m.P & 1))) return false;
   if (!jfast && (p.inner & 1)) return false;
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
-  if (!al(p.in0) || !al(p.out) || ((p.out_mode == OUT_ACC || p.out_mode == OUT_MUL) && (!p.acc || !al(p.acc)))) return false;
+  if (!al(p.in0) || !al(p.out) || ((p.out_mode == OUT_ACC || p.out_mode == OUT_MUL || p.out_mode == OUT_ACC2) && (!p.acc || !al(p.acc)))) return false;
   SweepParams q = p0;                                    // sizes: the buffer offsets must reach (prepare_v)
   q.P = m.P; q.H = m.H; q.sink = m.sink;
   switch (m.KS) {

@@ -338,17 +338,20 @@ def test_options_and_kernel_families_agree():
             sp.set_option("general_kernels", 0)
     for a_, b_ in zip(outs[0], outs[1]):
         assert float((a_ - b_).norm() / a_.norm()) < 1e-12
-    # the constant-coefficient matvec: one launch of d jobs + a sum in the chain's order against a launch per direction: same bits
-    for dims in ((66, 68, 72), (40, 36, 34), (130, 72), (33, 17, 9)):
+    # the constant-coefficient matvec: one launch of d jobs + a sum in the chain's order (1), a launch per direction (2), and the default by
+    # size (0: below 6 M unknowns in 3-D two jobs + a last direction that adds both terms as it stores, OUT_ACC2): same bits.  Short
+    # and long lines, mixed KS (the default then falls back), both tilings of the last direction
+    for dims in ((66, 68, 72), (40, 36, 34), (130, 72), (33, 17, 9), (130, 128, 126), (98, 100, 130), (20, 18, 16), (64, 64, 64)):
         op = sp.EllipticOp(dims)
-        U = torch.randn(op.global_size, dtype=torch.float64, device="cuda"); Va, Vb = torch.empty_like(U), torch.empty_like(U)
+        U = torch.randn(op.global_size, dtype=torch.float64, device="cuda"); Va, Vb, Vc = torch.empty_like(U), torch.empty_like(U), torch.empty_like(U)
         try:
             sp.set_option("poisson_launches", 1); op.mult(U, Va)
             sp.set_option("poisson_launches", 2); op.mult(U, Vb)
+            sp.set_option("poisson_launches", 0); op.mult(U, Vc)
         finally:
             sp.set_option("poisson_launches", 0)
         torch.cuda.synchronize()
-        assert torch.equal(Va, Vb), dims
+        assert torch.equal(Va, Vb) and torch.equal(Va, Vc), dims
         op.destroy()
     # the pressure gradient with each direction's end-point extrapolation folded into its matrix (the default) against the
     # three extrapolation passes of StokesPressureReduceOrder followed by plain D (option pressure_passes, read at create)
