@@ -19,11 +19,11 @@ sys.path.insert(0, "$R")
 import bench
 tot = {}
 for line in open("$R/$out/${tag}_pmc/summary.txt"):
-    m = re.search(r"cheb_sweep_vec4_kernel<32, (\w+), (\w+)(?:, \d+)?>.*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ mean=\s*([\d.]+)", line)
+    m = re.search(r"cheb_sweep_vec4_kernel<32, (\w+), (\w+)(?:, \d+)*>.*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ mean=\s*([\d.]+)", line)   # <KS, JFAST, MODE (0 store, 1 acc), RAW, INM>
     if m:
         k = (m.group(1), m.group(2)); tot.setdefault(k, 0.0)
         tot[k] += float(m.group(4)) * 1024.0 * (2.0 if m.group(3) == "FETCH_SIZE" else 1.0)   # KiB; FETCH_SIZE x2 on gfx950
-per = [tot.get(("false", "false"), 0), tot.get(("false", "true"), 0), tot.get(("true", "true"), 0)]
+per = [tot.get(("false", "0"), 0), tot.get(("false", "1"), 0), tot.get(("true", "1"), 0)]
 assert all(v > 0 for v in per), "no FETCH_SIZE / WRITE_SIZE rows for the three launches of the matvec: %r" % (tot,)
 rec = {"P": 256, "kernel": "cheb_sweep_vec4_kernel", "launches_per_matvec": 3, "hbm_bytes_per_matvec": sum(per), "hbm_bytes_per_launch": sum(per) / 3.0,
        "per_direction_bytes": per, "csrc_sha256": bench.csrc_hash(),
