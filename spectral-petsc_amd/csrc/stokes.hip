@@ -522,6 +522,262 @@ __global__ __launch_bounds__(256) void k_st_out_cm3p(long N, long I, const int *
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_st_zfused16: the z direction of the viscous block of StokesMatMultVV in ONE launch (d = 3, contiguous lines of 68 .. 128 points,
+// P % 4 == 0).  The separate-pass route computes V[2] = D_z xL (3 fields), runs the node loop over all nine gradient fields, and takes
+// -D_z of the three stress fields tau_z. -- the gradient and the stress along z each cross HBM twice.  Here a tile of 16 z-lines holds
+// all three components of its nodes, so
+//   A  v_c lines -> LDS, parity-split (as the sweep kernels do)
+//   B  G_z,c = D_z v_c on the matrix cores (v_mfma_f64_16x16x4, even / odd halves), written to LDS in node order
+//   C  the node loop of stokes.C:647-662 in LOADER layout -- one thread per (line, point pair + mirror pair), so that every operand
+//      (G_x, G_y, S0, eta, eta') comes as coalesced 16-byte pieces -- with G_z from LDS; tau_x., tau_y. overwrite G_x, G_y in place as
+//      in the separate route, the trace goes to `div`, tau_z. goes back to LDS, parity-split
+//   D  -D_z tau_z,c on the matrix cores -> yz
+// 216 B/node instead of 312 for the three kernels it replaces (z third of the gradient launch, node loop, z third of the divergence
+// launch).  The phases of a workgroup do not overlap each other: with 229 KB of loads in flight per workgroup in phase C the launch is
+// bound by bytes, not by the latency of its phases (the matrix work is < 10 % of its time at P = 128).  Same arithmetic in the same
+// order as the separate route: the same bits (tests).  DETA as in k_st_node_vv.
+typedef double zf_v4 __attribute__((ext_vector_type(4)));
+struct ZfParams {
+  int P, H; unsigned nlines, ntiles; long N;
+  const double *xL; double *Vx, *Vy;
+  const double *S0, *S1, *S2, *eta, *deta;
+  double *div, *yz;
+  const double *fragE, *fragO;
+  // StokesFunction (MODE 2): Vx / Vy are strain[0] / strain[1] (gradient in, symmetrised upper triangle out), Sz = strain[2];
+  // eta_w / deta_w and the six-slot stress T are written; the rheology of stokes.C:1920-1944
+  double *Sz, *eta_w, *deta_w, *T;
+  int kind; double hardness, expo, eps, gamma0;
+};
+constexpr int ZF_KS = 16, ZF_LDJ = 4 * ZF_KS + 2, ZF_NT = 16, ZF_PG = 130;   // k-steps; image row pitch (HP + 2); lines per tile; row pitch of G_z
+// MODE 0 / 1: the node loop of StokesMatMultVV without / with the eta' S0 z term (k_st_node_vv_pair); 2: the node loop of
+// StokesFunction with the six-component storage (k_st_node_fn_pair<true>: rheology, eta, eta', symmetrised strain as state)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
+  constexpr bool DETA = MODE == 1;
+  // Two workgroups of 256 threads per CU (out of phase with each other: one waits for memory while the other computes), 50.7 KB of
+  // LDS each: the parity-split images E[3], O[3]; G_z in node order ALIASES them (it lives between the end of the stage-1 chains and
+  // the moment every thread has taken its own values into registers).
+  constexpr int IMG = ZF_NT * ZF_LDJ, GPL = ZF_NT * ZF_PG;
+  static_assert(3 * GPL <= 6 * IMG, "G_z must fit in the image space");
+  __shared__ __attribute__((aligned(16))) double sI[6 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, mt = tid >> 6;         // wave = m-tile; every wave runs the three fields
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int P = p.P, H = p.H, nn = P - 1;
+  const long N = p.N;
+  const int frag = l16 * ZF_LDJ + kq;
+  const int oi = mt * 16 + l16;                                        // output point of this lane (and its mirror nn - oi)
+  // the two loader / node slots of this thread: line sl, points (sj, sj + 1) and their mirrors (nn - sj - 1, nn - sj)
+  int sl[2], sj[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) { const int id = tid + 256 * u; sl[u] = id >> 5; sj[u] = 2 * (id & 31); }
+  // (the matrix fragments are fetched per stage from L2 -- 64 KB per workgroup and stage -- rather than held across the node loop,
+  // whose operands need the registers)
+  const double *fragE = p.fragE, *fragO = p.fragO;
+  auto chains = [&](zf_v4 (&ce)[3], zf_v4 (&co)[3]) {
+    asm volatile("" : "+s"(fragE), "+s"(fragO));                       // no reuse of the previous stage's fragment registers
+    double ae[ZF_KS], ao[ZF_KS];
+#pragma unroll
+    for (int s = 0; s < ZF_KS; s++) { ae[s] = fragE[((long)(mt * ZF_KS + s)) * 64 + lane]; ao[s] = fragO[((long)(mt * ZF_KS + s)) * 64 + lane]; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      ce[c] = zf_v4{0.0, 0.0, 0.0, 0.0}; co[c] = zf_v4{0.0, 0.0, 0.0, 0.0};
+      const double *fE = sI + c * IMG + frag, *fO = sI + (3 + c) * IMG + frag;
+#pragma unroll
+      for (int s = 0; s < ZF_KS; s++) {
+        ce[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fE[4 * s], ae[s], ce[c], 0, 0, 0);
+        co[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fO[4 * s], ao[s], co[c], 0, 0, 0);
+      }
+    }
+  };
+  for (unsigned tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    bool live[2]; long a[2], m[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const unsigned gl = tile * ZF_NT + sl[u];
+      live[u] = sj[u] < H && gl < p.nlines;                            // H even: the pair is in or out together
+      a[u] = (long)gl * P + sj[u]; m[u] = (long)gl * P + (nn - sj[u] - 1);
+    }
+    // ---- A: v_c -> parity-split images (dead slots write the zero padding)
+    {
+      double2 rj[2][3], rm[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          rj[u][c] = make_double2(0.0, 0.0); rm[u][c] = rj[u][c];
+          if (live[u]) { rj[u][c] = *(const double2 *)(p.xL + c * N + a[u]); rm[u][c] = *(const double2 *)(p.xL + c * N + m[u]); }
+        }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          *(double2 *)(sI + c * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(rj[u][c].x + rm[u][c].y, rj[u][c].y + rm[u][c].x);
+          *(double2 *)(sI + (3 + c) * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(rj[u][c].x - rm[u][c].y, rj[u][c].y - rm[u][c].x);
+        }
+    }
+    __syncthreads();
+    // ---- B: G_z,c = D_z v_c, to LDS in node order (over the images, once every wave has finished its chains)
+    {
+      zf_v4 ce[3], co[3];
+      chains(ce, co);
+      __syncthreads();
+      if (oi < H) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            double *row = sI + c * GPL + (4 * r + kq) * ZF_PG;
+            row[oi] = ce[c][r] + co[c][r]; row[nn - oi] = co[c][r] - ce[c][r];
+          }
+      }
+    }
+    __syncthreads();
+    // ---- C: node loop on the two slots' four nodes each; G_z first into registers (its space becomes the tau_z images)
+    {
+      double2 gz[2][3][2];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          gz[u][k][0] = *(const double2 *)(sI + k * GPL + sl[u] * ZF_PG + sj[u]);
+          gz[u][k][1] = *(const double2 *)(sI + k * GPL + sl[u] * ZF_PG + (nn - sj[u] - 1));
+        }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        double2 tz[3][2];                                              // tau_z,k of the pair / of the mirror pair
+#pragma unroll
+        for (int k = 0; k < 3; k++) { tz[k][0] = make_double2(0.0, 0.0); tz[k][1] = tz[k][0]; }
+        if (live[u] && MODE == 2) {
+          double2 g[3][3][2];
+          const long off[2] = {a[u], m[u]};
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              g[0][k][h] = *(const double2 *)(p.Vx + k * N + off[h]);
+              g[1][k][h] = *(const double2 *)(p.Vy + k * N + off[h]);
+              g[2][k][h] = gz[u][k][h];
+            }
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            double2 sv[3][3], tv[3][3], e2, de2, dv;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              double sn[3][3], gamma = 0.0;
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { sn[j][k] = 0.5 * (comp(g[j][k][h], q) + comp(g[k][j][h], q)); gamma += 0.5 * (sn[j][k] * sn[j][k]); }
+              double e = 1.0, de = 0.0;
+              if (p.kind == 1) {
+                const double pw = (1.0 - p.expo) / (2.0 * p.expo);
+                const double qq = p.eps + gamma / p.gamma0, qp = pow(qq, pw);
+                e = p.hardness * qp;
+                de = (fabs(p.expo) > 1.0e-5) ? p.hardness * pw / p.gamma0 * (qp / qq) : 0.0;
+              }
+              comp(e2, q) = e; comp(de2, q) = de;
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { comp(tv[j][k], q) = e * sn[j][k]; comp(sv[j][k], q) = sn[j][k]; }
+              double tr = comp(g[0][0][h], q) + comp(g[1][1][h], q); tr += comp(g[2][2][h], q);
+              comp(dv, q) = tr;
+            }
+            *(double2 *)(p.eta_w + off[h]) = e2; *(double2 *)(p.deta_w + off[h]) = de2;
+            // state: the symmetrised strain in its upper triangle; stress: slot j + k + j k of T for j <= k, but (2,2): tau_zz is used
+            // on chip only
+#pragma unroll
+            for (int k = 0; k < 3; k++) *(double2 *)(p.Vx + k * N + off[h]) = sv[0][k];
+            *(double2 *)(p.Vy + 1 * N + off[h]) = sv[1][1]; *(double2 *)(p.Vy + 2 * N + off[h]) = sv[1][2];
+            *(double2 *)(p.Sz + 2 * N + off[h]) = sv[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+              for (int k = j; k < 3; k++) *(double2 *)(p.T + (long)(j + k + j * k) * N + off[h]) = tv[j][k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tz[k][h] = tv[2][k];
+            if (p.div) *(double2 *)(p.div + off[h]) = dv;
+          }
+        }
+        if (live[u] && MODE != 2) {
+          double2 g[3][3][2], s0[3][3][2], e[2], de[2];
+          const long off[2] = {a[u], m[u]};
+          const double *S[3] = {p.S0, p.S1, p.S2};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              g[0][k][h] = *(const double2 *)(p.Vx + k * N + off[h]);
+              g[1][k][h] = *(const double2 *)(p.Vy + k * N + off[h]);
+              g[2][k][h] = gz[u][k][h];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+              for (int k = j; k < 3; k++) { s0[j][k][h] = DETA ? *(const double2 *)(S[j] + k * N + off[h]) : make_double2(0.0, 0.0); s0[k][j][h] = s0[j][k][h]; }
+            e[h] = *(const double2 *)(p.eta + off[h]);
+            de[h] = DETA ? *(const double2 *)(p.deta + off[h]) : make_double2(0.0, 0.0);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            double2 out[3][3], dv;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              double strain[3][3], z = 0.0;
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { strain[j][k] = 0.5 * (comp(g[j][k][h], q) + comp(g[k][j][h], q)); z += strain[j][k] * comp(s0[j][k][h], q); }
+              const double eq = comp(e[h], q), deq = comp(de[h], q);
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) comp(out[j][k], q) = DETA ? eq * strain[j][k] + deq * comp(s0[j][k][h], q) * z : eq * strain[j][k];
+              double tr = comp(g[0][0][h], q) + comp(g[1][1][h], q); tr += comp(g[2][2][h], q);
+              comp(dv, q) = tr;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              *(double2 *)(p.Vx + k * N + off[h]) = out[0][k];
+              *(double2 *)(p.Vy + k * N + off[h]) = out[1][k];
+              tz[k][h] = out[2][k];
+            }
+            if (p.div) *(double2 *)(p.div + off[h]) = dv;
+          }
+        }
+        // tau_z,k parity-split: the pair is (t_j, t_{j+1}), the mirror pair (t_{nn-j-1}, t_{nn-j})
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double2 tp = tz[k][0], tm = tz[k][1];
+          *(double2 *)(sI + k * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(tp.x + tm.y, tp.y + tm.x);
+          *(double2 *)(sI + (3 + k) * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(tp.x - tm.y, tp.y - tm.x);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- D: yz_c = -D_z tau_z,c
+    {
+      zf_v4 ce[3], co[3];
+      chains(ce, co);
+      if (oi < H) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const unsigned ol = tile * ZF_NT + 4 * r + kq;
+            if (ol < p.nlines) {
+              double *row = p.yz + (long)c * N + (long)ol * P;
+              row[oi] = -1.0 * (ce[c][r] + co[c][r]); row[nn - oi] = -1.0 * (co[c][r] - ce[c][r]);
+            }
+          }
+      }
+    }
+    __syncthreads();                                                   // the images are rewritten by the next tile's phase A
+  }
+}
+
 __global__ void k_st_fill(long n, double v, double *__restrict__ a) { GS_LOOP(i, n) a[i] = v; }
 
 // ---------------------------------------------------------------------------------------------
@@ -861,10 +1117,11 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
 // kernels allow it (sweep_launch_multi), else one launch each.  Serial handles only.
 static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st, bool spaced = false,
-                        bool pext = false) {          // pext: the matrices with the end-point extrapolation of the pressure folded in
+                        bool pext = false, int k1 = -1) {   // pext: the matrices with the end-point extrapolation of the pressure folded in; directions k0 .. k1 - 1
   const DiffMat *m[3]; SweepParams sp[3];
   int n = 0;
-  for (int k = k0; k < op->d; k++, n++) {
+  if (k1 < 0) k1 = op->d;
+  for (int k = k0; k < k1; k++, n++) {
     sp[n] = SweepParams{};
     sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
     if (spaced && k > 0) {                                  // job k: its d fields are k N doubles further apart than dense stacking (stokes_op::T)
@@ -1026,8 +1283,41 @@ static int st_sync_strain(stokes_op *op, hipStream_t st) {
 
 // viscous part of StokesMatMultVV on xL: V[j] = DV[j] xL, node loop, yL = -sum DV[j] V[j]; div (may be null)
 // receives the trace of the gradient = StokesDivergence of the same xL.  have_gradient: V already holds DV[j] xL.
+// The z direction in one launch (k_st_zfused16): d = 3 on one GPU, contiguous lines of 68 .. 128 points (KS = 16), P % 4 == 0.
+// Option "stokes_z_separate" = 1 keeps the separate-pass route (A/B; the two give the same bits).
+static bool st_zfused_ok(stokes_op *op) {
+  if (op->d != 3 || op->slab || (op->N & 1) || opt(OPT_STOKES_Z_SEPARATE) || opt(OPT_GENERAL_KERNELS) || opt(OPT_SEPARATE_LAUNCHES)) return false;
+  const int P = op->dims[2];
+  return P > 64 && P <= 128 && (P % 4) == 0 && op->mats[P].KS == ZF_KS && op->mats[P].sym == 0 && op->N / P < 0x7fffffffL / ZF_NT;
+}
+static int st_zfused_launch(stokes_op *op, int mode, ZfParams zp, hipStream_t st) {
+  zp.P = op->dims[2]; zp.H = zp.P / 2; zp.N = op->N; zp.nlines = (unsigned)(op->N / zp.P); zp.ntiles = (zp.nlines + ZF_NT - 1) / ZF_NT;
+  zp.yz = op->yLx[2];
+  const DiffMat &m = op->mats[zp.P];
+  zp.fragE = m.fragE; zp.fragO = m.fragO;
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err); SHIPCHK(cu_err);
+  const unsigned grid = zp.ntiles < 2u * (unsigned)ncu ? zp.ntiles : 2u * (unsigned)ncu;      // two workgroups per CU
+  if (mode == 2) hipLaunchKernelGGL((k_st_zfused16<2>), dim3(grid), dim3(256), 0, st, zp);
+  else if (mode == 1) hipLaunchKernelGGL((k_st_zfused16<1>), dim3(grid), dim3(256), 0, st, zp);
+  else hipLaunchKernelGGL((k_st_zfused16<0>), dim3(grid), dim3(256), 0, st, zp);
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+static int st_viscous_jacobian_zfused(stokes_op *op, double *div, hipStream_t st) {
+  const double *x[3] = {op->xL, op->xL, op->xL};
+  int rc = sweeps_multi(op, true, 0, x, op->V, 1.0, st, false, false, 2); if (rc) return rc;            // V[0] = D_x xL, V[1] = D_y xL
+  ZfParams zp = {};
+  zp.xL = op->xL; zp.Vx = op->V[0]; zp.Vy = op->V[1];
+  zp.S0 = op->strain[0]; zp.S1 = op->strain[1]; zp.S2 = op->strain[2]; zp.eta = op->eta; zp.deta = op->deta;
+  zp.div = div;
+  if ((rc = st_zfused_launch(op, op->deta_nonzero ? 1 : 0, zp, st))) return rc;
+  double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
+  const double *t[3] = {op->V[0], op->V[1], op->V[2]};
+  return sweeps_multi(op, true, 0, t, y, -1.0, st, false, false, 2);                                     // yL = -D_x tau_x., yLx[1] = -D_y tau_y.
+}
 static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st, bool have_gradient = false) {
   const int d = op->d;
+  if (!have_gradient && st_zfused_ok(op)) return st_viscous_jacobian_zfused(op, div, st);
   if (!have_gradient) { int rc = st_gradient(op, op->V, st); if (rc) return rc; }                                               // :639
 #define NODE_VV(D_, DETA_) hipLaunchKernelGGL((k_st_node_vv<D_, DETA_>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, op->V[0], op->V[1], op->V[2], \
     (const double *)op->strain[0], (const double *)op->strain[1], (const double *)op->strain[2], (const double *)op->eta, (const double *)op->deta, div)
@@ -1278,6 +1568,27 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   op->strain_stale = false;                               // the node loop below leaves the strain as state
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
   st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
+  if (!op->slab && !st_one_launch_gradients(op) && op->sym && st_zfused_ok(op)) {
+    // the z direction in one launch (k_st_zfused16, MODE 2): gradient along x, y -> strain[0], strain[1]; the fused launch leaves eta,
+    // eta', the symmetrised strain (upper triangle) and the stress slots the x / y divergence reads, and returns -D_z tau_z. in yLx[2]
+    { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                         // :747
+    const double *x[3] = {op->xL, op->xL, op->xL};
+    int rc = sweeps_multi(op, true, 0, x, op->strain, 1.0, st, false, false, 2); if (rc) return rc;                              // :701 (x, y)
+    ZfParams zp = {};
+    zp.xL = op->xL; zp.Vx = op->strain[0]; zp.Vy = op->strain[1]; zp.Sz = op->strain[2];
+    zp.eta_w = op->eta; zp.deta_w = op->deta; zp.T = op->T; zp.div = op->p2;
+    zp.kind = op->rh_kind; zp.hardness = op->rh_hard; zp.expo = op->rh_expo; zp.eps = op->rh_eps; zp.gamma0 = op->rh_g0;
+    if ((rc = st_zfused_launch(op, 2, zp, st))) return rc;
+    op->deta_nonzero = (op->rh_kind == 1);
+    op->eta_uniform = (op->rh_kind == 0); op->eta_value = 1.0;
+    double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
+    const double *t[3] = {op->T, op->T + op->N, op->T + 2 * op->N};
+    if ((rc = sweeps_multi(op, true, 0, t, y, -1.0, st, true, false, 2))) return rc;                                             // :737-740 (x, y)
+    if ((rc = st_join(op, st))) return rc;
+    st_out_full(op, op->force, yG, st);                                                                                            // :750-756
+    SHIPCHK(hipGetLastError());
+    return 0;
+  }
   if (op->slab) {
     int rc = st_gradient_and_pressure_gradient_slab(op, op->strain, st); if (rc) return rc;                                      // :747, :701
   } else if (st_one_launch_gradients(op)) {

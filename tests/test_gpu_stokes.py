@@ -181,3 +181,44 @@ def test_stokes_blocks_large_vs_oracle(dims):
     assert relerr(run(op.mult_vp, p, gv), orc.stokes_mult_vp(dims, p, mode=orc.FAST, nthreads=16)) < 1e-10
     assert relerr(run(op.mult, x, g), orc.stokes_mult(dims, x, mode=orc.FAST, nthreads=16)) < 1e-10
     op.destroy()
+
+
+@pytest.mark.parametrize("dims", [(20, 18, 68), (34, 40, 100), (66, 70, 128), (128, 128, 128), (9, 7, 72)], ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("state", ["power", "eta_only"])
+def test_z_direction_in_one_launch_equals_the_separate_passes(dims, state):
+    """k_st_zfused16 (d = 3, contiguous lines of 68 .. 128 points): the z third of the gradient launch, the node loop and the z third of
+    the divergence launch of StokesMatMult / StokesMatMultVV as ONE launch -- the same arithmetic in the same order, so the results
+    equal those of the separate-pass route (option `stokes_z_separate`) to the bit.  Power-law state (eta' != 0: the S0 z term) and a
+    variable viscosity with eta' = 0; tiles that end inside the grid (line counts that are not multiples of 16)."""
+    sp = ge.load()
+    import torch
+    rng = np.random.default_rng(SEED + 31)
+    N = int(np.prod(dims))
+    outs = []
+    for sep in (0, 1):
+        sp.set_option("stokes_z_separate", sep)
+        try:
+            st = sp.StokesOp(dims)
+            fn = None
+            if state == "power":
+                st.set_rheology(1, 1.0, 3.0, 1e-2, 1.0)
+                st.set_dirichlet(np.random.default_rng(1).standard_normal(st.dirichlet_size)); st.set_force(np.random.default_rng(6).standard_normal(st.global_size))
+                x0 = torch.from_numpy(np.random.default_rng(2).standard_normal(st.global_size)).cuda()
+                r0 = torch.full_like(x0, float("nan"))
+                st.function(x0, r0); torch.cuda.synchronize()          # (StokesFunction takes the fused launch on two-stream grids: 128^3)
+                fn = [r0.cpu().numpy()] + [st.get_state(w) for w in range(5)]
+            else:
+                st.set_state(0, np.exp(np.random.default_rng(3).uniform(np.log(0.5), np.log(10.0), N)))
+            x = torch.from_numpy(np.random.default_rng(4).standard_normal(st.global_size)).cuda()
+            v = torch.from_numpy(np.random.default_rng(5).standard_normal(st.velocity_size)).cuda()
+            y = torch.full_like(x, float("nan")); w = torch.full_like(v, float("nan"))
+            st.mult(x, y); st.mult_vv(v, w); torch.cuda.synchronize()
+            outs.append((y.clone(), w.clone(), fn))
+            st.destroy()
+        finally:
+            sp.set_option("stokes_z_separate", 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (
+        float((outs[0][0] - outs[1][0]).norm() / outs[1][0].norm()), float((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm()))
+    if outs[0][2] is not None:                                # residual, eta, eta', the three strain blocks
+        for k, (p_, q_) in enumerate(zip(outs[0][2], outs[1][2])):
+            assert np.array_equal(p_, q_), k

@@ -11,9 +11,10 @@ import __graft_entry__ as ge
 sp = ge.load()
 optname = sys.argv[1]; P = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 LIN = len(sys.argv) > 3 and sys.argv[3] == 'lin'
+CALL_TIME = optname in ("stokes_z_separate",)          # options read per call: one handle, the option toggled around the timed loops
 ops = []
 for v in (0, 1):
-    sp.set_option(optname, v)
+    sp.set_option(optname, 0 if CALL_TIME else v)
     op = sp.StokesOp((P, P, P)); op.set_rheology(*((0, 1.0, 1.0, 1.0, 1.0) if LIN else (1, 1.0, 3.0, 1e-4, 1.0)))
     op.set_dirichlet(np.zeros(op.dirichlet_size)); op.set_force(np.zeros(op.global_size))
     ops.append(op)
@@ -31,4 +32,6 @@ for op in ops: op.function(x, y)
 for rnd in range(3):
     for v, op in enumerate(ops):
         xv = x[:op.velocity_size]; yv = y[:op.velocity_size]
+        if CALL_TIME: op = ops[0]; sp.set_option(optname, v)
         print("%s=%d: MatMult %.1f us  MatMultVV %.1f us  Function %.1f us" % (optname, v, t(lambda: op.mult(x, y)), t(lambda: op.mult_vv(xv, yv)), t(lambda: op.function(x, y))))
+        if CALL_TIME: sp.set_option(optname, 0)
