@@ -534,9 +534,11 @@ __global__ __launch_bounds__(256) void k_st_out_cm3p(long N, long I, const int *
 //      in the separate route, the trace goes to `div`, tau_z. goes back to LDS, parity-split
 //   D  -D_z tau_z,c on the matrix cores -> yz
 // 216 B/node instead of 312 for the three kernels it replaces (z third of the gradient launch, node loop, z third of the divergence
-// launch).  The phases of a workgroup do not overlap each other: with 229 KB of loads in flight per workgroup in phase C the launch is
-// bound by bytes, not by the latency of its phases (the matrix work is < 10 % of its time at P = 128).  Same arithmetic in the same
-// order as the separate route: the same bits (tests).  DETA as in k_st_node_vv.
+// launch); the matrix work is < 10 % of its time at P = 128.  The phases of a workgroup do not overlap each other, so two workgroups
+// of 256 threads share a CU (one waits for memory while the other computes): 115 us = 3.9 TB/s at 128^3 against 137 us for the three
+// kernels (rocprofv3, same run) -- the dependent rounds of loads of a tile (v; then the operands of slot 0, of slot 1) leave the memory
+// system under-occupied compared with a streaming node loop (6 TB/s); more rounds in flight need registers the node loop's 22
+// 16-byte operands per slot already take (252 VGPRs).  Same arithmetic in the same order as the separate route: the same bits (tests).
 typedef double zf_v4 __attribute__((ext_vector_type(4)));
 struct ZfParams {
   int P, H; unsigned nlines, ntiles; long N;
@@ -1288,7 +1290,10 @@ static int st_sync_strain(stokes_op *op, hipStream_t st) {
 static bool st_zfused_ok(stokes_op *op) {
   if (op->d != 3 || op->slab || (op->N & 1) || opt(OPT_STOKES_Z_SEPARATE) || opt(OPT_GENERAL_KERNELS) || opt(OPT_SEPARATE_LAUNCHES)) return false;
   const int P = op->dims[2];
-  return P > 64 && P <= 128 && (P % 4) == 0 && op->mats[P].KS == ZF_KS && op->mats[P].sym == 0 && op->N / P < 0x7fffffffL / ZF_NT;
+  // From 14 400 lines on (120^2): below, the tiles of 16 lines x 3 fields are too few to balance over 2 x 256 workgroups and the
+  // launch merely ties with the three it replaces (one process, MatVV separate / fused: 80^3 92 / 94 us, 96^3 126 / 123, 112^3 175 / 175,
+  // 128^3 254 / 230)
+  return P > 64 && P <= 128 && (P % 4) == 0 && op->mats[P].KS == ZF_KS && op->mats[P].sym == 0 && op->N / P >= 14400 && op->N / P < 0x7fffffffL / ZF_NT;
 }
 static int st_zfused_launch(stokes_op *op, int mode, ZfParams zp, hipStream_t st) {
   zp.P = op->dims[2]; zp.H = zp.P / 2; zp.N = op->N; zp.nlines = (unsigned)(op->N / zp.P); zp.ntiles = (zp.nlines + ZF_NT - 1) / ZF_NT;

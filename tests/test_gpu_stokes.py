@@ -183,13 +183,14 @@ def test_stokes_blocks_large_vs_oracle(dims):
     op.destroy()
 
 
-@pytest.mark.parametrize("dims", [(20, 18, 68), (34, 40, 100), (66, 70, 128), (128, 128, 128), (9, 7, 72)], ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("dims", [(120, 121, 68), (150, 97, 100), (122, 120, 128), (128, 120, 124), (128, 128, 128), (170, 85, 72)], ids=lambda d: "x".join(map(str, d)))
 @pytest.mark.parametrize("state", ["power", "eta_only"])
 def test_z_direction_in_one_launch_equals_the_separate_passes(dims, state):
     """k_st_zfused16 (d = 3, contiguous lines of 68 .. 128 points): the z third of the gradient launch, the node loop and the z third of
     the divergence launch of StokesMatMult / StokesMatMultVV as ONE launch -- the same arithmetic in the same order, so the results
     equal those of the separate-pass route (option `stokes_z_separate`) to the bit.  Power-law state (eta' != 0: the S0 z term) and a
-    variable viscosity with eta' = 0; tiles that end inside the grid (line counts that are not multiples of 16)."""
+    variable viscosity with eta' = 0; tiles that end inside the grid (line counts that are not multiples of 16); grids of at least
+    14 400 z-lines (smaller ones keep the separate passes)."""
     sp = ge.load()
     import torch
     rng = np.random.default_rng(SEED + 31)
