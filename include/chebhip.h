@@ -441,6 +441,9 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
  *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array
  *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read
+ *   stokes_z_separate     1: StokesMatMult / StokesMatMultVV / StokesFunction run the z direction of the viscous block as separate passes
+ *                            (z sweeps of the gradient launch, node loop, z sweeps of the divergence launch) also where the one-launch
+ *                            form exists (d = 3 on one GPU, contiguous lines of 68 .. 128 points, at least 14 400 of them); same bits (A/B)
  *   saddle_node_major     1: the block preconditioners (stokes_saddle_*) keep the vectors of their inner velocity solves node-major as
  *                            the reference does, with a (de)interleaving pass around every MatVVPC solve (read at create; A/B)
  *   fdm_passes            1: the fast-diagonalisation solve z = P_1^-1 (r / eta) of the finite-difference preconditioners divides by eta
