@@ -176,7 +176,7 @@ struct chebhip_fdpc {
   double *cf = nullptr, *eta_g = nullptr;
   double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr, *t5 = nullptr;   // nf * G each
   double *W = nullptr; bool W_tried = false;   // reciprocal modal weights, nf stacked copies (built on first use: fdm_solve)
-  double *Einv = nullptr; bool Einv_tried = false, Einv_ok = false;   // 1 / eta_g, nf stacked copies (rebuilt by fdpc_update; used by fdm_solve)
+  double *Einv = nullptr; bool Einv_ok = false;   // 1 / eta_g, nf stacked copies (rebuilt by fdpc_update; used by fdm_solve)
   int sweeps = 1;
   chebhip_fgmres *inner = nullptr; int inner_m = 0;   // the approximate solve with variable coefficients
   bool assembled = false;
@@ -269,6 +269,14 @@ static int fdpc_create(const FdView &v0, int nf, bool interleaved, chebhip_fdpc 
   PCCHK(hipMalloc((void **)&pc->t0, nf * gb)); PCCHK(hipMalloc((void **)&pc->t1, nf * gb));
   PCCHK(hipMalloc((void **)&pc->t2, nf * gb)); PCCHK(hipMalloc((void **)&pc->t3, nf * gb));
   PCCHK(hipMalloc((void **)&pc->t4, nf * gb)); PCCHK(hipMalloc((void **)&pc->t5, nf * gb));
+  // the operand arrays of the pointwise steps that ride inside the line transforms (fdm_solve: filled on first use / by update);
+  // allocated here so that no solve meets a hipMalloc.  A failed allocation only means the separate passes run.
+  if (!opt(OPT_FDM_PASSES) && v.G > 0) {
+    bool any_long = false;
+    for (int k = 0; k < v.d; k++) any_long = any_long || v.dims[k] - 2 > 64;
+    if (v.d >= 2 && v.d <= 3 && hipMalloc((void **)&pc->W, nf * gb) != hipSuccess) { pc->W = nullptr; (void)hipGetLastError(); }
+    if (any_long && hipMalloc((void **)&pc->Einv, nf * gb) != hipSuccess) { pc->Einv = nullptr; (void)hipGetLastError(); }
+  }
 #undef PCCHK
   *out = pc;
   return 0;
@@ -281,11 +289,7 @@ static int fdpc_eta_inverse(chebhip_fdpc *pc, hipStream_t st) {
   bool any_long = false;
   for (int k = 0; k < pc->geo.d; k++) any_long = any_long || pc->geo.dims[k] - 2 > 64;
   if (!any_long) return 0;
-  if (!pc->Einv && !pc->Einv_tried) {
-    pc->Einv_tried = true;
-    if (hipMalloc((void **)&pc->Einv, (size_t)pc->nf * pc->G * sizeof(double)) != hipSuccess) { pc->Einv = nullptr; (void)hipGetLastError(); }
-  }
-  if (!pc->Einv) return 0;
+  if (!pc->Einv) return 0;              // (allocated at create)
   hipLaunchKernelGGL(k_eta_inverse, dim3(pgrid(pc->G), (unsigned)pc->nf), dim3(256), 0, st, pc->G, (const double *)pc->eta_g, pc->Einv);
   PHIPCHK(hipGetLastError());
   pc->Einv_ok = true;
@@ -387,19 +391,18 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
   // The modal scaling rides on the store of the last forward transform (dimension d-1 > 0: local on slabs too) where that
   // transform is one launch of the 16-byte kernels: it multiplies by W = 1 / (l_i + l_j + l_k), built here on first use (the
   // separate pass divides: the two differ in the last bit).  Option "fdm_passes" = 1 keeps both pointwise passes (A/B).
-  if (!pc->W && !pc->W_tried && d >= 2 && d <= 3 && lines > 0 && lines <= 65535 && pc->nf <= 65535 && !opt(OPT_FDM_PASSES)) {
+  const bool w_ok = pc->W && d >= 2 && d <= 3 && lines > 0 && lines <= 65535 && pc->nf <= 65535 && !opt(OPT_FDM_PASSES);
+  if (w_ok && !pc->W_tried) {           // (filled here rather than at create: a slab handle learns its plane offset after create)
     pc->W_tried = true;
-    if (hipMalloc((void **)&pc->W, (size_t)pc->nf * pc->G * sizeof(double)) == hipSuccess) {
-      const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
-      hipLaunchKernelGGL(k_modal_weights3, dim3((unsigned)((nl + 255) / 256), (unsigned)lines, (unsigned)pc->nf), dim3(256), 0, st, d, n1, nl, pc->G,
-                         lam.p[0], lam.p[1], lam.p[2], pc->W);
-      PHIPCHK(hipGetLastError());
-    } else { pc->W = nullptr; (void)hipGetLastError(); }
+    const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
+    hipLaunchKernelGGL(k_modal_weights3, dim3((unsigned)((nl + 255) / 256), (unsigned)lines, (unsigned)pc->nf), dim3(256), 0, st, d, n1, nl, pc->G,
+                       lam.p[0], lam.p[1], lam.p[2], pc->W);
+    PHIPCHK(hipGetLastError());
   }
   bool scaled = false;
   for (int q = 0; q < d; q++) {
     const int k = order[q];
-    const bool last = q == d - 1 && q > 0 && pc->W && !opt(OPT_FDM_PASSES);
+    const bool last = q == d - 1 && q > 0 && w_ok;
     int rc = line_transform(pc, k, false, src, a, st, last ? pc->W : nullptr, last ? &scaled : nullptr, q == 0 ? in_mul : nullptr); if (rc) return rc;
     src = a; std::swap(a, b);
   }
