@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256) void k_st_out_cm3p(long N, long I, const int *
 // system under-occupied compared with a streaming node loop (6 TB/s); more rounds in flight need registers the node loop's 22
 // 16-byte operands per slot already take (252 VGPRs).  Built and lost, one process each: requesting the next tile's v lines one tile
 // ahead, under stage D (MatVV 230 -> 241 us); the node loop as four rounds with a rolling window of two rounds of operands in flight
-// (spills 38 VGPRs: MatVV 229 -> 235 us, StokesFunction 296 -> 322).  Same arithmetic in the same order as the separate route: the same bits (tests).
+// (spills 38 VGPRs: MatVV 229 -> 235 us, StokesFunction 296 -> 322; without the staging of G_z, images written after one more barrier:
+// 26 spilled in the eta' variant, 229 -> 240 / 296 -> 302).  Same arithmetic in the same order as the separate route: the same bits (tests).
 typedef double zf_v4 __attribute__((ext_vector_type(4)));
 struct ZfParams {
   int P, H; unsigned nlines, ntiles; long N;
