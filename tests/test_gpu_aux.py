@@ -499,3 +499,40 @@ def test_cheb_apply_on_an_array_of_a_gigabyte():
         got = y[h * (n // 2):(h + 1) * (n // 2)]
         assert float((got - ref).norm() / ref.norm()) < 1e-13
     big.destroy(); half.destroy()
+
+
+def test_fast_paths_are_the_ones_that_run():
+    """Sweep-launch counts of the BASELINE-size callbacks (chebhip_launch_count: one per sweep-kernel launch, multi-job launches
+    count once): a silent fall-back to a slower route -- an eligibility test that stops matching, a lost alignment -- changes them.
+      256^3 Poisson matvec                3  (one launch per direction)
+      128^3 Poisson matvec                2  (two jobs + a last direction with a two-operand accumulate)
+      64^3 linear StokesMatMult           2  (uniform-viscosity route: nine jobs, then the three sweeps of grad div v)
+      128^3 power-law StokesMatMultVV     2  (x / y gradient, x / y divergence; the z direction is k_st_zfused16, not a sweep launch)
+      128^3 power-law StokesMatMult       3  (+ the pressure-gradient launch), StokesFunction 3
+      MatVVPC solve at 128^3              6  (one launch per line transform, pointwise steps inside)"""
+    L = sp.lib()
+    def count(fn):
+        torch.cuda.synchronize(); before = L.chebhip_launch_count(); fn(); torch.cuda.synchronize(); return L.chebhip_launch_count() - before
+    rnd = lambda n: torch.randn(n, dtype=torch.float64, device="cuda")
+    for P, expect in ((256, 3), (128, 2)):
+        op = sp.EllipticOp((P, P, P)); U = rnd(op.global_size); V = torch.empty_like(U)
+        op.mult(U, V)
+        assert count(lambda: op.mult(U, V)) == expect, P
+        op.destroy(); del U, V
+    st = sp.StokesOp((64, 64, 64)); st.set_dirichlet(np.zeros(st.dirichlet_size)); st.set_force(np.zeros(st.global_size))
+    x = rnd(st.global_size); y = torch.empty_like(x)
+    st.function(x, y)
+    assert count(lambda: st.mult(x, y)) == 2
+    st.destroy()
+    st = sp.StokesOp((128, 128, 128)); st.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
+    st.set_dirichlet(np.zeros(st.dirichlet_size)); st.set_force(np.zeros(st.global_size))
+    x = rnd(st.global_size); y = torch.empty_like(x); v = rnd(st.velocity_size); w = torch.empty_like(v)
+    st.function(x, y)
+    assert count(lambda: st.mult_vv(v, w)) == 2
+    assert count(lambda: st.mult_vv_cm(v, w)) == 2
+    assert count(lambda: st.mult(x, y)) == 3
+    assert count(lambda: st.function(x, y)) == 3
+    pc = sp.FdPc(st, sweeps=0); pc.apply(v, w)
+    assert count(lambda: pc.apply(v, w)) == 6
+    assert count(lambda: pc.apply_cm(v, w)) == 6
+    pc.destroy(); st.destroy()
