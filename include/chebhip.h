@@ -441,6 +441,9 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
  *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array
  *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read
+ *   fdm_z_separate        1: the fast-diagonalisation solve runs its last forward line transform, the modal scaling and its first backward
+ *                            line transform as separate launches also where the one-launch form exists (last dimension with 66 .. 128
+ *                            interior points, an even number) (A/B)
  *   stokes_z_separate     1: StokesMatMult / StokesMatMultVV / StokesFunction run the z direction of the viscous block as separate passes
  *                            (z sweeps of the gradient launch, node loop, z sweeps of the divergence launch) also where the one-launch
  *                            form exists (d = 3 on one GPU, contiguous lines of 68 .. 128 points, at least 14 400 of them); same bits (A/B)

@@ -161,6 +161,105 @@ __global__ void k_deinterleave_over_eta(long G, int nf, const double *__restrict
   GS_LOOP(g, G) { const double e = eta_g[g]; for (int f = 0; f < nf; f++) out[(long)f * G + g] = a[g * nf + f] / e; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_fdm_zsolve16: the last forward line transform, the modal scaling and the first backward line transform of the fast-diagonalisation
+// solve in ONE launch.  The three act on the same contiguous lines (the last dimension) -- y = S ( W .* (S^-1 x) ) line by line -- so
+// the modal coefficients never have to leave the chip: the parity halves the forward product leaves in the accumulators (the raw-mode
+// layout of sweep.h: even modes at positions p < H, odd modes at M-1-q) are exactly the split input the backward product takes.
+//   A  x lines -> LDS, parity-split          B  c = S^-1 x on the matrix cores; c .*= W; back to LDS as the already split halves
+//   D  y = S c on the matrix cores -> HBM
+// 24 B/value (x, W, y) instead of 40 for the two launches it replaces.  Lines of 66 .. 128 interior points (KS = 16), M even; tiles of
+// 32 lines.
+typedef double fz_v4 __attribute__((ext_vector_type(4)));
+struct FzParams { int M, H; unsigned ncols, ntiles; const double *x, *W; double *y; const double *FE, *FO, *BE, *BO; };
+constexpr int FZ_KS = 16, FZ_LDJ = 4 * FZ_KS + 2, FZ_NT = 32;
+__global__ __launch_bounds__(256, 3) void k_fdm_zsolve16(const FzParams p) {
+  // Workgroups of 256 threads (wave = m-tile, two sub-tiles of 16 lines), three per CU, out of phase with each other; the matrix
+  // fragments are fetched from L2 per stage (64 KB) rather than held: 168 registers have to do
+  __shared__ __attribute__((aligned(16))) double sE[FZ_NT * FZ_LDJ], sO[FZ_NT * FZ_LDJ];
+  const int tid = threadIdx.x, lane = tid & 63, mt = tid >> 6;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int M = p.M, H = p.H, mm = M - 1;
+  const int oi = mt * 16 + l16;                                        // modal position / output point of this lane (mirror: mm - oi)
+  auto chains = [&](const double *AE, const double *AO, fz_v4 (&ce)[2], fz_v4 (&co)[2]) {
+    asm volatile("" : "+s"(AE), "+s"(AO));
+    double ae[FZ_KS], ao[FZ_KS];
+#pragma unroll
+    for (int s = 0; s < FZ_KS; s++) { const long q = ((long)(mt * FZ_KS + s)) * 64 + lane; ae[s] = AE[q]; ao[s] = AO[q]; }
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      ce[sub] = fz_v4{0.0, 0.0, 0.0, 0.0}; co[sub] = fz_v4{0.0, 0.0, 0.0, 0.0};
+      const int frag = (sub * 16 + l16) * FZ_LDJ + kq;
+#pragma unroll
+      for (int s = 0; s < FZ_KS; s++) {
+        ce[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(sE[frag + 4 * s], ae[s], ce[sub], 0, 0, 0);
+        co[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(sO[frag + 4 * s], ao[s], co[sub], 0, 0, 0);
+      }
+    }
+  };
+  for (unsigned tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // ---- A: four slots per thread: line, points (j, j + 1) and their mirrors (mm - j - 1, mm - j); H odd: the last pair is its own mirror
+    {
+      double2 rj[4], rm[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int id = tid + 256 * u, line = id >> 5, j = 2 * (id & 31);
+        const unsigned gl = tile * FZ_NT + line;
+        rj[u] = make_double2(0.0, 0.0); rm[u] = rj[u];
+        if (j < H && gl < p.ncols) { rj[u] = *(const double2 *)(p.x + (long)gl * M + j); rm[u] = *(const double2 *)(p.x + (long)gl * M + (mm - j - 1)); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int id = tid + 256 * u, line = id >> 5, j = 2 * (id & 31);
+        const bool two = j + 1 < H;                                    // (j + 1 == H: that point belongs to the mirror half)
+        *(double2 *)(sE + line * FZ_LDJ + j) = make_double2(rj[u].x + rm[u].y, two ? rj[u].y + rm[u].x : 0.0);
+        *(double2 *)(sO + line * FZ_LDJ + j) = make_double2(rj[u].x - rm[u].y, two ? rj[u].y - rm[u].x : 0.0);
+      }
+    }
+    __syncthreads();
+    // ---- B: modal coefficients, scaled, back to LDS as the split halves of the backward product
+    {
+      double we[2][4], wo[2][4];
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned gl = tile * FZ_NT + sub * 16 + 4 * r + kq;
+          const bool ok = oi < H && gl < p.ncols;
+          we[sub][r] = ok ? p.W[(long)gl * M + oi] : 0.0; wo[sub][r] = ok ? p.W[(long)gl * M + (mm - oi)] : 0.0;
+        }
+      fz_v4 ce[2], co[2];
+      chains(p.FE, p.FO, ce, co);
+      __syncthreads();                                                 // every wave has finished reading the x images
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int line = sub * 16 + 4 * r + kq;
+          sE[line * FZ_LDJ + oi] = we[sub][r] * ce[sub][r];             // (positions H .. 4 KS - 1 get 0: the zero padding of the images)
+          sO[line * FZ_LDJ + oi] = wo[sub][r] * co[sub][r];
+        }
+    }
+    __syncthreads();
+    // ---- D: y = S c: row i <- E + O, row mm - i <- E - O (the backward matrix is stored centro-symmetric)
+    {
+      fz_v4 ce[2], co[2];
+      chains(p.BE, p.BO, ce, co);
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned gl = tile * FZ_NT + sub * 16 + 4 * r + kq;
+          if (oi < H && gl < p.ncols) {
+            double *row = p.y + (long)gl * M;
+            row[oi] = ce[sub][r] + co[sub][r]; row[mm - oi] = ce[sub][r] - co[sub][r];
+          }
+        }
+    }
+    __syncthreads();                                                   // the images are rewritten by the next tile
+  }
+}
+
 struct LineMats { DiffMat Fcs, Fca, Bcs, Bca, Fraw, Braw; double *lam = nullptr; bool ok = false; };
 
 }  // namespace
@@ -399,14 +498,23 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
                        lam.p[0], lam.p[1], lam.p[2], pc->W);
     PHIPCHK(hipGetLastError());
   }
+  // The last forward transform, the scaling and the first backward transform act on the same contiguous lines: one launch
+  // (k_fdm_zsolve16) where those lines have 66 .. 128 interior points, an even number of them (option "fdm_z_separate" = 1: A/B)
+  bool zsolve = false;
+  {
+    const int M = pc->geo.dims[d - 1] - 2;
+    LineMats &lm = pc->lines[pc->geo.dims[d - 1]];
+    zsolve = w_ok && d >= 2 && !opt(OPT_FDM_Z_SEPARATE) && !opt(OPT_NO_RAW_TRANSFORMS) && !opt(OPT_GENERAL_KERNELS) && (M & 1) == 0 &&
+             lm.Fraw.KS == FZ_KS && lm.Braw.KS == FZ_KS && lm.Braw.sym == 1 && pc->G * pc->nf / M < 0x7fffffffL - FZ_NT;
+  }
   bool scaled = false;
-  for (int q = 0; q < d; q++) {
+  for (int q = 0; q < (zsolve ? d - 1 : d); q++) {
     const int k = order[q];
     const bool last = q == d - 1 && q > 0 && w_ok;
     int rc = line_transform(pc, k, false, src, a, st, last ? pc->W : nullptr, last ? &scaled : nullptr, q == 0 ? in_mul : nullptr); if (rc) return rc;
     src = a; std::swap(a, b);
   }
-  if (!scaled) {
+  if (!scaled && !zsolve) {
     if (lines == 0) { /* a slab without interior planes: nothing to scale (it still takes part in the transforms along dimension 0) */ }
     else if (d <= 3 && lines <= 65535 && pc->nf <= 65535) {
       const int n1 = d == 3 ? pc->geo.dims[1] - 2 : 1;
@@ -416,7 +524,20 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
     else
       hipLaunchKernelGGL(k_modal_scale, dim3(pgrid(pc->G * pc->nf)), dim3(256), 0, st, pc->geo, pc->G, pc->nf, lam, (double *)src);
   }
-  for (int k = d - 1; k >= 0; k--) {
+  if (zsolve) {
+    const int M = pc->geo.dims[d - 1] - 2;
+    LineMats &lm = pc->lines[pc->geo.dims[d - 1]];
+    FzParams fp = {};
+    fp.M = M; fp.H = (M + 1) / 2; fp.ncols = (unsigned)(pc->G * pc->nf / M); fp.ntiles = (fp.ncols + FZ_NT - 1) / FZ_NT;
+    fp.x = src; fp.W = pc->W; fp.y = (d == 1) ? z : a;
+    fp.FE = lm.Fraw.fragE; fp.FO = lm.Fraw.fragO; fp.BE = lm.Braw.fragE; fp.BO = lm.Braw.fragO;
+    hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err); PHIPCHK(cu_err);
+    const unsigned grid = fp.ntiles < 3u * (unsigned)ncu ? fp.ntiles : 3u * (unsigned)ncu;       // three workgroups per CU
+    if (grid) hipLaunchKernelGGL(k_fdm_zsolve16, dim3(grid), dim3(256), 0, st, fp);
+    PHIPCHK(hipGetLastError());
+    src = a; std::swap(a, b);
+  }
+  for (int k = (zsolve ? d - 2 : d - 1); k >= 0; k--) {
     double *dst = (k == 0) ? z : a;
     int rc = line_transform(pc, k, true, src, dst, st); if (rc) return rc;
     src = dst; std::swap(a, b);

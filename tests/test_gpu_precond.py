@@ -143,13 +143,15 @@ def test_stokes_velocity_pc(dims):
 
 @pytest.mark.parametrize("visc", ["unit", "variable"])
 @pytest.mark.parametrize("dims,stokes", [((20, 18, 16), False), ((34, 34, 34), False), ((66, 66, 66), False), ((70, 68, 40), False), ((40, 68, 130), False),
-                                         ((130, 70), False), ((40, 131), False), ((131, 40), False), ((34, 34, 34), True), ((20, 18, 130), True), ((70, 20, 18), True)],
+                                         ((130, 70), False), ((40, 131), False), ((131, 40), False), ((34, 34, 34), True), ((20, 18, 130), True), ((70, 20, 18), True),
+                                         ((20, 18, 128), True), ((34, 20, 100), False), ((30, 128), False), ((36, 70, 68), True)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("stokes" if v else "scalar"))
 def test_pointwise_steps_inside_the_line_transforms(dims, stokes, visc):
     """z = P_1^-1 (r / eta): the division by eta rides on the LOAD of the first forward line transform (IN_MUL, lines of more than
     64 points) and the modal scaling on the STORE of the last one (OUT_MUL) -- multiplications by reciprocals, sweep.h -- where
     those transforms are one launch of the 16-byte kernels: short and long lines, both tilings, one and d stacked fields; odd
-    interior extents keep the passes.  Option `fdm_passes` restores the two passes that divide: the routes agree to rounding,
+    interior extents keep the passes.  Where the last dimension has 66 .. 128 interior points (an even number) the last forward
+    transform, the scaling and the first backward transform are ONE launch (k_fdm_zsolve16; H even and odd, partial tiles).  Option `fdm_passes` restores the two passes that divide: the routes agree to rounding,
     and with eta == 1 the solve is still the inverse of the stencil."""
     op = sp.StokesOp(dims) if stokes else sp.EllipticOp(dims)
     n = op.velocity_size if stokes else op.global_size
