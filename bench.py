@@ -362,12 +362,21 @@ def solves(sp, torch):
     b = torch.empty_like(us)
     op.function(us, None, b, 4.0, 2.0)                      # b = A(u*) u*
     x = torch.zeros_like(us)
-    pc = sp.FdPc(op, sweeps=0)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-10, ksp_rtol=1e-6, ksp_restart=30, ksp_max_it=300, M=pc,
-                                        monitor=lambda i, f, k: pc.update())
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    out["elliptic_256_gamma4"] = {"seconds": dt, "newton_its": its, "krylov_its": kits,
+    # Every solve is run twice from the same start and the SECOND run is reported (`seconds`): the first (`seconds_first_run`)
+    # also pays the one-off costs of a fresh process -- device allocations of the Krylov bases (gigabytes at these sizes), first
+    # touches, clocks -- which vary by tens of per cent from box to box and say nothing about the solve (1.28 / 1.51 s were seen
+    # for the same config-5 solve on the same sources).  Same iteration counts in both runs.
+    dts = []
+    for rep in range(2):
+        x.zero_()
+        pc = sp.FdPc(op, sweeps=0)                          # (a fresh preconditioner per run: assembled from the state of ITS first residual)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-10, ksp_rtol=1e-6, ksp_restart=30, ksp_max_it=300, M=pc,
+                                            monitor=lambda i, f, k: pc.update())
+        torch.cuda.synchronize(); dts.append(time.perf_counter() - t0)
+        if rep == 0:
+            pc.destroy()
+    out["elliptic_256_gamma4"] = {"seconds": dts[1], "seconds_first_run": dts[0], "newton_its": its, "krylov_its": kits,
                                   "rel_err_vs_manufactured": float((x - us).abs().max() / us.abs().max())}
     pc.destroy(); op.destroy(); del us, b, x
 
@@ -392,13 +401,16 @@ def solves(sp, torch):
         U, U2, dv = exact2(P)
         st.set_dirichlet(dv); st.set_force(U2)
         x = torch.zeros(st.global_size, dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        stats = {}
-        # the linear problem is solved to its floor (-exact 2 is resolved to rounding on 64 CGL points): tight tolerances
-        log = solve.stokes_solve(sp, st, x, rheology=rheo, cont0=0, cont=cont, snes_rtol=1e-8 if rheo[0] else 1e-12, ksp_rtol=1e-5 if rheo[0] else 1e-12,
-                                 ksp_restart=60, ksp_max_it=200, max_linear_fail=3, snes_max_it=20, stats=stats)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        rec = {"seconds": dt, "stages": len(log), "newton_its": int(sum(s[2] for s in log)), "krylov_its": int(sum(s[3] for s in log)),
+        dts = []
+        for rep in range(2):                                # (the second run is the one reported: see above)
+            x.zero_()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            stats = {}
+            # the linear problem is solved to its floor (-exact 2 is resolved to rounding on 64 CGL points): tight tolerances
+            log = solve.stokes_solve(sp, st, x, rheology=rheo, cont0=0, cont=cont, snes_rtol=1e-8 if rheo[0] else 1e-12, ksp_rtol=1e-5 if rheo[0] else 1e-12,
+                                     ksp_restart=60, ksp_max_it=200, max_linear_fail=3, snes_max_it=20, stats=stats)
+            torch.cuda.synchronize(); dts.append(time.perf_counter() - t0)
+        rec = {"seconds": dts[1], "seconds_first_run": dts[0], "stages": len(log), "newton_its": int(sum(s[2] for s in log)), "krylov_its": int(sum(s[3] for s in log)),
                "residual_norm": float(log[-1][4]), "linear_solves_ended_on_iteration_limit": int(stats.get("linear_fails", -1))}
         if not rheo[0]:                                     # the field is the exact solution of the linear problem only
             xs = x.cpu().numpy().reshape(-1, 4); Us = U.reshape(-1, 4)
