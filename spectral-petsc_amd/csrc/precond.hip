@@ -169,7 +169,8 @@ __global__ void k_deinterleave_over_eta(long G, int nf, const double *__restrict
 //   A  x lines -> LDS, parity-split          B  c = S^-1 x on the matrix cores; c .*= W; back to LDS as the already split halves
 //   D  y = S c on the matrix cores -> HBM
 // 24 B/value (x, W, y) instead of 40 for the two launches it replaces.  Lines of 66 .. 128 interior points (KS = 16), M even; tiles of
-// 32 lines.
+// 32 lines.  (W and y move as 8-byte pieces in accumulator layout; 16-byte pieces after a DPP lane exchange, as in the sweep kernels'
+// epilogue, were built and gave nothing: 144 -> 145-147 us for the MatVVPC solve.)
 typedef double fz_v4 __attribute__((ext_vector_type(4)));
 struct FzParams { int M, H; unsigned ncols, ntiles; const double *x, *W; double *y; const double *FE, *FO, *BE, *BO; };
 constexpr int FZ_KS = 16, FZ_LDJ = 4 * FZ_KS + 2, FZ_NT = 32;
