@@ -19,7 +19,9 @@ counters, profiles/) when the committed measurement belongs to the sources being
 FP64 matrix peak that actually bounds the kernel at P = 256.  `cpu_baseline` times the CPU oracle (a port of
 the reference's pass structure; FFTW/PETSc are not installed) on this box's host cores, rank 0, N = 1 only.
 `spinup` untimed matvecs run before the W warm-up steps (setup: an idle MI355X needs a few ms of load before
-its clocks settle) and are reported in the line.
+its clocks settle) and are reported in the line.  After the timed region (N = 1, informational): `extras_us` (the other
+callbacks of BASELINE configs 2, 4, 5), `dist_rank_compute` (one slab rank's kernels without a wire) and `solves` (end-to-end
+solves of the callers; each is run twice and the second run is `seconds`, the first `seconds_first_run`).
 """
 import argparse
 import json
