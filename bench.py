@@ -9,6 +9,9 @@ Poisson state (gamma = 0: eta == 1, deta == 0), global in/out vectors resident i
                                                            (N > 1: the same 256^3 grid slab-split
                                                             over N ranks, RCCL all-to-all transposes;
                                                             strong scaling)
+  python bench.py --gpus N ...                             (the same, typed without a launcher: bench.py starts
+                                                            the N ranks itself as child processes -- before it
+                                                            touches the GPU -- and exits with their status)
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (cheb_sweep_vec4_kernel,
 csrc/sweep_vec.hip) with the algorithmic bytes of SURVEY 8(d): 112 B/point per matvec (the six-ChebMult
 model), spread over the 3 launches that carry it.  That figure is a MODEL figure of merit: the
@@ -49,7 +52,51 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings of the other BASELINE configs")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="N > 1 plumbing only (tests/test_bench_launch.py): spawn, rendezvous, one all-reduce, rank 0's line; no GPU, no compute, no metric")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` typed as it stands (no launcher, WORLD_SIZE unset): start the N ranks ourselves.  The parent has
+    not imported torch.cuda nor touched the GPU in any way (on this pool a process that has initialised the GPU must never exec,
+    and a parent holding the GPU would be a rank too many on the card): it starts `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <the same arguments>` as a CHILD process
+    (subprocess, not exec), whose rank 0 prints the JSON line on the stdout it inherits, and exits with the child's status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    env["BENCH_SPAWNED_BY"] = str(os.getpid())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_selftest(args, world, rank):
+    """--launch-selftest: what the self-spawning entry adds, and nothing else -- the ranks exist, meet on 127.0.0.1 over
+    BENCH_DIST_BACKEND (gloo on CPU), agree on one all-reduce, and rank 0's single JSON line reaches the caller's stdout."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("BENCH_DIST_BACKEND", "gloo")
+    if backend == "nccl":
+        raise SystemExit("--launch-selftest is a CPU check of the launcher: BENCH_DIST_BACKEND=gloo")
+    if world > 1:
+        dist.init_process_group(backend=backend)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_selftest": True, "n_gpus": world, "rank_sum": int(t.item()), "backend": backend,
+                          "spawned_by_bench": "BENCH_SPAWNED_BY" in os.environ}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def csrc_hash():
@@ -425,18 +472,26 @@ def solves(sp, torch):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed without a launcher: this process becomes the parent of the N ranks -- decided before torch is imported
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run, or unset WORLD_SIZE and let bench.py start its ranks)" % (args.gpus, world))
+    if args.launch_selftest:
+        sys.exit(launch_selftest(args, world, rank))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
     sp = ge.load()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if world > 1 and os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d on a box with %d GPU(s): RCCL needs one GPU per rank (BENCH_DIST_BACKEND=gloo rehearses the N > 1 path "
+                         "with the ranks sharing a GPU and the exchange staged through the host: plumbing, not a measurement)" % (world, torch.cuda.device_count()))
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1
     # path on a single-GPU box (the exchange is then staged through the host: not a measurement)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -588,16 +643,17 @@ def main():
             except Exception as e:
                 out["power_error"] = repr(e)[:200]
         if world == 1 and not args.no_extras:
+            try:                                            # informational: never at the expense of the metric line
+                out["extras_us"] = extras(sp, torch)        # (before solves(): the callbacks' handles are made in a fresh allocator state)
+                out["extras_frac"] = extras_frac(out["extras_us"])
+            except Exception as e:
+                out["extras_us"] = {"error": repr(e)[:200]}
+        if world == 1 and not args.no_extras:
             try:
                 out["solves"] = solves(sp, torch)
             except Exception as e:
                 out["solves_error"] = repr(e)[:300]
         if world == 1 and not args.no_extras:
-            try:                                            # informational: never at the expense of the metric line
-                out["extras_us"] = extras(sp, torch)
-                out["extras_frac"] = extras_frac(out["extras_us"])
-            except Exception as e:
-                out["extras_us"] = {"error": repr(e)[:200]}
             try:                                            # compute side of one rank at G = 2, 4, 8 (no wire)
                 out["dist_rank_compute"] = dist_rank_compute(sp, ge.load_dist(), torch, dev_ms / args.steps * 1e3)
             except Exception as e:

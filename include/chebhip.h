@@ -362,8 +362,8 @@ int chebhip_fdpc_destroy(chebhip_fdpc *pc);
 /* Slab mode (the serial reference has no counterpart): the handle preconditions the unknowns of ONE slab of planes of
  * dimension 0; its approximate solve is z = P_1^-1 (r / eta) by fast diagonalisation (sweeps = 0), whose line transforms along
  * dimension 0 run on pencils: `dim0` (collective over the ranks) moves `nfields` stacked interior fields of the slab at in_dev to
- * pencils, applies chebhip_fdpc_pencil_transform and moves the result back to out_dev.  Made by chebhip_dist_stokes_pc_create /
- * chebhip_dist_ell_pc_create (csrc/slabx.hip), which supply the callback; i0_offset = interior planes owned by lower ranks. */
+ * pencils, applies chebhip_fdpc_pencil_transform and moves the result back to out_dev.  Made by chebhip_dist_stokes_pc /
+ * chebhip_dist_ell_pc (csrc/slabx.hip), which supply the callback; i0_offset = interior planes owned by lower ranks. */
 typedef int (*chebhip_fdpc_dim0_fn)(void *ctx, int backward, int nfields, const double *in_dev, double *out_dev, void *stream);
 int stokes_pc_create_slab(stokes_op *slab_op, long i0_offset, chebhip_fdpc_dim0_fn dim0, void *ctx, chebhip_fdpc **out);
 int ell_pc_create_slab(ell_op *slab_op, long i0_offset, chebhip_fdpc_dim0_fn dim0, void *ctx, chebhip_fdpc **out);
@@ -389,7 +389,9 @@ typedef struct stokes_saddle stokes_saddle;
 int stokes_saddle_create(stokes_op *op, stokes_saddle **out);
 /* On slabs: slab_op = chebhip_dist_stokes_op(D), slab_pc = chebhip_dist_stokes_pc(D) (borrowed), reduce / reduce_ctx =
  * chebhip_comm_reduce with the driver's communicator.  The inner solves and the removal of the constant pressure mode complete
- * their sums over the ranks; stokes_saddle_apply is then collective.  The serial reference has no counterpart. */
+ * their sums over the ranks; stokes_saddle_apply is then collective.  The serial reference has no counterpart.
+ * Destroy order: the saddle BORROWS slab_op, slab_pc and reduce_ctx -- destroy it before chebhip_dist_stokes_destroy(D) (which frees
+ * the pc) and before the communicator. */
 int stokes_saddle_create_slab(stokes_op *slab_op, chebhip_fdpc *slab_pc, chebhip_reduce_fn reduce, void *reduce_ctx, stokes_saddle **out);
 int stokes_saddle_destroy(stokes_saddle *s);
 /* -pc_saddle_type (stokes.C:177-187): 0 block LU, 1 upper triangular, 2 block diagonal, 3 lower triangular. */

@@ -554,11 +554,27 @@ class StokesOp:
         _chk(lib().stokes_op_pencil_pressure(self._h, ncol, p_pencil.data_ptr(), gp0_pencil.data_ptr(), _stream()))
         return gp0_pencil
 
-    def mult_schur(self, p, pout, restart=None, rtol=None, atol=1e-50, max_it=10000):
-        """StokesMatMultSchur (stokes.C:523-535) with the built-in inner GMRES on MatVV (KSP defaults unless given)."""
+    def mult_schur(self, p, pout, restart=None, rtol=None, atol=1e-50, max_it=10000, inner=None):
+        """StokesMatMultSchur (stokes.C:523-535) with the built-in inner GMRES on MatVV (KSP defaults unless given), or with
+        `inner`: a callable (b, x) on device velocity tensors that solves VV x = b -- the user's KSPSchurVelocity (stokes.C:531),
+        handed to the C entry point as its inner_solve callback exactly as the PETSc adapter does."""
         if restart is not None or rtol is not None:
             _chk(lib().stokes_op_set_inner_solver(self._h, 30 if restart is None else restart, 1e-5 if rtol is None else rtol, atol, max_it))
-        _chk(lib().stokes_op_mult_schur(self._h, _dev_ptr(p, self.pressure_size), _dev_ptr(pout, self.pressure_size), None, None, _stream()))
+        cb = None
+        if inner is not None:
+            n = self.velocity_size
+
+            def tramp(ctx, bp, xp, stream):
+                try:
+                    inner(device_view(bp, n), device_view(xp, n))
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 5
+            cb = Fgmres.APPLY_FN(tramp)
+        _chk(lib().stokes_op_mult_schur(self._h, _dev_ptr(p, self.pressure_size), _dev_ptr(pout, self.pressure_size),
+                                        C.cast(cb, C.c_void_p) if cb else None, None, _stream()))
         return pout
 
     def set_inner_reduce(self, group=None):

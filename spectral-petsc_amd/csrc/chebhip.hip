@@ -51,6 +51,7 @@ extern "C" long chebhip_launch_count(void) { return sweep_launch_count(); }
 // ---------------------------------------------------------------------------------------------
 extern "C" int chebhip_set_option(const char *name, int value) {
   if (!name) return fail(CHEBHIP_ERR_ARG, "NULL option name");
+  if (!strcmp(name, "no_rocblas")) { opt_set(OPT_VENDOR_GEMM, value ? 0 : 1); return 0; }   // deprecated name (rounds 1-3), inverted meaning
   const int id = opt_find(name);
   if (id < 0) return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
   opt_set(id, value);
@@ -58,6 +59,7 @@ extern "C" int chebhip_set_option(const char *name, int value) {
 }
 extern "C" int chebhip_get_option(const char *name, int *value) {
   if (!name || !value) return fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (!strcmp(name, "no_rocblas")) { *value = opt(OPT_VENDOR_GEMM) ? 0 : 1; return 0; }
   const int id = opt_find(name);
   if (id < 0) return fail(CHEBHIP_ERR_ARG, "unknown option '%s'", name);
   *value = opt(id);
@@ -557,7 +559,7 @@ int ell_op_sync_coeffs(ell_op *op, void *stream) { return op ? ell_sync_coeffs(o
 
 int ell_op_fd_view(ell_op *op, chebhip::FdView *v) {
   if (!op || !v) return fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (op->slab) return fail(CHEBHIP_ERR_ARG, "slab-mode handle: the preconditioner comes from chebhip_dist_ell_pc_create");
+  if (op->slab) return fail(CHEBHIP_ERR_ARG, "slab-mode handle: the preconditioner comes from chebhip_dist_ell_pc");
   return ell_op_fd_view_any(op, v, nullptr);
 }
 int ell_op_fd_view_any(ell_op *op, chebhip::FdView *v, int *gP0) {

@@ -470,11 +470,13 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
   const int d = pc->geo.d;
   const double *src = r;
   double *a = pc->t0, *b = pc->t1;
-  // Forward transforms commute: on slabs the first one is a local direction (1) rather than the collective one (0), so that it
-  // can take the division by eta on its load side; the last one (d-1) takes the modal scaling on its store side.
+  // Forward transforms commute: on slabs in 3-D the first one is a local direction (1) rather than the collective one (0), so that
+  // it can take the division by eta on its load side.  Dimension d-1 stays LAST in every order: it takes the modal scaling on its
+  // store side, and the one-launch z solve below replaces exactly that transform (a 2-D slab therefore keeps the order 0, 1: its
+  // only local direction is the last one, and the division by eta is the separate pass).
   int order[MAXD];
   for (int k = 0; k < d; k++) order[k] = k;
-  if (pc->slab && d >= 2) { order[0] = 1; order[1] = 0; }
+  if (pc->slab && d >= 3) { order[0] = 1; order[1] = 0; }
   const double *in_mul = nullptr;
   if (over_eta) {
     if (pc->Einv_ok && !opt(OPT_FDM_PASSES) && d >= 2 && line_in_mul_ok(pc, order[0], r, a, pc->Einv)) in_mul = pc->Einv;

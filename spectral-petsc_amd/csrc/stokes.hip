@@ -1005,7 +1005,7 @@ extern "C" int stokes_op_create_slab(int d, const int *dims, int lo, int hi, sto
 
 int stokes_op_fd_view(stokes_op *op, chebhip::FdView *v) {
   if (!op || !v) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode handle: the preconditioner comes from chebhip_dist_stokes_pc_create");
+  if (op->slab) return chebhip_fail(CHEBHIP_ERR_ARG, "slab-mode handle: the preconditioner comes from chebhip_dist_stokes_pc");
   return stokes_op_fd_view_any(op, v, nullptr);
 }
 int stokes_op_fd_view_any(stokes_op *op, chebhip::FdView *v, int *gP0) {

@@ -28,6 +28,7 @@ The local arithmetic is delegated to a backend: HipBackend (the product: C-ABI c
 tensors).  tests/ supplies an oracle-based CPU backend to exercise the exchange logic under gloo.
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -596,6 +597,11 @@ class _DistC:
         return self._rng
 
     def destroy(self):
+        for w in getattr(self, "_saddles", []):       # borrowers of this driver's handles go first
+            M = w()
+            if M is not None:
+                M.destroy()
+        self._saddles = []
         if getattr(self, "_h", None):
             torch.cuda.synchronize()
             self._destroy(self._h)
@@ -642,7 +648,12 @@ class DistStokesC(_DistC):
         if self.comm is None:
             raise ValueError("slab preconditioner needs a communicator")
         rfn, rctx = self.comm.reduce_fn()
-        return self.sp.StokesSaddlePc(self.op, saddle_type, vel, schur, svel, 0, schur_jacobi, slab=(self.pc(), rfn, rctx))
+        M = self.sp.StokesSaddlePc(self.op, saddle_type, vel, schur, svel, 0, schur_jacobi, slab=(self.pc(), rfn, rctx))
+        # the saddle borrows the driver's pc handle and the communicator's reduce context: it keeps both alive, and
+        # destroy() of this driver destroys the saddles it handed out first (chebhip.h: stokes_saddle_create_slab)
+        M._slab_owner = (self, self.comm)
+        self._saddles = [w for w in getattr(self, "_saddles", []) if w() is not None] + [weakref.ref(M)]
+        return M
 
 
 class DistEllipticC(_DistC):

@@ -218,11 +218,15 @@ def _serial_state(sp, dims, x, dv, force, rheology):
     return ser
 
 
-@pytest.mark.parametrize("G,dims", [(2, (10, 9, 8)), (3, (13, 12)), (3, (4, 6)), (4, (18, 17, 9)), (6, (11, 15, 25)), (5, (24, 20, 70))], ids=str)
+@pytest.mark.parametrize("G,dims", [(2, (10, 9, 8)), (3, (13, 12)), (3, (4, 6)), (4, (18, 17, 9)), (6, (11, 15, 25)), (5, (24, 20, 70)),
+                                    (3, (24, 70)), (2, (40, 130)), (3, (12, 10, 100))], ids=str)
 def test_velocity_preconditioner_on_slabs(G, dims):
     """chebhip_dist_stokes_pc: z = P_1^-1 (r / eta) (MatVVPC's approximate solve, stokes.C:1160-1241 by fast diagonalisation) on the
     velocity unknowns of every slab, with a power-law viscosity, against the serial handle's.  (3, (4, 6)) and (6, (11, 15, 25)):
-    a rank without unknowns still takes part in the exchanges; (5, (24, 20, 70)): 68-point lines, the 16-byte kernels."""
+    a rank without unknowns still takes part in the exchanges; (5, (24, 20, 70)): 68-point lines, the 16-byte kernels.
+    (3, (24, 70)), (2, (40, 130)): 2-D slabs whose last dimension takes the one-launch z solve (k_fdm_zsolve16: 66..128 interior
+    points, an even number) -- the round-4 order of the forward transforms skipped dimension 0 there (ADVICE r4, high);
+    (3, (12, 10, 100)): the same launch in 3-D."""
     sp = ge.load(); dsp = ge.load_dist()
     d = len(dims)
     x, dv, force, w = stokes_inputs(dims)
@@ -249,6 +253,44 @@ def test_velocity_preconditioner_on_slabs(G, dims):
     pc.apply(rs, zs); torch.cuda.synchronize()
     pc.destroy(); ser.destroy()
     assert relerr(z, zs.cpu().numpy()) < 1e-12
+
+
+@pytest.mark.parametrize("G,dims", [(3, (24, 70)), (2, (40, 130)), (4, (18, 17, 9)), (3, (5, 29)), (6, (5, 7, 6)), (3, (12, 10, 100)), (2, (13, 12))], ids=str)
+def test_elliptic_preconditioner_on_slabs(G, dims):
+    """chebhip_dist_ell_pc (FormJacobian's matrix, elliptic.C:537-590, solved by fast diagonalisation on slabs): z = P_1^-1 (r / eta)
+    with the variable eta a FormFunction (gamma = 4) leaves, against the serial handle's FdPc(sweeps = 0).  2-D and 3-D, last dimensions
+    that take the one-launch z solve (68, 128 and 98 interior points), (3, (5, 29)) and (6, (5, 7, 6)): ranks without interior planes
+    (SlabX::setup_interior with dims[0] - 2 < G) that still take part in the exchanges."""
+    sp = ge.load(); dsp = ge.load_dist()
+    n, g, nd = orc.sizes(dims)
+    rng = np.random.default_rng(SEED)
+    U = rng.random(g) + 0.5; b = rng.standard_normal(g); dirv = rng.standard_normal(nd); r = rng.standard_normal(g)
+
+    def body(rank, comm):
+        D = dsp.DistEllipticC(dims, sp, comm=comm)
+        (n0, n1), (b0, b1) = D.serial_ranges()
+        D.op.set_dirichlet(dirv[b0:b1])
+        Ul, bl, rl = (torch.from_numpy(a[n0:n1].copy()).cuda() for a in (U, b, r))
+        R = torch.empty_like(Ul)
+        D.function(Ul, bl, R, gamma=4.0, exponent=2.0)
+        pc = D.pc(); pc.update()
+        zl = torch.full_like(rl, float("nan"))
+        pc.apply(rl, zl); pc.apply(rl, zl)
+        torch.cuda.current_stream().synchronize()
+        res = (n0, zl.cpu().numpy())
+        D.destroy()
+        return res
+    parts = sorted(run_ranks(G, body), key=lambda t: t[0])
+    z = np.concatenate([p[1] for p in parts])
+    ser = sp.EllipticOp(dims)
+    ser.set_dirichlet(dirv)
+    Us, bs = torch.from_numpy(U).cuda(), torch.from_numpy(b).cuda(); Rs = torch.empty_like(Us)
+    ser.function(Us, bs, Rs, gamma=4.0, exponent=2.0)
+    pc = sp.FdPc(ser, sweeps=0); pc.update()
+    rs = torch.from_numpy(r).cuda(); zs = torch.empty_like(rs)
+    pc.apply(rs, zs); torch.cuda.synchronize()
+    pc.destroy(); ser.destroy()
+    assert np.all(np.isfinite(z)) and relerr(z, zs.cpu().numpy()) < 1e-12
 
 
 @pytest.mark.parametrize("G,dims,stype", [(2, (10, 9, 8), 0), (3, (13, 12), 1), (3, (4, 6), 0), (4, (18, 17, 9), 2), (6, (11, 15, 25), 3)], ids=str)

@@ -155,3 +155,106 @@ def test_stokes_schur_vs_dense(sp, dims):
     assert op.inner_iterations <= its_tight
     assert np.linalg.norm(yd.cpu().numpy() - ref) <= 1e-2 * np.linalg.norm(ref)
     op.destroy()
+
+
+def _schur_inner(sp, op):
+    """KSPSchurVelocity as a caller would supply it (stokes.C:531): flexible GMRES on MatVV, right-preconditioned by the MatVVPC
+    solve, driven to its floor -- handed to stokes_op_mult_schur as the inner_solve callback."""
+    pc = sp.FdPc(op, sweeps=0); pc.update()
+    ks = sp.Fgmres(op.velocity_size, restart=80, rtol=1e-14, max_it=400)
+    its = []
+
+    def inner(b, x):
+        ks.solve(op, b, x, M=pc, a_entry="mult_vv")
+        its.append(ks.iterations)
+    return inner, its, (ks, pc)
+
+
+def test_schur_apply_vs_oracle_side_solve_32(sp):
+    """StokesMatMultSchur (stokes.C:523-535) against the composition assembled on the ORACLE side only: -PV (VV^-1 (VP p)) with
+    VV^-1 by scipy's GMRES on the oracle's StokesMatMultVV (preconditioned by a sparse LU of the oracle's MatVVPC matrix,
+    orc_fd_matrix), at 32^3 -- the largest size at which the oracle-side solve takes seconds."""
+    import scipy.sparse.linalg as spla
+    import torch
+    dims = (32, 32, 32)
+    op = sp.StokesOp(dims)
+    gv, gp = op.velocity_size, op.pressure_size
+    p = np.random.default_rng(SEED + 11).standard_normal(gp)
+    # oracle side
+    rhs = orc.stokes_mult_vp(dims, p, nthreads=16)
+    lu = spla.splu(orc.fd_matrix(dims).tocsc())
+
+    def prec(r):
+        R = r.reshape(-1, 3)
+        return np.stack([lu.solve(np.ascontiguousarray(R[:, c])) for c in range(3)], axis=1).ravel()
+    A = spla.LinearOperator((gv, gv), matvec=lambda v: orc.stokes_mult_vv(dims, v, nthreads=16), dtype=np.float64)
+    M = spla.LinearOperator((gv, gv), matvec=prec, dtype=np.float64)
+    v, info = spla.gmres(A, rhs, M=M, rtol=1e-13, atol=0.0, restart=120, maxiter=20)
+    assert info == 0
+    assert np.linalg.norm(orc.stokes_mult_vv(dims, v, nthreads=16) - rhs) <= 1e-11 * np.linalg.norm(rhs)
+    ref = -orc.stokes_divergence(dims, v, nthreads=16)
+    # HIP side: the C entry point with a caller-supplied inner solve, and with its built-in GMRES at KSP's default tolerance
+    inner, its, keep = _schur_inner(sp, op)
+    pd = torch.from_numpy(p).cuda(); sd = torch.full_like(pd, float("nan"))
+    op.mult_schur(pd, sd, inner=inner)
+    torch.cuda.synchronize()
+    s = sd.cpu().numpy()
+    assert its and 0 < its[0] < 400
+    err = np.linalg.norm(s - ref) / np.linalg.norm(ref)
+    assert err <= 1e-8, err
+    op.mult_schur(pd, sd, restart=30, rtol=1e-5)
+    torch.cuda.synchronize()
+    assert op.inner_iterations > 0
+    assert np.linalg.norm(sd.cpu().numpy() - ref) <= 1e-2 * np.linalg.norm(ref)
+    keep[0].destroy(); keep[1].destroy(); op.destroy()
+
+
+def test_schur_apply_at_config4_size_64(sp):
+    """BASELINE config 4 names the Schur apply at 64^3.  No oracle-side solve is affordable there, so S = -PV VV^-1 VP is pinned by
+    what needs forward applies of the oracle only: with v the HIP path's inner solution for VP p (the same caller-supplied solve),
+    (1) VV_oracle v = VP_oracle p to the solver's floor, i.e. v IS VV^-1 VP p of the oracle's operators, and (2) the entry point's
+    result equals -PV_oracle v.  Properties: S 1 = 0 (the constant pressure is in the null space, stokes.C:1017-1023: VP 1 = 0),
+    linearity, and the built-in inner GMRES at KSP's default tolerance lands within that tolerance of the tight result.
+    (<x, S y> = <S x, y> is NOT a property here: the collocation blocks are not symmetric in the l2 inner product; the test
+    asserts that the asymmetry is real rather than pretending otherwise.)"""
+    import torch
+    dims = (64, 64, 64)
+    op = sp.StokesOp(dims)
+    gv, gp = op.velocity_size, op.pressure_size
+    rng = np.random.default_rng(SEED + 12)
+    p, q = rng.standard_normal(gp), rng.standard_normal(gp)
+    inner, its, keep = _schur_inner(sp, op)
+    dev = lambda a: torch.from_numpy(a).cuda()
+
+    def S(x):
+        yd = torch.full((gp,), float("nan"), dtype=torch.float64, device="cuda")
+        op.mult_schur(dev(x), yd, inner=inner)
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+    sp_, sq = S(p), S(q)
+    assert all(0 < k < 400 for k in its)                     # every inner solve converged before its limit
+    # (1), (2): the oracle's forward operators on the HIP path's inner solution
+    rd = torch.empty(gv, dtype=torch.float64, device="cuda"); vd = torch.empty_like(rd)
+    op.mult_vp(dev(p), rd); inner(rd, vd); torch.cuda.synchronize()
+    v = vd.cpu().numpy()
+    rhs = orc.stokes_mult_vp(dims, p, nthreads=16)
+    res = np.linalg.norm(orc.stokes_mult_vv(dims, v, nthreads=16) - rhs) / np.linalg.norm(rhs)
+    assert res <= 1e-10, res
+    ref = -orc.stokes_divergence(dims, v, nthreads=16)
+    err = np.linalg.norm(sp_ - ref) / np.linalg.norm(ref)
+    assert err <= 1e-10, err
+    # properties
+    scale = np.linalg.norm(sp_) / np.linalg.norm(p)
+    s1 = S(np.ones(gp))
+    assert np.linalg.norm(s1) <= 1e-9 * scale * np.sqrt(gp), np.linalg.norm(s1)
+    lin = S(0.75 * p - 1.5 * q)
+    assert np.linalg.norm(lin - (0.75 * sp_ - 1.5 * sq)) <= 1e-9 * np.linalg.norm(lin)
+    asym = abs(q @ sp_ - p @ sq) / (np.linalg.norm(p) * np.linalg.norm(sq))
+    assert asym > 1e-6, asym
+    # the built-in solver: unpreconditioned GMRES(30) on MatVV at KSP's defaults (what a NULL callback runs)
+    yd = torch.empty(gp, dtype=torch.float64, device="cuda")
+    op.mult_schur(dev(p), yd, restart=30, rtol=1e-5)
+    torch.cuda.synchronize()
+    assert op.inner_iterations > 0
+    assert np.linalg.norm(yd.cpu().numpy() - sp_) <= 1e-2 * np.linalg.norm(sp_)
+    keep[0].destroy(); keep[1].destroy(); op.destroy()
