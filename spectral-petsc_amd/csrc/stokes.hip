@@ -856,8 +856,9 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   for (auto &kv : op->matsDD) diffmat_destroy(&kv.second);
   if (op->slab) { op->pL = nullptr; op->gp[0] = nullptr; }      // parts of xL / V[0] / strain[0] (st_create)
   double *all[] = {op->xL, op->yL, op->V[0], op->V[1], op->V[2], op->strain[0], op->strain[1], op->strain[2], op->eta, op->deta,
-                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->dirloc, op->force, op->yLx[1], op->yLx[2], op->T, op->xF};
+                   op->pL, op->p2, op->gp[0], op->gp[1], op->gp[2], op->yLx[1], op->yLx[2], op->T, op->xF};
   for (double *p : all) st_free(p);
+  st_free(op->dirloc); st_free(op->force);
   st_free(op->sv0); st_free(op->sv1);
   if (op->inner) chebhip_fgmres_destroy(op->inner);
   if (op->aux) (void)hipStreamDestroy(op->aux);
@@ -938,25 +939,35 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
   // fields, see st_gradient_and_pressure_gradient_slab): pL sits right behind xL, and gp[0] is the (d+1)-th field of whichever
   // array receives the gradient (V[0] in StokesMatMult, strain[0] in StokesFunction) -- set per call, not allocated.
   const size_t nd1 = slab ? nd + (size_t)N : nd;
-  OPRC(st_alloc(&op->xL, nd1)); OPRC(st_alloc(&op->yL, nd));
-  if (op->uniform_ok) OPRC(st_alloc(&op->xF, nd));
-  for (int j = 1; j < d; j++) OPRC(st_alloc(&op->yLx[j], nd));
+  struct Req { double **p; size_t n; };
+  std::vector<Req> reqs;
+  auto want = [&](double **p, size_t n) { reqs.push_back({p, n}); };
+  want(&op->xL, nd1); want(&op->yL, nd);
+  if (op->uniform_ok) want(&op->xF, nd);
+  for (int j = 1; j < d; j++) want(&op->yLx[j], nd);
   for (int j = 0; j < d; j++) {
-    OPRC(st_alloc(&op->V[j], j == 0 ? nd1 : nd)); OPRC(st_alloc(&op->strain[j], j == 0 ? nd1 : nd));
-    if (!(slab && j == 0)) OPRC(st_alloc(&op->gp[j], (size_t)N));
+    want(&op->V[j], j == 0 ? nd1 : nd); want(&op->strain[j], j == 0 ? nd1 : nd);
+    if (!(slab && j == 0)) want(&op->gp[j], (size_t)N);
   }
-  if (slab) op->gp[0] = op->V[0] + nd;
-  OPRC(st_alloc(&op->eta, (size_t)N)); OPRC(st_alloc(&op->deta, (size_t)N));
+  want(&op->eta, (size_t)N); want(&op->deta, (size_t)N);
   // (the spaced-out input fields of the six-component storage exist in the 16-byte kernels only: not with "general_kernels")
   if (!slab && d == 3 && (N & 1) == 0 && (size_t)N * 9 * 8 < 0x38000000ull && !opt(OPT_FULL_STRESS) && !opt(OPT_GENERAL_KERNELS)) {
     bool ok = true;
     for (int k = 0; k < d; k++) ok = ok && op->mats[dims[k]].KS >= 16 && (dims[k] & 1) == 0;       // the long-line 16-byte kernel, both tilings
     const int nt_last = op->mats[dims[d - 1]].KS == 16 ? 64 : 32;                                   // lines per tile of the contiguous direction
     ok = ok && ((N / dims[d - 1]) % nt_last) == 0;
-    if (ok) { OPRC(st_alloc(&op->T, (size_t)N * 9)); op->sym = true; }
+    if (ok) { want(&op->T, (size_t)N * 9); op->sym = true; }
   }
-  if (slab) op->pL = op->xL + nd; else OPRC(st_alloc(&op->pL, (size_t)N));
-  OPRC(st_alloc(&op->p2, (size_t)N));
+  if (!slab) want(&op->pL, (size_t)N);
+  want(&op->p2, (size_t)N);
+  // One hipMalloc per array.  (Round 5 measured the alternative -- ONE allocation with every array at a chosen offset: contiguous, with
+  // 2..34-MiB gaps, with per-array shifts of 256 B .. 2 MiB, and with exactly the offsets separate allocations get -- because handles of
+  // one process differ by 6 % and keep their speed for life (128^3 power-law StokesMatMult 275 / 283 / 291 us; tools/placement_probe.py).
+  // Every arena layout ran at 279..290 us, the separate allocations of a fresh process at 275..278: the virtual layout is not the lever,
+  // the physical blocks behind each allocation are (the difference vanishes when a profiler serialises the launches, i.e. it lives in
+  // what one launch leaves in the caches for the next).  profiles/r05_placement*.txt, r05_arena_sweep*.txt; DESIGN_history.md.)
+  for (const Req &r : reqs) OPRC(st_alloc(r.p, r.n));
+  if (slab) { op->gp[0] = op->V[0] + nd; op->pL = op->xL + nd; }
   hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
   // Lagrange weights of the interior nodes x_1..x_{P-2} at x_0 and x_{P-1} (the polyInterp functional)
   op->w0.assign(d, nullptr); op->w1.assign(d, nullptr);
@@ -990,6 +1001,16 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
 #undef OPRC
   *out = op;
   return 0;
+}
+
+// Diagnostic (tools/placement_probe.py; not in the header): device addresses of the work arrays in request order
+extern "C" int chebhip_debug_stokes_arrays(stokes_op *op, int cap, unsigned long long *addr) {
+  if (!op || !addr) return -1;
+  double *all[] = {op->xL, op->yL, op->xF, op->yLx[1], op->yLx[2], op->V[0], op->strain[0], op->gp[0], op->V[1], op->strain[1], op->gp[1],
+                   op->V[2], op->strain[2], op->gp[2], op->eta, op->deta, op->T, op->pL, op->p2};
+  int n = 0;
+  for (double *p : all) if (n < cap) addr[n++] = (unsigned long long)(uintptr_t)p;
+  return n;
 }
 
 extern "C" int stokes_op_create(int d, const int *dims, stokes_op **out) { return st_create(d, dims, 0, 0, nullptr, nullptr, out); }

@@ -219,7 +219,7 @@ def _serial_state(sp, dims, x, dv, force, rheology):
 
 
 @pytest.mark.parametrize("G,dims", [(2, (10, 9, 8)), (3, (13, 12)), (3, (4, 6)), (4, (18, 17, 9)), (6, (11, 15, 25)), (5, (24, 20, 70)),
-                                    (3, (24, 70)), (2, (40, 130)), (3, (12, 10, 100))], ids=str)
+                                    (3, (24, 70)), (2, (40, 130)), (3, (12, 10, 100)), (4, (8, 5, 6))], ids=str)
 def test_velocity_preconditioner_on_slabs(G, dims):
     """chebhip_dist_stokes_pc: z = P_1^-1 (r / eta) (MatVVPC's approximate solve, stokes.C:1160-1241 by fast diagonalisation) on the
     velocity unknowns of every slab, with a power-law viscosity, against the serial handle's.  (3, (4, 6)) and (6, (11, 15, 25)):
@@ -255,12 +255,13 @@ def test_velocity_preconditioner_on_slabs(G, dims):
     assert relerr(z, zs.cpu().numpy()) < 1e-12
 
 
-@pytest.mark.parametrize("G,dims", [(3, (24, 70)), (2, (40, 130)), (4, (18, 17, 9)), (3, (5, 29)), (6, (5, 7, 6)), (3, (12, 10, 100)), (2, (13, 12))], ids=str)
+@pytest.mark.parametrize("G,dims", [(3, (24, 70)), (2, (40, 130)), (4, (18, 17, 9)), (3, (5, 29)), (4, (5, 7, 6)), (4, (8, 5, 6)), (3, (12, 10, 100)), (2, (13, 12))], ids=str)
 def test_elliptic_preconditioner_on_slabs(G, dims):
     """chebhip_dist_ell_pc (FormJacobian's matrix, elliptic.C:537-590, solved by fast diagonalisation on slabs): z = P_1^-1 (r / eta)
     with the variable eta a FormFunction (gamma = 4) leaves, against the serial handle's FdPc(sweeps = 0).  2-D and 3-D, last dimensions
-    that take the one-launch z solve (68, 128 and 98 interior points), (3, (5, 29)) and (6, (5, 7, 6)): ranks without interior planes
-    (SlabX::setup_interior with dims[0] - 2 < G) that still take part in the exchanges."""
+    that take the one-launch z solve (68, 128 and 98 interior points), (3, (5, 29)) and (4, (5, 7, 6)): ranks without interior planes
+    (SlabX::setup_interior with dims[0] - 2 < G) that still take part in the exchanges; (4, (8, 5, 6)): dims[1] - 2 < G, a rank
+    without pencil columns."""
     sp = ge.load(); dsp = ge.load_dist()
     n, g, nd = orc.sizes(dims)
     rng = np.random.default_rng(SEED)
