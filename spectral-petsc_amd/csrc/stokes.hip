@@ -871,6 +871,7 @@ extern "C" int stokes_op_destroy(stokes_op *op) {
   return 0;
 }
 
+static bool st_zfused_ok(stokes_op *op);
 // boundary node of the GLOBAL grid?  ind: local multi-index (dimension 0 is offset by op->lo in slab mode)
 static inline bool st_is_bdy(const stokes_op *op, const int *ind) {
   const int g0 = ind[0] + op->lo;
@@ -990,7 +991,11 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     // The pressure chain on a second stream pays on large grids (128^3 StokesMatMult 298 against 325 us, 120^3 260 against
     // 275); below about 100^3 the fork / join events cost more than the overlap gives (64^3: 70.5 against 66.5 us, and
     // 62 us with the one-launch gradients of the one-stream path; 96^3 .. 112^3: a tie), so smaller grids stay on one stream.
-    if (!opt(OPT_STOKES_SINGLE_STREAM) && !slab && N >= 1200000) {         // "stokes_single_stream": read when the handle is created
+    // Round 5: where the fused-z route runs (st_zfused_ok) the pressure-gradient sweeps are jobs of its first launch instead, and
+    // the second stream is only made with option "stokes_pressure_stream" = 1 (A/B)
+    op->N = N;
+    const bool z1 = st_zfused_ok(op) && !opt(OPT_STOKES_PRESSURE_STREAM);
+    if (!opt(OPT_STOKES_SINGLE_STREAM) && !slab && N >= 1200000 && !z1) {         // "stokes_single_stream": read when the handle is created
       OPCHK(hipStreamCreateWithFlags(&op->aux, hipStreamNonBlocking));
       OPCHK(hipEventCreateWithFlags(&op->ev_fork, hipEventDisableTiming));
       OPCHK(hipEventCreateWithFlags(&op->ev_join, hipEventDisableTiming));
@@ -1081,6 +1086,12 @@ extern "C" int stokes_op_set_force(stokes_op *op, const double *force) {
 }
 
 // ---- building blocks ------------------------------------------------------------------------
+// Diagnostic (tools/stokes_ablate.py; not in the header): launches of the 128^3 callbacks left out one at a time -- results are wrong,
+// the timings give each launch's MARGINAL cost in the pipelined callback (a profiler serialises the launches and both streams).
+// bit 0 gather, 1 x/y gradient, 2 fused z launch, 3 x/y divergence, 4 scatter, 5 pressure chain
+static int g_st_ablate = 0;
+extern "C" void chebhip_debug_stokes_ablate(int mask) { g_st_ablate = mask; }
+#define ST_ABL(bit) (g_st_ablate & (1 << (bit)))
 // DP[k] (scalar field) or DV[k] (d stacked fields: same lines, d times as many)
 static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *y, int out_mode, const double *acc,
                        double alpha, hipStream_t st, bool pext = false) {       // pext: the pressure matrices (stokes_op::matsP)
@@ -1332,16 +1343,41 @@ static int st_zfused_launch(stokes_op *op, int mode, ZfParams zp, hipStream_t st
   SHIPCHK(hipGetLastError());
   return 0;
 }
-static int st_viscous_jacobian_zfused(stokes_op *op, double *div, hipStream_t st) {
-  const double *x[3] = {op->xL, op->xL, op->xL};
-  int rc = sweeps_multi(op, true, 0, x, op->V, 1.0, st, false, false, 2); if (rc) return rc;            // V[0] = D_x xL, V[1] = D_y xL
+// The x / y gradient of the fused-z route, out[0] = D_x xL, out[1] = D_y xL (3 fields each), and -- with_pressure -- the three
+// pressure-gradient sweeps gp[i] = DP[i] pL as jobs of the SAME launch: five independent plain sweeps of the two local vectors.
+// (The pressure chain on a second stream, rounds 2-4, costs the callback 32 us for 100 MB: tools/stokes_ablate.py,
+// profiles/r05_stokes_ablate.txt -- fork, join and a launch that competes with the viscous chain for the memory system rather
+// than filling idle CUs.)  Option "stokes_pressure_stream" = 1 (read when the handle is created) keeps the second stream (A/B).
+static int st_xy_gradient(stokes_op *op, double *const *out, bool with_pressure, hipStream_t st) {
+  const int d = op->d;
+  const DiffMat *m[5]; SweepParams sp[5];
+  int n = 0;
+  for (int k = 0; k < 2; k++, n++) {
+    sp[n] = SweepParams{};
+    sp[n].ncols = op->ncolsV[k]; sp[n].inner = op->innerP[k];
+    sp[n].in0 = op->xL; sp[n].in_mode = IN_PLAIN; sp[n].out = out[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = 1.0;
+    m[n] = &op->mats[op->dims[k]];
+  }
+  if (with_pressure)
+    for (int k = 0; k < d; k++, n++) {
+      sp[n] = SweepParams{};
+      sp[n].ncols = op->ncolsP[k]; sp[n].inner = op->innerP[k];
+      sp[n].in0 = op->pL; sp[n].in_mode = IN_PLAIN; sp[n].out = op->gp[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = 1.0;
+      m[n] = op->pext ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
+    }
+  SHIPCHK(sweep_launch_multi(n, m, sp, st));
+  return 0;
+}
+static int st_viscous_jacobian_zfused(stokes_op *op, double *div, hipStream_t st, bool with_pressure = false) {
+  int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->V, with_pressure, st); if (rc) return rc;            // V[0] = D_x xL, V[1] = D_y xL (+ gp[])
   ZfParams zp = {};
   zp.xL = op->xL; zp.Vx = op->V[0]; zp.Vy = op->V[1];
   zp.S0 = op->strain[0]; zp.S1 = op->strain[1]; zp.S2 = op->strain[2]; zp.eta = op->eta; zp.deta = op->deta;
   zp.div = div;
-  if ((rc = st_zfused_launch(op, op->deta_nonzero ? 1 : 0, zp, st))) return rc;
+  if (!ST_ABL(2) && (rc = st_zfused_launch(op, op->deta_nonzero ? 1 : 0, zp, st))) return rc;
   double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
   const double *t[3] = {op->V[0], op->V[1], op->V[2]};
+  if (ST_ABL(3)) return 0;
   return sweeps_multi(op, true, 0, t, y, -1.0, st, false, false, 2);                                     // yL = -D_x tau_x., yLx[1] = -D_y tau_y.
 }
 static int st_viscous_jacobian(stokes_op *op, double *div, hipStream_t st, bool have_gradient = false) {
@@ -1546,7 +1582,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   const int d = op->d;
   // scatterGV + scatterVL (zero boundary) and scatterGP (:505-510) in one pass over xG; the same xL serves
   // MatVV (:508) and MatPV (:509), whose result is the trace written by the node loop
-  st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
+  if (!ST_ABL(0)) st_local(op, d + 1, d, xG, nullptr, op->xL, op->pL, st);
   int rc;
   if (st_uniform(op)) {
     bool split = false;
@@ -1559,16 +1595,19 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   if (op->slab) {
     if ((rc = st_gradient_and_pressure_gradient_slab(op, op->V, st))) return rc;                                                 // MatVP (:512) + :639
     if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
+  } else if (!op->aux && st_zfused_ok(op)) {                  // the fused-z route with the pressure-gradient sweeps inside its first launch
+    if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
+    if ((rc = st_viscous_jacobian_zfused(op, op->p2, st, !ST_ABL(5)))) return rc;                                                // MatVP (:512) + MatVV
   } else if (st_one_launch_gradients(op)) {
     if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     if ((rc = st_gradient_and_pressure_gradient(op, op->V, st))) return rc;                                                      // MatVP (:512) + :639
     if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
   } else {
-    if ((rc = st_pressure_gradient_forked(op, st))) return rc;                                                                   // MatVP (:512)
+    if (!ST_ABL(5) && (rc = st_pressure_gradient_forked(op, st))) return rc;                                                     // MatVP (:512)
     if ((rc = st_viscous_jacobian(op, op->p2, st))) return rc;
   }
-  if ((rc = st_join(op, st))) return rc;
-  st_out_full(op, nullptr, yG, st);
+  if (!ST_ABL(5) && (rc = st_join(op, st))) return rc;
+  if (!ST_ABL(4)) st_out_full(op, nullptr, yG, st);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -1596,25 +1635,25 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   }
   op->strain_stale = false;                               // the node loop below leaves the strain as state
   // xL = velocity with Dirichlet values (stokes.C:691-699); it also feeds StokesDivergence(withDirichlet) (:746)
-  st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
-  if (!op->slab && !st_one_launch_gradients(op) && op->sym && st_zfused_ok(op)) {
+  if (!ST_ABL(0)) st_local(op, d + 1, d, xG, op->dirloc, op->xL, op->pL, st);
+  if (!op->slab && op->sym && st_zfused_ok(op)) {
     // the z direction in one launch (k_st_zfused16, MODE 2): gradient along x, y -> strain[0], strain[1]; the fused launch leaves eta,
     // eta', the symmetrised strain (upper triangle) and the stress slots the x / y divergence reads, and returns -D_z tau_z. in yLx[2]
-    { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                                                         // :747
-    const double *x[3] = {op->xL, op->xL, op->xL};
-    int rc = sweeps_multi(op, true, 0, x, op->strain, 1.0, st, false, false, 2); if (rc) return rc;                              // :701 (x, y)
+    if (op->aux && !ST_ABL(5)) { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                             // :747 (second stream: A/B)
+    if (!op->aux && !op->pext) st_pressure_extrapolate(op, op->pL, st);
+    int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->strain, !op->aux && !ST_ABL(5), st); if (rc) return rc;                      // :701 (x, y), :747
     ZfParams zp = {};
     zp.xL = op->xL; zp.Vx = op->strain[0]; zp.Vy = op->strain[1]; zp.Sz = op->strain[2];
     zp.eta_w = op->eta; zp.deta_w = op->deta; zp.T = op->T; zp.div = op->p2;
     zp.kind = op->rh_kind; zp.hardness = op->rh_hard; zp.expo = op->rh_expo; zp.eps = op->rh_eps; zp.gamma0 = op->rh_g0;
-    if ((rc = st_zfused_launch(op, 2, zp, st))) return rc;
+    if (!ST_ABL(2) && (rc = st_zfused_launch(op, 2, zp, st))) return rc;
     op->deta_nonzero = (op->rh_kind == 1);
     op->eta_uniform = (op->rh_kind == 0); op->eta_value = 1.0;
     double *y[3] = {op->yL, op->yLx[1], op->yLx[2]};
     const double *t[3] = {op->T, op->T + op->N, op->T + 2 * op->N};
-    if ((rc = sweeps_multi(op, true, 0, t, y, -1.0, st, true, false, 2))) return rc;                                             // :737-740 (x, y)
-    if ((rc = st_join(op, st))) return rc;
-    st_out_full(op, op->force, yG, st);                                                                                            // :750-756
+    if (!ST_ABL(3) && (rc = sweeps_multi(op, true, 0, t, y, -1.0, st, true, false, 2))) return rc;                               // :737-740 (x, y)
+    if (!ST_ABL(5) && (rc = st_join(op, st))) return rc;
+    if (!ST_ABL(4)) st_out_full(op, op->force, yG, st);                                                                            // :750-756
     SHIPCHK(hipGetLastError());
     return 0;
   }
