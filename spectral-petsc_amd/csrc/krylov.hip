@@ -8,8 +8,13 @@
 //   w = A M v_j;  h = V^T w (classical Gram-Schmidt, one pass -- PETSc's default orthogonalisation);
 //   w -= V h;  h_{j+1,j} = |w|;  Givens rotations and the triangular solve on the device (one thread).
 // Reductions are two-stage with a fixed block order: results do not depend on scheduling.
+// Round 5: ONE reduction per Gram-Schmidt step (k_gs_dots / k_gs_update below): w.w is taken in the same pass as V^T w and
+// w.w - |h|^2 ~ h_{j+1,j}^2 supplies the scale of the new vector, so that the update and the normalisation are one pass over the
+// basis and the step is two launches instead of three; the stored vector's exact norm comes out of that pass and is carried beside
+// it (gs_coefficients), so nothing rests on the cancelling difference.  Option "krylov_exact_norm" = 1: the three-launch step.
 #include "../../include/chebhip.h"
 #include "timers.h"
+#include "sweep.h"
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <new>
@@ -195,6 +200,196 @@ __global__ __launch_bounds__(RT) void k_givens_scale(int j, int m, const double 
   res[j] = fabs(g1[j + 1]);
 }
 
+// ---- Gram-Schmidt step with one reduction (round 5) -------------------------------------------------------------------------------
+// The Givens part of a step: column j of H (entries hcol[0..j] and hnext below the diagonal), the previous rotations, the new one, the
+// rotated right-hand side G_{j+1} (a fresh copy: iterations issued speculatively beyond the converged one must not disturb what the
+// solve reads), the residual estimate for the host (pinned memory).
+__device__ void givens_column(int j, int m, const double *hcol, double hnext, double *H, double *cs, double *sn, double *G, double *res) {
+  double *hc = H + (long)j * (m + 1);
+  for (int i = 0; i <= j; i++) hc[i] = hcol[i];
+  hc[j + 1] = hnext;
+  for (int i = 0; i < j; i++) {
+    const double t = cs[i] * hc[i] + sn[i] * hc[i + 1];
+    hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1]; hc[i] = t;
+  }
+  const double den = hypot(hc[j], hc[j + 1]);
+  const double *g0 = G + (long)j * (m + 2);
+  double *g1 = G + (long)(j + 1) * (m + 2);
+  for (int i = 0; i < j; i++) g1[i] = g0[i];
+  if (den == 0.0 || !(den == den)) { res[j] = nan(""); return; }
+  const double c = hc[j] / den, s_ = hc[j + 1] / den;
+  cs[j] = c; sn[j] = s_;
+  hc[j] = den; hc[j + 1] = 0.0;
+  g1[j] = c * g0[j]; g1[j + 1] = -s_ * g0[j];
+  res[j] = fabs(g1[j + 1]);
+}
+// One pass gives d[kk] = V[kk].w and w.w.  The stored basis vectors are only APPROXIMATELY normalised: V[kk] has the exactly known norm
+// rn[kk] (rn[0] = 1), the orthonormal basis of the method is V[kk] / rn[kk].  So
+//   h[kk] = d[kk] / rn[kk]                 (column j of H),        c[kk] = h[kk] / rn[kk]   (w - sum c[kk] V[kk] is the new direction),
+//   e2 = w.w - |h|^2 ~ h_{j+1,j}^2         (exact for an orthonormal basis; in floating point it loses the digits by which it is smaller than w.w)
+// and e2 is used for ONE thing: the factor f = 1 / sqrt(e2) by which the update pass scales the new vector so that its norm is about 1.  The
+// update pass then sums the squares of what it stores: rn[j+1] exactly, and h_{j+1,j} = rn[j+1] / f exactly -- a cancelled e2 costs nothing
+// but a basis vector whose stored norm is not close to 1 (any positive f gives the same orthonormal direction).  scal[1] = f.
+__device__ void gs_coefficients(int k, double *hcol, double *coef, const double *rn, double *scal) {
+  const double ww = hcol[k];
+  double ssq = 0.0;
+  for (int i = 0; i < k; i++) { const double h = hcol[i] / rn[i]; hcol[i] = h; coef[i] = h / rn[i]; ssq += h * h; }
+  double e2 = ww - ssq;
+  if (!(e2 >= 1.0e-12 * ww)) e2 = 1.0e-12 * ww;            // cancelled (or negative): any scale of the right order will do
+  scal[0] = ww;
+  scal[1] = (e2 > 0.0 && e2 <= 1.7976931348623157e308) ? 1.0 / sqrt(e2) : 0.0;      // w = 0 (breakdown) or NaN: scale by 0 as before
+}
+// ... and after the update pass: rn[j+1] and h_{j+1,j} from the squares of the stored vector (nsq), then the Givens step.
+// est != 0: no update pass was run (the last iteration of a truncated solve: its vector is not used) -- h_{j+1,j} is the estimate sqrt(e2).
+__device__ void gs_norm_and_givens(int j, int m, const double *hcol, const double *scal, double nsq, int est, double *rn,
+                                   double *H, double *cs, double *sn, double *G, double *res) {
+  const double f = scal[1];
+  double hn;
+  if (est) hn = f > 0.0 ? 1.0 / f : (scal[0] == 0.0 ? 0.0 : nan(""));
+  else {
+    const double r = sqrt(nsq);
+    rn[j + 1] = (r > 0.0 && r <= 1.7976931348623157e308) ? r : 1.0;
+    hn = f > 0.0 ? r / f : (scal[0] == 0.0 ? 0.0 : nan(""));
+  }
+  givens_column(j, m, hcol, hn, H, cs, sn, G, res);
+}
+// The LAST block to arrive (device-scope ticket: no block ever waits for another) sums the 256 partials of `rows` rows in a fixed order
+// (wave q of 16 takes rows q, q + 16, ..; a lane adds its four partials in order, then the wave tree) into out[0..rows-1].
+// Every partial was written before its writer's ticket, and every ticket before this block's.
+__device__ __forceinline__ bool gs_last_block(int *ticket, int nblocks, int *sh_last) {
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);                    // this thread's agent-scope stores of its partials have been acknowledged
+    *sh_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
+  }
+  __syncthreads();
+  return *sh_last != 0;
+}
+__device__ __forceinline__ void gs_row_sums(double *part, int rows, double *out) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto ld = [&](long i) { return __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  for (int r = wv; r < rows; r += ST / 64) {
+    double a = ld((long)r * RB + lane);
+    a += ld((long)r * RB + 64 + lane); a += ld((long)r * RB + 128 + lane); a += ld((long)r * RB + 192 + lane);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if (lane == 0) out[r] = a;
+  }
+  __syncthreads();
+}
+// part[row][b] = sum over chunk b of V[row][i] * w[i] for row < k, and of w[i]^2 for row == k (the row after the basis rows); the last
+// block leaves the sums in hcol[0..k]; with `finish` (one rank: nothing left to reduce) it goes on to gs_coefficients, and with
+// finish == 2 (no update pass will follow) to the Givens step with the estimated h_{j+1,j}.
+template <bool V2>
+__global__ __launch_bounds__(ST) void k_gs_dots(long n, int k, const double *__restrict__ V, long ldv, const double *__restrict__ w,
+                                                double *part, int *ticket, double *hcol, double *coef, double *rn, int finish,
+                                                int j, int m, double *scal, double *H, double *cs, double *sn, double *G, double *res) {
+  __shared__ double sh[ST / 64];
+  __shared__ int last;
+  const int kk0 = blockIdx.y * KB, rows = k + 1;
+  const int cnt = rows - kk0 < KB ? rows - kk0 : KB;
+  const double *v[KB];
+#pragma unroll
+  for (int q = 0; q < KB; q++) { const int r = kk0 + (q < cnt ? q : 0); v[q] = r < k ? V + (long)r * ldv : w; }
+  double s[KB];
+#pragma unroll
+  for (int q = 0; q < KB; q++) s[q] = 0.0;
+  if (V2) {
+    double t[KB];
+#pragma unroll
+    for (int q = 0; q < KB; q++) t[q] = 0.0;
+    const long n2 = n >> 1;
+    for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n2; i += (long)RB * ST) {
+      const double2 wi = ((const double2 *)w)[i];
+#pragma unroll
+      for (int q = 0; q < KB; q++) if (q < cnt) { const double2 a = ((const double2 *)v[q])[i]; s[q] += a.x * wi.x; t[q] += a.y * wi.y; }
+    }
+#pragma unroll
+    for (int q = 0; q < KB; q++) s[q] += t[q];
+  } else {
+    for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
+      const double wi = w[i];
+#pragma unroll
+      for (int q = 0; q < KB; q++) if (q < cnt) s[q] += v[q][i] * wi;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KB; q++) {
+    const double r = block_sum_t<ST>(s[q], sh);
+    if (threadIdx.x == 0 && q < cnt) __hip_atomic_store(part + (long)(kk0 + q) * RB + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!gs_last_block(ticket, (int)(gridDim.x * gridDim.y), &last)) return;
+  gs_row_sums(part, rows, hcol);
+  if (threadIdx.x == 0) {
+    *ticket = 0;
+    if (finish) {
+      gs_coefficients(k, hcol, coef, rn, scal);
+      if (finish == 2) gs_norm_and_givens(j, m, hcol, scal, 0.0, 1, rn, H, cs, sn, G, res);
+    }
+  }
+}
+// several ranks: hcol[0..k] / nsq have been summed over the ranks by the reduction callback
+__global__ void k_gs_coefficients(int k, double *hcol, double *coef, const double *rn, double *scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) gs_coefficients(k, hcol, coef, rn, scal);
+}
+__global__ void k_gs_givens(int j, int m, const double *hcol, const double *scal, const double *nsq, int est, double *rn,
+                            double *H, double *cs, double *sn, double *G, double *res) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) gs_norm_and_givens(j, m, hcol, scal, nsq ? nsq[0] : 0.0, est, rn, H, cs, sn, G, res);
+}
+// w = (w - sum_{kk<k} c[kk] V[kk]) * f: the update and the (approximate) normalisation in one pass, the subtractions in row order;
+// npart[b] = the squares of what block b stored; the last block sums them (fixed order) and, with `finish`, runs the Givens step;
+// otherwise (several ranks) it leaves the local sum in nsq.
+template <bool V2>
+__global__ __launch_bounds__(ST) void k_gs_update(long n, int k, const double *__restrict__ V, long ldv, const double *__restrict__ coef,
+                                                  const double *scal, double *__restrict__ w, double *npart, int *ticket, double *nsq, int finish,
+                                                  int j, int m, const double *hcol, double *rn, double *H, double *cs, double *sn, double *G, double *res) {
+  __shared__ double h[ST];
+  __shared__ double sh[ST / 64];
+  __shared__ int last;
+  for (int kk = threadIdx.x; kk < k; kk += ST) h[kk] = coef[kk];
+  __syncthreads();
+  const double f = scal[1];
+  double s = 0.0;
+  if (V2) {
+    const long n2 = n >> 1;
+    double s2 = 0.0;
+    for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n2; i += (long)RB * ST) {
+      double2 x = ((const double2 *)w)[i];
+      int kk = 0;
+      for (; kk + 4 <= k; kk += 4) {
+        const double2 a0 = ((const double2 *)(V + (long)kk * ldv))[i], a1 = ((const double2 *)(V + (long)(kk + 1) * ldv))[i],
+                      a2 = ((const double2 *)(V + (long)(kk + 2) * ldv))[i], a3 = ((const double2 *)(V + (long)(kk + 3) * ldv))[i];
+        x.x -= h[kk] * a0.x; x.y -= h[kk] * a0.y; x.x -= h[kk + 1] * a1.x; x.y -= h[kk + 1] * a1.y;
+        x.x -= h[kk + 2] * a2.x; x.y -= h[kk + 2] * a2.y; x.x -= h[kk + 3] * a3.x; x.y -= h[kk + 3] * a3.y;
+      }
+      for (; kk < k; kk++) { const double2 a = ((const double2 *)(V + (long)kk * ldv))[i]; x.x -= h[kk] * a.x; x.y -= h[kk] * a.y; }
+      x.x *= f; x.y *= f;
+      ((double2 *)w)[i] = x;
+      s += x.x * x.x; s2 += x.y * x.y;
+    }
+    s += s2;
+  } else {
+    for (long i = blockIdx.x * (long)ST + threadIdx.x; i < n; i += (long)RB * ST) {
+      double x = w[i];
+      int kk = 0;
+      for (; kk + 4 <= k; kk += 4) {
+        const double a0 = V[(long)kk * ldv + i], a1 = V[(long)(kk + 1) * ldv + i], a2 = V[(long)(kk + 2) * ldv + i], a3 = V[(long)(kk + 3) * ldv + i];
+        x -= h[kk] * a0; x -= h[kk + 1] * a1; x -= h[kk + 2] * a2; x -= h[kk + 3] * a3;
+      }
+      for (; kk < k; kk++) x -= h[kk] * V[(long)kk * ldv + i];
+      x *= f;
+      w[i] = x;
+      s += x * x;
+    }
+  }
+  const double r = block_sum_t<ST>(s, sh);
+  if (threadIdx.x == 0) __hip_atomic_store(npart + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!gs_last_block(ticket, (int)gridDim.x, &last)) return;
+  gs_row_sums(npart, 1, nsq);
+  if (threadIdx.x == 0) {
+    *ticket = 0;
+    if (finish) gs_norm_and_givens(j, m, hcol, scal, nsq[0], 0, rn, H, cs, sn, G, res);
+  }
+}
+
 // y = R^{-1} g for the leading kk columns (R upper triangular, column-major with leading dimension m + 1)
 __global__ void k_trisolve(int kk, int m, const double *__restrict__ H, const double *__restrict__ g, double *__restrict__ y) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -243,14 +438,19 @@ struct chebhip_fgmres {
   chebhip_reduce_fn reduce = nullptr;   // several ranks: sums device doubles over the ranks, in place, stream-ordered
   void *reduce_ctx = nullptr;
   double *nsq = nullptr;                // device scalar for the reduced |w|^2
+  int *ticket = nullptr;                // k_gs_dots: blocks that have delivered their partial sums
+  double *scal = nullptr;               // k_gs_dots -> k_gs_update: h_{j+1,j} and its reciprocal
+  double *coef = nullptr, *rn = nullptr; // k_gs_dots -> k_gs_update: update coefficients; exact norms of the stored basis vectors
+  bool exact = false;                   // option "krylov_exact_norm": the three-launch step with the explicit norm
   int its = 0, reason = 0;
   double rnorm = 0.0, rnorm0 = 0.0;
 };
 
 extern "C" int chebhip_fgmres_destroy(chebhip_fgmres *k) {
   if (!k) return 0;
-  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->nsq};
+  double *dev[] = {k->V, k->Z, k->part, k->npart, k->hcol, k->ydev, k->H, k->cs, k->sn, k->G, k->nsq, k->scal, k->coef, k->rn};
   for (double *p : dev) if (p) (void)hipFree(p);
+  if (k->ticket) (void)hipFree(k->ticket);
   if (k->res) (void)hipHostFree(k->res);
   for (hipEvent_t e : k->ev) (void)hipEventDestroy(e);
   delete k;
@@ -273,9 +473,14 @@ extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) 
     return chebhip_fail(e_ == hipErrorOutOfMemory ? CHEBHIP_ERR_MEMORY : CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
   KC(hipMalloc((void **)&k->V, (size_t)(m + 1) * k->ld * sizeof(double)));
   KC(hipMalloc((void **)&k->Z, (size_t)m * k->ld * sizeof(double)));
-  KC(hipMalloc((void **)&k->part, (size_t)(m + 1) * RB * sizeof(double)));
+  KC(hipMalloc((void **)&k->part, (size_t)(m + 2) * RB * sizeof(double)));
+  KC(hipMalloc((void **)&k->ticket, sizeof(int)));
+  KC(hipMemset(k->ticket, 0, sizeof(int)));
+  KC(hipMalloc((void **)&k->scal, 4 * sizeof(double)));
+  KC(hipMalloc((void **)&k->coef, (size_t)(m + 3) * sizeof(double)));
+  KC(hipMalloc((void **)&k->rn, (size_t)(m + 3) * sizeof(double)));
   KC(hipMalloc((void **)&k->npart, (size_t)RB * sizeof(double)));
-  KC(hipMalloc((void **)&k->hcol, (size_t)(m + 2) * sizeof(double)));
+  KC(hipMalloc((void **)&k->hcol, (size_t)(m + 3) * sizeof(double)));
   KC(hipMalloc((void **)&k->ydev, (size_t)(m + 2) * sizeof(double)));
   KC(hipMalloc((void **)&k->H, (size_t)m * (m + 1) * sizeof(double)));
   KC(hipMalloc((void **)&k->cs, (size_t)m * sizeof(double)));
@@ -333,6 +538,7 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
   const long n = k->n, ld = k->ld;
   const int m = k->m;
   k->its = 0; k->reason = 0;
+  k->exact = chebhip::opt(chebhip::OPT_KRYLOV_EXACT_NORM) != 0;
   double bnorm = 0.0;
   int rc = dev_norm(k, b, st, &bnorm); if (rc) return rc;
   const double tol = std::fmax(k->rtol * bnorm, k->atol);
@@ -364,6 +570,7 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
     if (k->its >= k->max_it) { k->reason = -3; return clear_x(); }              // KSP_DIVERGED_ITS
     hipLaunchKernelGGL(k_scale, dim3(pgrid(n)), dim3(256), 0, st, n, 1.0 / beta, rsrc, k->V);
     hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, k->G, beta);
+    hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, k->rn, 1.0);          // V[0] is normalised exactly
 
     // One cycle.  Iteration j is enqueued BEFORE the host looks at the result of iteration j - 1: the device
     // never waits for the host.  If j - 1 turns out to have converged, iteration j was speculative; it only
@@ -388,6 +595,38 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       const int use_next = (j + 1 < m && k->its + j + 1 < k->max_it) ? 1 : 0;
       const unsigned gsgrid = use_next ? pgrid(n) : 1u;
       if ((rc = A(actx, zj, w, st))) return rc;
+      if (!k->exact) {
+        // V^T w and w.w in one pass; the update and the normalisation in one pass (see gs_coefficients)
+        const int single = k->reduce ? 0 : 1;
+        const dim3 dg(RB, (j + 1 + KB) / KB);
+        const int fin = single ? (use_next ? 1 : 2) : 0;
+        if ((n & 1) == 0) hipLaunchKernelGGL((k_gs_dots<true>), dg, dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part, k->ticket, k->hcol, k->coef, k->rn, fin,
+                                             j, m, k->scal, k->H, k->cs, k->sn, k->G, k->res);
+        else hipLaunchKernelGGL((k_gs_dots<false>), dg, dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part, k->ticket, k->hcol, k->coef, k->rn, fin,
+                                j, m, k->scal, k->H, k->cs, k->sn, k->G, k->res);
+        if (!single) {
+          if ((rc = k->reduce(k->reduce_ctx, k->hcol, j + 2, st))) return rc;
+          hipLaunchKernelGGL(k_gs_coefficients, dim3(1), dim3(1), 0, st, j + 1, k->hcol, k->coef, (const double *)k->rn, k->scal);
+          if (!use_next) hipLaunchKernelGGL(k_gs_givens, dim3(1), dim3(1), 0, st, j, m, (const double *)k->hcol, (const double *)k->scal, (const double *)nullptr, 1, k->rn,
+                                            k->H, k->cs, k->sn, k->G, k->res);
+        }
+        if (use_next) {             // (the last iteration of a truncated solve needs h_{j+1,j} only: no pass over the basis at all)
+          if ((n & 1) == 0) hipLaunchKernelGGL((k_gs_update<true>), dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->coef, (const double *)k->scal, w,
+                                               k->npart, k->ticket, k->nsq, single, j, m, (const double *)k->hcol, k->rn, k->H, k->cs, k->sn, k->G, k->res);
+          else hipLaunchKernelGGL((k_gs_update<false>), dim3(RB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)k->coef, (const double *)k->scal, w,
+                                  k->npart, k->ticket, k->nsq, single, j, m, (const double *)k->hcol, k->rn, k->H, k->cs, k->sn, k->G, k->res);
+          if (!single) {
+            if ((rc = k->reduce(k->reduce_ctx, k->nsq, 1, st))) return rc;
+            hipLaunchKernelGGL(k_gs_givens, dim3(1), dim3(1), 0, st, j, m, (const double *)k->hcol, (const double *)k->scal, (const double *)k->nsq, 0, k->rn,
+                               k->H, k->cs, k->sn, k->G, k->res);
+          }
+        }
+        KHIPCHK(hipGetLastError());
+        KHIPCHK(hipEventRecord(k->ev[j], st));
+        enq = j + 1;
+        if (j >= 1) { KHIPCHK(hipEventSynchronize(k->ev[j - 1])); examine(j - 1); }
+        continue;
+      }
       if ((n & 1) == 0) hipLaunchKernelGGL((k_multidot_grouped<true>), dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       else hipLaunchKernelGGL((k_multidot_grouped<false>), dim3(RB, (j + KB) / KB), dim3(ST), 0, st, n, j + 1, (const double *)k->V, ld, (const double *)w, k->part);
       if (!k->reduce) {
