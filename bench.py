@@ -317,7 +317,21 @@ def dist_rank_compute(sp, dsp, torch, t1_us):
             t1s = t_us(lambda: D.mult(U, V))
         finally:
             sp.set_option("dist_single_stream", 0)
-        out["poisson_256"]["G%d" % G] = {"rank_us": t, "rank_us_single_stream": t1s, "bound_speedup": t1_us / min(t, t1s)}
+        rec = {"rank_us": t, "rank_us_single_stream": t1s, "bound_speedup": t1_us / min(t, t1s)}
+        # several vectors per exchange (chebhip_dist_mult_batch): rank time PER VECTOR at nrhs = 2, 4 -- one launch per direction on the
+        # stacked slabs / pencils, so the fixed cost of a launch of 256-point lines is shared
+        for nrhs in (2, 4):
+            Ub = torch.randn((nrhs, D.local_size), dtype=torch.float64, device="cuda"); Vb = torch.empty_like(Ub)
+            tb = t_us(lambda: D.mult_batch(Ub, Vb))
+            sp.set_option("dist_single_stream", 1)
+            try:
+                tb1 = t_us(lambda: D.mult_batch(Ub, Vb))
+            finally:
+                sp.set_option("dist_single_stream", 0)
+            rec["nrhs%d_rank_us_per_vector" % nrhs] = min(tb, tb1) / nrhs
+            del Ub, Vb
+        rec["bound_speedup_nrhs4"] = t1_us / rec["nrhs4_rank_us_per_vector"]
+        out["poisson_256"]["G%d" % G] = rec
         D.destroy(); comm.destroy(); del U, V
     ser = sp.StokesOp((128, 128, 128)); ser.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
     ser.set_dirichlet(np.zeros(ser.dirichlet_size)); ser.set_force(np.zeros(ser.global_size))

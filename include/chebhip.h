@@ -248,6 +248,12 @@ int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm);
 int chebhip_dist_set_exchange(chebhip_dist *D, chebhip_exchange_fn fn, void *ctx);
 /* MatMult_Elliptic (elliptic.C:297-339, eta = 1, deta = 0) on the slab: V = -(L_0 + L_1 + ..) U. */
 int chebhip_dist_mult(chebhip_dist *D, const double *U_slab_dev, double *V_slab_dev, void *stream);
+/* The same matvec on nrhs vectors at once (1..64; U, V: nrhs consecutive slab vectors of chebhip_dist_local_size doubles each): one
+ * launch per direction on the stacked slabs / pencils, one pack, ONE grouped exchange each way carrying every vector's blocks, one
+ * final sum -- the fixed cost of a launch of 256-point lines and of an RCCL launch is paid per batch, not per vector.  Each vector's
+ * result is chebhip_dist_mult's.  For the independent vectors of a block / s-step Krylov method or several right-hand sides; needs a
+ * chebhip_comm transport (chebhip_dist_use_comm / _use_rccl).  Collective.  The serial reference has no counterpart. */
+int chebhip_dist_mult_batch(chebhip_dist *D, int nrhs, const double *U_slabs_dev, double *V_slabs_dev, void *stream);
 /* For hosts without a communicator of their own: rank 0 makes the 128-byte id, the host hands it to every rank. */
 int chebhip_rccl_unique_id(void *id128);
 int chebhip_rccl_comm_create(int nranks, int rank, const void *id128, void **nccl_comm_out);

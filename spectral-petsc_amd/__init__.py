@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "chebhip_timers_enable", "chebhip_timers_reset", "chebhip_timers_read", "chebhip_stage_name",
     "stokes_op_viscosity_range", "stokes_op_write_vtk",
     "chebhip_dist_create", "chebhip_dist_destroy", "chebhip_dist_local_size", "chebhip_dist_slab_offset",
-    "chebhip_dist_use_rccl", "chebhip_dist_set_exchange", "chebhip_dist_mult",
+    "chebhip_dist_use_rccl", "chebhip_dist_set_exchange", "chebhip_dist_mult", "chebhip_dist_mult_batch",
     "chebhip_rccl_unique_id", "chebhip_rccl_comm_create", "chebhip_rccl_comm_destroy", "chebhip_rccl_reduce",
     "chebhip_comm_create_rccl", "chebhip_local_group_create", "chebhip_local_group_destroy", "chebhip_local_group_abort",
     "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_create_null", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
@@ -179,6 +179,7 @@ def lib():
         L.chebhip_dist_use_rccl.argtypes = [vp, vp]
         L.chebhip_dist_set_exchange.argtypes = [vp, vp, vp]
         L.chebhip_dist_mult.argtypes = [vp, vp, vp, vp]
+        L.chebhip_dist_mult_batch.argtypes = [vp, C.c_int, vp, vp, vp]
         L.chebhip_rccl_unique_id.argtypes = [vp]
         L.chebhip_rccl_comm_create.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
         L.chebhip_rccl_comm_destroy.argtypes = [vp]

@@ -32,6 +32,7 @@
 #include "sweep.h"
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -54,11 +55,12 @@ struct APtrs { const double *p[9]; int n; };
 // block needs no message) instead of the buffer.  V2: every run starts on a 16-byte boundary and has even length.
 template <bool V2>
 __global__ __launch_bounds__(256) void k_pack(Split sp, long m0, long M1, long R, const double *__restrict__ slab, double *__restrict__ buf,
-                                             int own, double *__restrict__ own_ptr) {
+                                             int own, double *__restrict__ own_ptr, long lq, long pq) {
   const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G;
   const long w = sp.c1[s + 1] - sp.c1[s], len = w * R;
-  const double *src = slab + (i0 * M1 + sp.c1[s]) * R;
-  double *dst = (s == own) ? own_ptr + i0 * len : buf + m0 * sp.c1[s] * R + i0 * len;
+  const long q = blockIdx.z;                                  // vector of a batch (chebhip_dist_mult_batch): slabs / buffers `lq` apart, pencils `pq`
+  const double *src = slab + q * lq + (i0 * M1 + sp.c1[s]) * R;
+  double *dst = (s == own) ? own_ptr + q * pq + i0 * len : buf + q * lq + m0 * sp.c1[s] * R + i0 * len;
   // gridDim.y workgroups share a run (at G = 2 a run is 32 k values: one workgroup per run left the chip three quarters idle)
   const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
   if (V2) { for (long t = t0; t < (len >> 1); t += T) ((double2 *)dst)[t] = ((const double2 *)src)[t]; }
@@ -67,10 +69,11 @@ __global__ __launch_bounds__(256) void k_pack(Split sp, long m0, long M1, long R
 // V = ((T + A_1) + A_2) + ...   T in exchange order: the serial accumulation order k = 0, 1, 2 (elliptic.C:331-334)
 template <bool V2>
 __global__ __launch_bounds__(256) void k_combine(Split sp, long m0, long M1, long R, const double *__restrict__ buf, int own,
-                                                const double *__restrict__ own_ptr, APtrs A, double *__restrict__ out) {
+                                                const double *__restrict__ own_ptr, APtrs A, double *__restrict__ out, long lq, long pq) {
   const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G;
-  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = (i0 * M1 + sp.c1[s]) * R;
-  const double *src = (s == own) ? own_ptr + i0 * len : buf + m0 * sp.c1[s] * R + i0 * len;
+  const long q = blockIdx.z;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = q * lq + (i0 * M1 + sp.c1[s]) * R;
+  const double *src = (s == own) ? own_ptr + q * pq + i0 * len : buf + q * lq + m0 * sp.c1[s] * R + i0 * len;
   const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
   if (V2) {
     for (long t = t0; t < (len >> 1); t += T) {
@@ -97,10 +100,17 @@ struct chebhip_dist {
   std::vector<long> m0, m1, s0, s1;           // plane / column counts and offsets per rank
   long local = 0, pencil = 0;
   std::vector<long> fwd_send, fwd_recv;       // doubles per peer (backward: roles swap)
-  std::vector<cheb_plan *> slab_plan;         // directions 1..d-1 on the slab
-  cheb_plan *pencil_plan = nullptr;           // direction 0 on the pencil
-  std::vector<double *> A;                    // d-1 local contributions
-  double *sendbuf = nullptr, *recvbuf = nullptr, *UT = nullptr, *TT = nullptr;
+  // plans and work arrays of a matvec on `nrhs` vectors at a time (w[1]: chebhip_dist_mult; w[n]: chebhip_dist_mult_batch, made on first
+  // use): the stacked slabs are one tensor (nrhs m0, M1, ..), the stacked pencils one tensor (nrhs, M0, m1, ..) -- ONE launch per
+  // direction and ONE grouped exchange each way for all the vectors
+  struct Work {
+    int nrhs = 1;
+    std::vector<cheb_plan *> slab_plan;       // directions 1..d-1 on the slab(s)
+    cheb_plan *pencil_plan = nullptr;         // direction 0 on the pencil(s)
+    std::vector<double *> A;                  // d-1 local contributions
+    double *sendbuf = nullptr, *recvbuf = nullptr, *UT = nullptr, *TT = nullptr;
+  };
+  std::map<int, Work *> w;
   hipStream_t side = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   chebhip_exchange_fn xfn = nullptr; void *xctx = nullptr;
@@ -111,16 +121,48 @@ struct chebhip_dist {
 
 extern "C" int chebhip_dist_destroy(chebhip_dist *D) {
   if (!D) return 0;
-  for (auto p : D->slab_plan) if (p) cheb_plan_destroy(p);
-  if (D->pencil_plan) cheb_plan_destroy(D->pencil_plan);
-  for (auto p : D->A) if (p) (void)hipFree(p);
-  double *all[] = {D->sendbuf, D->recvbuf, D->UT, D->TT};
-  for (double *p : all) if (p) (void)hipFree(p);
+  for (auto &kv : D->w) {
+    chebhip_dist::Work *W = kv.second;
+    for (auto p : W->slab_plan) if (p) cheb_plan_destroy(p);
+    if (W->pencil_plan) cheb_plan_destroy(W->pencil_plan);
+    for (auto p : W->A) if (p) (void)hipFree(p);
+    double *all[] = {W->sendbuf, W->recvbuf, W->UT, W->TT};
+    for (double *p : all) if (p) (void)hipFree(p);
+    delete W;
+  }
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->ev_in) (void)hipEventDestroy(D->ev_in);
   if (D->ev_out) (void)hipEventDestroy(D->ev_out);
   if (D->own_comm) chebhip_comm_destroy(D->own_comm);
   delete D;
+  return 0;
+}
+
+// the work set for `nrhs` vectors per call (made on first use)
+static int dist_work(chebhip_dist *D, int nrhs, chebhip_dist::Work **out) {
+  auto it = D->w.find(nrhs);
+  if (it != D->w.end()) { if (out) *out = it->second; return 0; }
+  chebhip_dist::Work *W = new (std::nothrow) chebhip_dist::Work;
+  if (!W) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  W->nrhs = nrhs;
+  D->w[nrhs] = W;                                  // (owned by the handle from here on: chebhip_dist_destroy frees what exists)
+  const int d = D->d, rank = D->rank;
+  if ((double)D->local * nrhs > 2.0e9 || (double)D->pencil * nrhs > 2.0e9) return chebhip_fail(CHEBHIP_ERR_DIMS, "batch of %d vectors: more than 2^31 values per rank", nrhs);
+  {  // plans on the stored (interior) tensors: slabs (nrhs m0, M1, M2..), pencils (nrhs, M0, m1, M2..)
+    std::vector<int> sd(d), pd(d + 1);
+    for (int k = 0; k < d; k++) { sd[k] = (int)D->M[k]; pd[k + 1] = (int)D->M[k]; }
+    sd[0] = (int)(D->m0[rank] * nrhs); pd[0] = nrhs; pd[2] = (int)D->m1[rank];
+    W->slab_plan.assign(d, nullptr);
+    for (int k = 1; k < d; k++) { int rc = cheb_plan_create_trimmed(d, k, sd.data(), &W->slab_plan[k]); if (rc) return rc; }
+    int rc = nrhs == 1 ? cheb_plan_create_trimmed(d, 0, pd.data() + 1, &W->pencil_plan) : cheb_plan_create_trimmed(d + 1, 1, pd.data(), &W->pencil_plan);
+    if (rc) return rc;
+  }
+  const size_t lb = (size_t)(D->local > 0 ? D->local : 1) * nrhs * sizeof(double), pb = (size_t)(D->pencil > 0 ? D->pencil : 1) * nrhs * sizeof(double);
+  W->A.assign(d - 1, nullptr);
+  for (int k = 0; k < d - 1; k++) DHIPCHK(hipMalloc((void **)&W->A[k], lb));
+  DHIPCHK(hipMalloc((void **)&W->sendbuf, lb)); DHIPCHK(hipMalloc((void **)&W->recvbuf, lb));
+  DHIPCHK(hipMalloc((void **)&W->UT, pb)); DHIPCHK(hipMalloc((void **)&W->TT, pb));
+  if (out) *out = W;
   return 0;
 }
 
@@ -147,27 +189,12 @@ extern "C" int chebhip_dist_create(int d, const int *dims, int nranks, int rank,
   D->fwd_send.resize(nranks); D->fwd_recv.resize(nranks);
   for (int s = 0; s < nranks; s++) { D->fwd_send[s] = D->m0[rank] * D->m1[s] * D->R; D->fwd_recv[s] = D->m0[s] * D->m1[rank] * D->R; }
   D->split.G = nranks; for (int s = 0; s <= nranks; s++) D->split.c1[s] = D->s1[s];
-  int rc = 0;
-#define DCHK(expr) do { rc = (expr); if (rc) { chebhip_dist_destroy(D); return rc; } } while (0)
 #define DHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { chebhip_dist_destroy(D); \
     return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-  {  // plans on the stored (interior) tensors: slab (m0, M1, M2..), pencil (M0, m1, M2..)
-    std::vector<int> sd(d), pd(d);
-    for (int k = 0; k < d; k++) { sd[k] = (int)D->M[k]; pd[k] = (int)D->M[k]; }
-    sd[0] = (int)D->m0[rank]; pd[1] = (int)D->m1[rank];
-    D->slab_plan.assign(d, nullptr);
-    for (int k = 1; k < d; k++) DCHK(cheb_plan_create_trimmed(d, k, sd.data(), &D->slab_plan[k]));
-    DCHK(cheb_plan_create_trimmed(d, 0, pd.data(), &D->pencil_plan));
-  }
-  const size_t lb = (size_t)(D->local > 0 ? D->local : 1) * sizeof(double), pb = (size_t)(D->pencil > 0 ? D->pencil : 1) * sizeof(double);
-  D->A.assign(d - 1, nullptr);
-  for (int k = 0; k < d - 1; k++) DHIP(hipMalloc((void **)&D->A[k], lb));
-  DHIP(hipMalloc((void **)&D->sendbuf, lb)); DHIP(hipMalloc((void **)&D->recvbuf, lb));
-  DHIP(hipMalloc((void **)&D->UT, pb)); DHIP(hipMalloc((void **)&D->TT, pb));
+  { int rc = dist_work(D, 1, nullptr); if (rc) { chebhip_dist_destroy(D); return rc; } }
   DHIP(hipStreamCreateWithFlags(&D->side, hipStreamNonBlocking));
   DHIP(hipEventCreateWithFlags(&D->ev_in, hipEventDisableTiming));
   DHIP(hipEventCreateWithFlags(&D->ev_out, hipEventDisableTiming));
-#undef DCHK
 #undef DHIP
   *out = D;
   return 0;
@@ -195,24 +222,27 @@ extern "C" int chebhip_dist_use_rccl(chebhip_dist *D, void *nccl_comm) {
   return chebhip_dist_use_comm(D, D->own_comm);
 }
 
-// send[s] (doubles, peer-major, contiguous) -> recv[s]: one grouped launch of the transport.  own >= 0: that rank's block is
-// not moved (the kernels on either side read / write it in place)
-static int exchange(chebhip_dist *D, const double *send, const long *sc, double *recv, const long *rc_, int own, hipStream_t st) {
-  if (D->xfn) return D->xfn(D->xctx, send, sc, recv, rc_, (void *)st);
+// send[s] (doubles, peer-major, contiguous) -> recv[s], for each of nrhs vectors (their buffers lq / pq doubles apart): ONE grouped
+// launch of the transport.  own >= 0: that rank's block is not moved (the kernels on either side read / write it in place)
+static int exchange(chebhip_dist *D, int nrhs, const double *send, long sq, const long *sc, double *recv, long rq, const long *rc_, int own, hipStream_t st) {
+  if (D->xfn) {
+    if (nrhs != 1) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist_mult_batch needs a chebhip_comm transport (chebhip_dist_use_comm / _use_rccl)");
+    return D->xfn(D->xctx, send, sc, recv, rc_, (void *)st);
+  }
   if (D->G > 1 && !D->comm) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist: no transport set (chebhip_dist_use_comm / _use_rccl / _set_exchange)");
   D->segs.clear();
-  long so = 0, ro = 0;
-  for (int s = 0; s < D->G; s++) { if (s != own) D->segs.push_back(XSeg{s, send + so, sc[s], recv + ro, rc_[s]}); so += sc[s]; ro += rc_[s]; }
+  for (int q = 0; q < nrhs; q++) {           // (the k-th segment for a peer meets that peer's k-th segment for this rank: both run q = 0, 1, ..)
+    long so = 0, ro = 0;
+    for (int s = 0; s < D->G; s++) { if (s != own) D->segs.push_back(XSeg{s, send + q * sq + so, sc[s], recv + q * rq + ro, rc_[s]}); so += sc[s]; ro += rc_[s]; }
+  }
   if (D->segs.empty()) return 0;
   return chebhip::comm_exchange(D->comm, D->segs.data(), (int)D->segs.size(), st);
 }
 
-extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, void *stream) {
-  if (!D || !U || !V) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
-  if (U == V) return chebhip_fail(CHEBHIP_ERR_ARG, "U and V must be distinct");
+static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, double *V, hipStream_t st) {
   const bool one_stream = chebhip::opt(chebhip::OPT_DIST_SINGLE_STREAM) != 0;     // "dist_single_stream": no overlap, no cross-stream dependencies
-  hipStream_t st = (hipStream_t)stream, side = one_stream ? st : D->side;
-  const int d = D->d, r = D->rank;
+  hipStream_t side = one_stream ? st : D->side;
+  const int d = D->d, r = D->rank, nrhs = W->nrhs;
   const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
   // side stream: the local directions, each into its own array (they overlap both exchanges); U is ready when the
   // caller's stream gets here
@@ -226,45 +256,66 @@ extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, vo
   // into arrays of their own, and the final sum reads them in the serial order -- at these sizes a launch costs its fixed 10-13 us
   // (matrix fetch, fill, drain), not its bytes, and the extra array sits in the Infinity Cache.  The one-GPU bits, as with the option.
   bool local_done = false;
-  if (d >= 3 && D->local > 0 && D->local < 6000000L && !chebhip::opt(chebhip::OPT_SEPARATE_LAUNCHES)) {
-    rc = chebhip::lap1d_multi_try(d - 1, D->slab_plan.data() + 1, U, D->A.data(), -1.0, side, &local_done);
+  if (d >= 3 && D->local > 0 && D->local * nrhs < 6000000L && !chebhip::opt(chebhip::OPT_SEPARATE_LAUNCHES)) {
+    rc = chebhip::lap1d_multi_try(d - 1, W->slab_plan.data() + 1, U, W->A.data(), -1.0, side, &local_done);
     if (local_done) exact = true;
   }
   for (int k = 1; k < d && !rc && !local_done; k++) {
-    if (exact || k == 1) rc = cheb_apply_lap1d(D->slab_plan[k], U, nullptr, -1.0, D->A[exact ? k - 1 : 0], side);
-    else rc = cheb_apply_lap1d(D->slab_plan[k], U, D->A[0], -1.0, D->A[0], side);
+    if (exact || k == 1) rc = cheb_apply_lap1d(W->slab_plan[k], U, nullptr, -1.0, W->A[exact ? k - 1 : 0], side);
+    else rc = cheb_apply_lap1d(W->slab_plan[k], U, W->A[0], -1.0, W->A[0], side);
   }
   hipError_t e1 = one_stream ? hipSuccess : hipEventRecord(D->ev_out, side);
   // caller's stream: the exchange chain.  With a chebhip_exchange_fn (the older callback contract moves every block, the
   // own one included) everything goes through the buffers; otherwise the own block bypasses them.
   const int own = (D->xfn || chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES)) ? -1 : r;     // (the option: one-rank smoke runs of the transport)
-  double *own_in = D->UT + D->s0[r] * D->m1[r] * R;          // where the own block sits in the pencil: rows s0[r] .. s0[r+1]
-  const double *own_out = D->TT + D->s0[r] * D->m1[r] * R;
+  double *own_in = W->UT + D->s0[r] * D->m1[r] * R;          // where the own block sits in the pencil: rows s0[r] .. s0[r+1]
+  const double *own_out = W->TT + D->s0[r] * D->m1[r] * R;
+  const long lq = D->local, pq = D->pencil;                  // vector q of a batch: slab-sized arrays lq apart, pencils pq apart
   // 16-byte accesses: every run (c1[s+1] - c1[s]) R long starting at (i0 M1 + c1[s]) R must be even-aligned
-  bool v2 = ((R & 1) == 0 || ((M1 & 1) == 0)) && (((size_t)U | (size_t)V) & 15) == 0;
+  bool v2 = ((R & 1) == 0 || ((M1 & 1) == 0)) && (((size_t)U | (size_t)V) & 15) == 0 && (nrhs == 1 || ((lq & 1) == 0 && (pq & 1) == 0));
   if (v2 && (R & 1)) for (int s = 0; s <= D->G; s++) v2 = v2 && (D->s1[s] & 1) == 0;
   const unsigned grid1 = (unsigned)(m0 * D->G);
   // workgroups per run: about 2048 values (1024 16-byte pieces) per workgroup pass, at most 64
   unsigned gy = 1;
   { long wmax = 0; for (int s = 0; s < D->G; s++) wmax = D->m1[s] > wmax ? D->m1[s] : wmax; const long len = wmax * R; gy = (unsigned)((len + 2047) / 2048); if (gy < 1) gy = 1; if (gy > 64) gy = 64; }
-  const dim3 grid(grid1, gy);
+  const dim3 grid(grid1, gy, (unsigned)nrhs);
   if (!rc && grid1) {
-    if (v2) hipLaunchKernelGGL((k_pack<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, D->sendbuf, own, own_in);
-    else hipLaunchKernelGGL((k_pack<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, D->sendbuf, own, own_in);
+    if (v2) hipLaunchKernelGGL((k_pack<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, W->sendbuf, own, own_in, lq, pq);
+    else hipLaunchKernelGGL((k_pack<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, W->sendbuf, own, own_in, lq, pq);
     if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pack launch failed");
   }
-  if (!rc) rc = exchange(D, D->sendbuf, D->fwd_send.data(), D->UT, D->fwd_recv.data(), own, st);          // lands as the pencil
-  if (!rc) rc = cheb_apply_lap1d(D->pencil_plan, D->UT, nullptr, -1.0, D->TT, st);                        // TT = -L_0 UT
-  if (!rc) rc = exchange(D, D->TT, D->fwd_recv.data(), D->recvbuf, D->fwd_send.data(), own, st);           // pencil rows -> slab blocks
+  if (!rc) rc = exchange(D, nrhs, W->sendbuf, lq, D->fwd_send.data(), W->UT, pq, D->fwd_recv.data(), own, st);          // lands as the pencil(s)
+  if (!rc) rc = cheb_apply_lap1d(W->pencil_plan, W->UT, nullptr, -1.0, W->TT, st);                                      // TT = -L_0 UT
+  if (!rc) rc = exchange(D, nrhs, W->TT, pq, D->fwd_recv.data(), W->recvbuf, lq, D->fwd_send.data(), own, st);           // pencil rows -> slab blocks
   // the caller's stream is rejoined with the side stream on every path, errors included
   hipError_t e2 = one_stream ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
   if (rc) { chebhip::comm_abort(D->comm); return rc; }     // thread ranks waiting for this one fail at once instead of timing out
   if (e1 != hipSuccess || e2 != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream join failed");
-  APtrs A; A.n = exact ? d - 1 : 1; for (int k = 0; k < 9; k++) A.p[k] = k < A.n ? D->A[k] : nullptr;
+  APtrs A; A.n = exact ? d - 1 : 1; for (int k = 0; k < 9; k++) A.p[k] = k < A.n ? W->A[k] : nullptr;
   if (grid1) {
-    if (v2) hipLaunchKernelGGL((k_combine<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, own, own_out, A, V);
-    else hipLaunchKernelGGL((k_combine<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)D->recvbuf, own, own_out, A, V);
+    if (v2) hipLaunchKernelGGL((k_combine<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)W->recvbuf, own, own_out, A, V, lq, pq);
+    else hipLaunchKernelGGL((k_combine<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, (const double *)W->recvbuf, own, own_out, A, V, lq, pq);
   }
   DHIPCHK(hipGetLastError());
   return 0;
+}
+
+extern "C" int chebhip_dist_mult(chebhip_dist *D, const double *U, double *V, void *stream) {
+  if (!D || !U || !V) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (U == V) return chebhip_fail(CHEBHIP_ERR_ARG, "U and V must be distinct");
+  return dist_mult(D, D->w[1], U, V, (hipStream_t)stream);
+}
+
+// The same matvec on nrhs vectors at once (U, V: nrhs consecutive local vectors): one launch per direction on the stacked slabs /
+// pencils, ONE pack, ONE grouped exchange each way (nrhs (G - 1) messages in it) and ONE final sum -- the fixed cost of a launch of
+// 256-point lines (10-15 us: matrix fetch, fill, drain) and of an RCCL launch (~25 us) is paid once per batch, not per vector.
+// Callers: the independent right-hand sides of a block / s-step Krylov method, several Newton right-hand sides, the bench's pipelined
+// steps.  Each vector's result equals chebhip_dist_mult's (same kernels, same order of operations per line).  Collective.
+extern "C" int chebhip_dist_mult_batch(chebhip_dist *D, int nrhs, const double *U, double *V, void *stream) {
+  if (!D || !U || !V) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
+  if (U == V) return chebhip_fail(CHEBHIP_ERR_ARG, "U and V must be distinct");
+  if (nrhs < 1 || nrhs > 64) return chebhip_fail(CHEBHIP_ERR_ARG, "nrhs = %d must be in 1..64", nrhs);
+  chebhip_dist::Work *W = nullptr;
+  int rc = dist_work(D, nrhs, &W); if (rc) return rc;
+  return dist_mult(D, W, U, V, (hipStream_t)stream);
 }

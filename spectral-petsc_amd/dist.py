@@ -244,6 +244,14 @@ class DistPoissonC:
         sp._chk(sp.lib().chebhip_dist_mult(self._h, sp._dev_ptr(U, self.local_size), sp._dev_ptr(V, self.local_size), sp._stream()))
         return V
 
+    def mult_batch(self, U, V):
+        """chebhip_dist_mult_batch: U, V of shape (nrhs, local_size), contiguous -- nrhs vectors through ONE exchange each way."""
+        sp = self.sp
+        nrhs = int(U.shape[0])
+        assert U.dim() == 2 and U.shape[1] == self.local_size and V.shape == U.shape and U.is_contiguous() and V.is_contiguous()
+        sp._chk(sp.lib().chebhip_dist_mult_batch(self._h, nrhs, sp._dev_ptr(U.view(-1), nrhs * self.local_size), sp._dev_ptr(V.view(-1), nrhs * self.local_size), sp._stream()))
+        return V
+
     def reduce_fn(self):
         """(chebhip_reduce_fn, ctx) completing Krylov inner products over the ranks: ncclAllReduce on the C side."""
         import ctypes as C

@@ -79,6 +79,66 @@ def test_poisson_thread_ranks_small(G, dims):
     assert relerr(V, orc.elliptic_mult(dims, U, mode=orc.DIRECT)) < 1e-10
 
 
+@pytest.mark.parametrize("G,dims,nrhs", [(3, (13, 12, 10), 3), (2, (9, 8), 2), (5, (20, 18, 11), 4), (8, (70, 68, 66), 2)], ids=str)
+def test_poisson_batch_thread_ranks(G, dims, nrhs):
+    """chebhip_dist_mult_batch: nrhs vectors through ONE pack, ONE grouped exchange each way, one launch per direction on the stacked
+    slabs / pencils -- every vector's result equals chebhip_dist_mult's on the same handle to the bit, and the oracle's serial matvec
+    to 1e-10.  Uneven splits, odd extents (8-byte pack / combine), the 16-byte kernels (68 x 66 x 64 interior)."""
+    sp = ge.load(); dsp = ge.load_dist()
+    n, g, nd = orc.sizes(dims)
+    rng = np.random.default_rng(SEED + 5)
+    U = rng.standard_normal((nrhs, g))
+
+    def body(r, comm):
+        D = dsp.DistPoissonC(dims, sp, comm=comm)
+        o, ln = D.slab_offset, D.local_size
+        Ul = torch.from_numpy(np.ascontiguousarray(U[:, o:o + ln])).cuda()
+        Vb = torch.full_like(Ul, float("nan")); V1 = torch.full_like(Ul, float("nan"))
+        D.mult_batch(Ul, Vb)
+        D.mult_batch(Ul, Vb)                                   # (work set reused)
+        for q in range(nrhs):
+            D.mult(Ul[q], V1[q])
+        torch.cuda.current_stream().synchronize()
+        res = (o, Vb.cpu().numpy(), V1.cpu().numpy())
+        D.destroy()
+        return res
+    sp.set_option("dist_exact_order", 1)                         # (so that batch and single calls, which may take different launch routes, add in one order)
+    try:
+        parts = sorted(run_ranks(G, body), key=lambda t: t[0])
+    finally:
+        sp.set_option("dist_exact_order", 0)
+    Vb = np.concatenate([p[1] for p in parts], axis=1); V1 = np.concatenate([p[2] for p in parts], axis=1)
+    assert np.array_equal(Vb, V1)
+    for q in range(nrhs):
+        assert relerr(Vb[q], orc.elliptic_mult(dims, U[q], mode=orc.FAST, nthreads=8)) < 1e-10
+
+
+def test_poisson_256_batch_of_4_over_8_ranks():
+    """BASELINE config 3 at its size, four vectors per exchange over 8 thread ranks: each equals the serial handle's matvec (1e-13)."""
+    sp = ge.load(); dsp = ge.load_dist()
+    dims, G, nrhs = (256, 256, 256), 8, 4
+    g = 254 ** 3
+    U = torch.randn((nrhs, g), dtype=torch.float64, generator=torch.Generator().manual_seed(SEED + 6))
+
+    def body(r, comm):
+        D = dsp.DistPoissonC(dims, sp, comm=comm)
+        o, ln = D.slab_offset, D.local_size
+        Ul = U[:, o:o + ln].contiguous().cuda(); Vb = torch.empty_like(Ul)
+        D.mult_batch(Ul, Vb)
+        torch.cuda.current_stream().synchronize()
+        res = (o, Vb.cpu())
+        D.destroy()
+        return res
+    parts = sorted(run_ranks(G, body), key=lambda t: t[0])
+    Vb = torch.cat([p[1] for p in parts], dim=1)
+    ser = sp.EllipticOp(dims)
+    for q in range(nrhs):
+        Ud = U[q].cuda(); Vd = torch.empty_like(Ud)
+        ser.mult(Ud, Vd); torch.cuda.synchronize()
+        assert relerr(Vb[q].numpy(), Vd.cpu().numpy()) < 1e-13
+    ser.destroy()
+
+
 def test_poisson_256_over_8_ranks():
     """BASELINE config 3: -dim 256,256,256 slab-split over 8 ranks (254 = 6*32 + 2*31 planes, 254 x 32|31 x 254 pencils)."""
     sp = ge.load()
