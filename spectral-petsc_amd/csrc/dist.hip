@@ -315,6 +315,7 @@ extern "C" int chebhip_dist_mult_batch(chebhip_dist *D, int nrhs, const double *
   if (!D || !U || !V) return chebhip_fail(CHEBHIP_ERR_ARG, "NULL argument");
   if (U == V) return chebhip_fail(CHEBHIP_ERR_ARG, "U and V must be distinct");
   if (nrhs < 1 || nrhs > 64) return chebhip_fail(CHEBHIP_ERR_ARG, "nrhs = %d must be in 1..64", nrhs);
+  if (D->xfn && nrhs != 1) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist_mult_batch needs a chebhip_comm transport (chebhip_dist_use_comm / _use_rccl)");
   chebhip_dist::Work *W = nullptr;
   int rc = dist_work(D, nrhs, &W); if (rc) return rc;
   return dist_mult(D, W, U, V, (hipStream_t)stream);
