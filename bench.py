@@ -243,17 +243,8 @@ def extras(sp, torch):
         return e0.elapsed_time(e1) * 1e3 / reps
     out = {}
     rnd = lambda n: torch.randn(n, dtype=torch.float64, device="cuda")
-    op = sp.EllipticOp((128, 128, 128)); U = rnd(op.global_size); V = torch.empty_like(U)
-    out["poisson_128_matvec_us"] = t_us(lambda: op.mult(U, V), 300)
-    op.destroy()
-    op = sp.EllipticOp((256, 256, 256)); U = torch.rand(op.global_size, dtype=torch.float64, device="cuda") + 0.5
-    X = rnd(op.global_size); b = rnd(op.global_size); R = torch.empty_like(U)
-    out["formfunction_256_gamma4_us"] = t_us(lambda: op.function(U, b, R, 4.0, 2.0), 40)
-    out["jacobian_apply_256_gamma4_us"] = t_us(lambda: op.mult(X, R), 60)
-    op.destroy()
-    x = rnd(256 ** 3); y = torch.empty_like(x); pl = sp.ChebPlan((256, 256, 256), 1)
-    out["chebmult_256_us"] = t_us(lambda: pl.mult(x, y), 100)
-    pl.destroy(); del x, y
+    # (the Stokes handles first: their ~30 work arrays then come from a fresh allocator state -- handles made after gigabytes have been
+    # allocated and freed run 5-7 % slower for life)
     for P, power, key in ((64, False, "stokes_64_linear"), (128, True, "stokes_128_powerlaw")):
         op = sp.StokesOp((P, P, P))
         if power:
@@ -272,6 +263,17 @@ def extras(sp, torch):
             assert op.inner_iterations == 20
             out[key + "_schur_apply_20_inner_its_us"] = t_us(lambda: op.mult_schur(xp, yp), 10)
         op.destroy()
+    op = sp.EllipticOp((128, 128, 128)); U = rnd(op.global_size); V = torch.empty_like(U)
+    out["poisson_128_matvec_us"] = t_us(lambda: op.mult(U, V), 300)
+    op.destroy()
+    op = sp.EllipticOp((256, 256, 256)); U = torch.rand(op.global_size, dtype=torch.float64, device="cuda") + 0.5
+    X = rnd(op.global_size); b = rnd(op.global_size); R = torch.empty_like(U)
+    out["formfunction_256_gamma4_us"] = t_us(lambda: op.function(U, b, R, 4.0, 2.0), 40)
+    out["jacobian_apply_256_gamma4_us"] = t_us(lambda: op.mult(X, R), 60)
+    op.destroy()
+    x = rnd(256 ** 3); y = torch.empty_like(x); pl = sp.ChebPlan((256, 256, 256), 1)
+    out["chebmult_256_us"] = t_us(lambda: pl.mult(x, y), 100)
+    pl.destroy(); del x, y
     return out
 
 
@@ -429,16 +431,21 @@ def solves(sp, torch):
     # also pays the one-off costs of a fresh process -- device allocations of the Krylov bases (gigabytes at these sizes), first
     # touches, clocks -- which vary by tens of per cent from box to box and say nothing about the solve (1.28 / 1.51 s were seen
     # for the same config-5 solve on the same sources).  Same iteration counts in both runs.
+    # The Krylov handle (8 GB of basis vectors at this size) is the caller's and outlives the solves, as the KSP of elliptic.C:181-185
+    # does: making and freeing it inside the timed region added 0.0-0.8 s of hipMalloc / hipFree at random (device time of the solve
+    # constant at 0.22 s: tools/solve_order_probe.py, profiles/r05_solve_order.txt).
     dts = []
+    ks = sp.Fgmres(op.global_size, restart=30, rtol=1e-6, max_it=300)
     for rep in range(2):
         x.zero_()
         pc = sp.FdPc(op, sweeps=0)                          # (a fresh preconditioner per run: assembled from the state of ITS first residual)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-10, ksp_rtol=1e-6, ksp_restart=30, ksp_max_it=300, M=pc,
-                                            monitor=lambda i, f, k: pc.update())
+                                            monitor=lambda i, f, k: pc.update(), ks=ks)
         torch.cuda.synchronize(); dts.append(time.perf_counter() - t0)
         if rep == 0:
             pc.destroy()
+    ks.destroy()
     out["elliptic_256_gamma4"] = {"seconds": dts[1], "seconds_first_run": dts[0], "newton_its": its, "krylov_its": kits,
                                   "rel_err_vs_manufactured": float((x - us).abs().max() / us.abs().max())}
     pc.destroy(); op.destroy(); del us, b, x
@@ -465,14 +472,17 @@ def solves(sp, torch):
         st.set_dirichlet(dv); st.set_force(U2)
         x = torch.zeros(st.global_size, dtype=torch.float64, device="cuda")
         dts = []
+        ks = sp.Fgmres(st.global_size, restart=60, rtol=1e-5 if rheo[0] else 1e-12, max_it=200)       # the caller's KSP and PC objects (stokes.C:155-176)
+        pcs = sp.StokesSaddlePc(st, 0)
         for rep in range(2):                                # (the second run is the one reported: see above)
             x.zero_()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             stats = {}
             # the linear problem is solved to its floor (-exact 2 is resolved to rounding on 64 CGL points): tight tolerances
             log = solve.stokes_solve(sp, st, x, rheology=rheo, cont0=0, cont=cont, snes_rtol=1e-8 if rheo[0] else 1e-12, ksp_rtol=1e-5 if rheo[0] else 1e-12,
-                                     ksp_restart=60, ksp_max_it=200, max_linear_fail=3, snes_max_it=20, stats=stats)
+                                     ksp_restart=60, ksp_max_it=200, max_linear_fail=3, snes_max_it=20, stats=stats, ks=ks, pc=pcs)
             torch.cuda.synchronize(); dts.append(time.perf_counter() - t0)
+        ks.destroy(); pcs.destroy()
         rec = {"seconds": dts[1], "seconds_first_run": dts[0], "stages": len(log), "newton_its": int(sum(s[2] for s in log)), "krylov_its": int(sum(s[3] for s in log)),
                "residual_norm": float(log[-1][4]), "linear_solves_ended_on_iteration_limit": int(stats.get("linear_fails", -1))}
         if not rheo[0]:                                     # the field is the exact solution of the linear problem only

@@ -10,15 +10,18 @@ import torch
 
 
 def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50,
-                  ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000, M=None, monitor=None, norm=None, line_search=True):
+                  ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000, M=None, monitor=None, norm=None, line_search=True, ks=None):
     """Solve FormFunction(x) = A(x) x - b = 0 in place in x (device tensor).  Returns (newton_its, total_ksp_its, |F|).
     On several ranks (vectors = this rank's pieces) `op` is a callable driver of dist.py, `sp.Fgmres` must return a
-    solver with its reduction set, and `norm` the global 2-norm."""
+    solver with its reduction set, and `norm` the global 2-norm.
+    ks: a caller's Fgmres to use and keep (as a KSP object outlives its solves, elliptic.C:181-185); None: one is made and destroyed here."""
     n = op.global_size
     norm = norm or (lambda t: float(t.norm()))
     F = torch.empty_like(x)
     dx = torch.empty_like(x)
-    ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
+    own_ks = ks is None
+    if own_ks:
+        ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
     total = 0
     op.function(x, b, F, gamma, exponent)
     f0 = fn = norm(F)
@@ -46,7 +49,8 @@ def newton_krylov(sp, op, b, x, gamma=0.0, exponent=2.0, snes_rtol=1e-8, snes_at
             if monitor:
                 monitor(it, fn, ks.iterations)
     finally:
-        ks.destroy()
+        if own_ks:
+            ks.destroy()
     return it, total, fn
 
 
@@ -63,7 +67,7 @@ def continuation_schedule(exponent, regularization, cont0=0, cont=1):
 def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, saddle_type=0,
                  snes_rtol=1e-8, snes_atol=1e-50, snes_max_it=50, ksp_rtol=1e-5, ksp_restart=30, ksp_max_it=10000,
                  vel=(4, 1e-5), schur=(3, 1e-5), svel=(0, 1e-5), pc_sweeps=0, line_search=True, monitor=None, max_linear_fail=1,
-                 schur_jacobi=True, stats=None, dist=None):
+                 schur_jacobi=True, stats=None, dist=None, ks=None, pc=None):
     """The solve phase of stokes.C:213-235 on device vectors: for every continuation stage, SNESSolve = Newton with a
     backtracking line search around StokesFunction (stokes.C:680-758), each step KSPSolve(KSPFGMRES) on the
     Newton-linearised StokesMatMult (stokes.C:499-519) right-preconditioned by StokesPCApply<saddle_type>
@@ -74,17 +78,24 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
     `stats` (a dict) receives "linear_fails": the number of linear solves that ended on their iteration limit.
     `dist`: a slab driver of dist.py (DistStokesC) whose slab-mode operator `op` is: the vectors are this rank's pieces, every
     rank calls collectively; norms, the Krylov inner products and the block preconditioner's sums go through its communicator.
+    ks, pc: the caller's outer Fgmres and block preconditioner to use and keep (the KSP / PC objects of stokes.C:155-176 outlive their
+    solves); None: made and destroyed here.
     Returns a list of (exponent, regularization, newton_its, ksp_its, |F|) per stage."""
     kind, hardness, exponent, regularization, gamma0 = rheology
     n = op.global_size
     F = torch.empty_like(x); dx = torch.empty_like(x)
-    ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
+    own_ks, own_pc = ks is None, pc is None
+    if own_ks:
+        ks = sp.Fgmres(n, restart=ksp_restart, rtol=ksp_rtol, max_it=ksp_max_it)
     if dist is not None:
-        ks.set_reduce_raw(*dist.comm.reduce_fn())
-        pc = dist.saddle(saddle_type, vel, schur, svel, schur_jacobi)
+        if own_ks:
+            ks.set_reduce_raw(*dist.comm.reduce_fn())
+        if own_pc:
+            pc = dist.saddle(saddle_type, vel, schur, svel, schur_jacobi)
         gnorm = dist.comm.norm
     else:
-        pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps, schur_jacobi)
+        if own_pc:
+            pc = sp.StokesSaddlePc(op, saddle_type, vel, schur, svel, pc_sweeps, schur_jacobi)
         gnorm = lambda t: float(t.norm())
     stages = continuation_schedule(exponent, regularization, cont0, cont) if kind == 1 else [(exponent, regularization)]
     out = []
@@ -115,7 +126,10 @@ def stokes_solve(sp, op, x, rheology=(0, 1.0, 1.0, 1.0, 1.0), cont0=0, cont=1, s
                     monitor(e_i, r_i, it, fn, ks.iterations, lam)
             out.append((e_i, r_i, it, total, fn))
     finally:
-        ks.destroy(); pc.destroy()
+        if own_ks:
+            ks.destroy()
+        if own_pc:
+            pc.destroy()
         if stats is not None:
             stats["linear_fails"] = fails
     return out
