@@ -1002,6 +1002,51 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     }
   }
   OPCHK(hipDeviceSynchronize());
+  // Placement trials (round 5; large 3-D handles only -- where the fused-z route runs).  Where the ~20 work arrays land in physical
+  // memory decides 5-7 % of every callback for the life of the handle (128^3 StokesMatMult 275 .. 293 us; not a matter of
+  // virtual offsets, and not visible when launches are serialised).  Nothing but a measurement tells a good set from a bad one, so the
+  // handle makes up to `stokes_placement_trials` (default 3) complete sets -- each allocated while the incumbent is still held, so that
+  // it lands elsewhere -- times the general-route StokesMatMult on each (zero data: a few ms per set) and keeps the fastest.
+  {
+    const int trials = opt(OPT_STOKES_PLACEMENT_TRIALS);
+    if (trials > 1 && st_zfused_ok(op)) {
+      const long g = op->I * (d + 1);
+      double *xg = nullptr, *yg = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      bool ok = hipMalloc((void **)&xg, (size_t)g * sizeof(double)) == hipSuccess && hipMalloc((void **)&yg, (size_t)g * sizeof(double)) == hipSuccess &&
+                hipMemset(xg, 0, (size_t)g * sizeof(double)) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+      auto probe = [&](float *ms) -> bool {            // the general route (26 streams in its node loop), as a power-law state takes it
+        const bool eu = op->eta_uniform, dn = op->deta_nonzero;
+        op->eta_uniform = false; op->deta_nonzero = true;
+        bool good = true;
+        for (int it = 0; it < 9 && good; it++) {
+          if (it == 3) good = hipEventRecord(e0, nullptr) == hipSuccess;
+          good = good && stokes_op_mult(op, xg, yg, nullptr) == 0;
+        }
+        good = good && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+        op->eta_uniform = eu; op->deta_nonzero = dn;
+        return good;
+      };
+      float best = 0.0f;
+      ok = ok && probe(&best);
+      for (int t = 1; t < trials && ok; t++) {
+        std::vector<double *> cand(reqs.size(), nullptr), keep(reqs.size());
+        bool got = true;
+        for (size_t i = 0; i < reqs.size() && got; i++) got = st_alloc(&cand[i], reqs[i].n) == 0;
+        if (!got) { for (double *q : cand) st_free(q); (void)hipGetLastError(); break; }      // (out of memory: keep what we have)
+        for (size_t i = 0; i < reqs.size(); i++) { keep[i] = *reqs[i].p; *reqs[i].p = cand[i]; }
+        hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
+        float ms = 0.0f;
+        const bool timed = probe(&ms);
+        if (timed && ms < best) { best = ms; for (double *q : keep) st_free(q); }
+        else { for (size_t i = 0; i < reqs.size(); i++) *reqs[i].p = keep[i]; (void)hipDeviceSynchronize(); for (double *q : cand) st_free(q); }
+      }
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      st_free(xg); st_free(yg);
+      (void)hipDeviceSynchronize(); (void)hipGetLastError();
+    }
+  }
 #undef OPCHK
 #undef OPRC
   *out = op;
