@@ -172,7 +172,10 @@ __global__ void k_deinterleave_over_eta(long G, int nf, const double *__restrict
 // 32 lines.  (W and y move as 8-byte pieces in accumulator layout; 16-byte pieces after a DPP lane exchange, as in the sweep kernels'
 // epilogue, were built and gave nothing: 144 -> 145-147 us for the MatVVPC solve.)
 typedef double fz_v4 __attribute__((ext_vector_type(4)));
-struct FzParams { int M, H; unsigned ncols, ntiles; const double *x, *W; double *y; const double *FE, *FO, *BE, *BO; };
+struct FzParams { int M, H; unsigned ncols, ntiles; const double *x; double *y; const double *FE, *FO, *BE, *BO;
+                  // the modal weights 1 / ((l_0[i] + l_1[j]) + l_z[k]) are formed on the fly (the association of k_modal_weights3: the same
+                  // bits as its array W, which cost this launch a third of its bytes): line -> (i, j) within a field of `flines` lines
+                  int d, n1; unsigned flines; const double *l0, *l1, *lz; };
 constexpr int FZ_KS = 16, FZ_LDJ = 4 * FZ_KS + 2, FZ_NT = 32;
 __global__ __launch_bounds__(256, 3) void k_fdm_zsolve16(const FzParams p) {
   // Workgroups of 256 threads (wave = m-tile, two sub-tiles of 16 lines), three per CU, out of phase with each other; the matrix
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(256, 3) void k_fdm_zsolve16(const FzParams p) {
       }
     }
   };
+  const double lze = oi < H ? p.lz[oi] : 0.0, lzo = oi < H ? p.lz[mm - oi] : 0.0;      // this lane's two modes along z
   for (unsigned tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     // ---- A: four slots per thread: line, points (j, j + 1) and their mirrors (mm - j - 1, mm - j); H odd: the last pair is its own mirror
     {
@@ -227,7 +231,13 @@ __global__ __launch_bounds__(256, 3) void k_fdm_zsolve16(const FzParams p) {
         for (int r = 0; r < 4; r++) {
           const unsigned gl = tile * FZ_NT + sub * 16 + 4 * r + kq;
           const bool ok = oi < H && gl < p.ncols;
-          we[sub][r] = ok ? p.W[(long)gl * M + oi] : 0.0; wo[sub][r] = ok ? p.W[(long)gl * M + (mm - oi)] : 0.0;
+          double sxy = 0.0;
+          if (ok) {
+            const unsigned lf = gl % p.flines;
+            if (p.d == 3) { const unsigned i0 = lf / (unsigned)p.n1, i1 = lf - i0 * (unsigned)p.n1; sxy = p.l0[i0] + p.l1[i1]; }
+            else sxy = p.l0[lf];
+          }
+          we[sub][r] = ok ? 1.0 / (sxy + lze) : 0.0; wo[sub][r] = ok ? 1.0 / (sxy + lzo) : 0.0;
         }
       fz_v4 ce[2], co[2];
       chains(p.FE, p.FO, ce, co);
@@ -532,7 +542,9 @@ static int fdm_solve(chebhip_fdpc *pc, const double *r, double *z, hipStream_t s
     LineMats &lm = pc->lines[pc->geo.dims[d - 1]];
     FzParams fp = {};
     fp.M = M; fp.H = (M + 1) / 2; fp.ncols = (unsigned)(pc->G * pc->nf / M); fp.ntiles = (fp.ncols + FZ_NT - 1) / FZ_NT;
-    fp.x = src; fp.W = pc->W; fp.y = (d == 1) ? z : a;
+    fp.x = src; fp.y = (d == 1) ? z : a;
+    fp.d = d; fp.n1 = d == 3 ? pc->geo.dims[1] - 2 : 1; fp.flines = (unsigned)(pc->G / M);
+    fp.l0 = lam.p[0]; fp.l1 = lam.p[1]; fp.lz = lam.p[d - 1];
     fp.FE = lm.Fraw.fragE; fp.FO = lm.Fraw.fragO; fp.BE = lm.Braw.fragE; fp.BO = lm.Braw.fragO;
     hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err); PHIPCHK(cu_err);
     const unsigned grid = fp.ntiles < 3u * (unsigned)ncu ? fp.ntiles : 3u * (unsigned)ncu;       // three workgroups per CU
