@@ -128,8 +128,8 @@ def cpu_baseline(P, threads, U, V=None, warm=2, reps=5):
     med = float(np.median(secs))
     out = {"value": 1.0 / med, "unit": "matvecs/s", "cores": threads, "kind": "port", "fftw": bool(use_fftw),
            "best": 1.0 / min(secs), "timed_applies": reps, "warmup_applies": warm, "seconds_per_apply": secs,
-           "sample": "%d warm-up + %d timed full %d^3 Poisson matvecs (6 ChebMult + pointwise passes each), median; oracle %s; %.1f s of CPU work in all"
-                     % (warm, reps, P, "pass structure around libfftw3 guru plans (FFTW_ESTIMATE)" if use_fftw else "FAST path (restated transforms; no libfftw3 on this box)", total)}
+           "sample": "%d warm-up + %d timed full %d^3 Poisson matvecs (6 ChebMult + pointwise passes each), median%s; oracle %s; %.1f s of CPU work in all"
+                     % (warm, reps, P, " (BASELINE.md section 3 asks 2 + 5: cut to 1 + 3 by the ~30-s bound on the CPU sample, 7-8 s per apply on one core)" if (warm, reps) == (1, 3) else "", "pass structure around libfftw3 guru plans (FFTW_ESTIMATE)" if use_fftw else "FAST path (restated transforms; no libfftw3 on this box)", total)}
     parity = None
     if V is not None:
         parity = {"rel_l2_vs_oracle": float(np.linalg.norm(V - ref) / np.linalg.norm(ref)), "tolerance": 1e-10,

@@ -432,7 +432,8 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   no_raw_transforms     1: the preconditioner's line transforms take two launches instead of one
  *   equal_shares          1: multi-job launches give every job min(tiles, CUs) workgroups instead of proportional shares
  *   force_gemm            1: every extent of 4 .. 256 points takes the library-DGEMM route of the longest lines (read at operator create)
- *   stokes_single_stream  1: StokesMatMult / StokesFunction keep the pressure chain on the caller's stream (read at create)
+ *   stokes_single_stream  1: StokesMatMult / StokesFunction keep the pressure chain on the caller's stream, also on large grids off the
+ *                            fused-z route (read at create)
  *   eta_from_memory       1: FormFunction reads eta instead of forming 1 + gamma u^2 on chip (exponent 2)
  *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
  *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
@@ -460,7 +461,15 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   fdm_passes            1: the fast-diagonalisation solve z = P_1^-1 (r / eta) of the finite-difference preconditioners divides by eta
  *                            and by the modal sums in passes of their own, instead of multiplying by the reciprocals in the load of its
  *                            first and the store of its last forward line transform (A/B; the two differ in the last bits)
- *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create) */
+ *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create)
+ *   stokes_pressure_stream 1: where the fused-z route runs, the pressure-gradient sweeps go to a second stream between the gather and the
+ *                            final scatter (rounds 2-4) instead of being jobs of the route's first launch (read at create; A/B: a tie)
+ *   stokes_placement_trials  large 3-D Stokes handles (where the fused-z route runs) make this many complete sets of their work arrays at
+ *                            create, time StokesMatMult on each and keep the fastest: where the arrays land in physical memory decides
+ *                            5-7 % of every callback for the life of the handle (default 4; 1 = the first set, no trial)
+ *   krylov_exact_norm     1: chebhip_fgmres runs its Gram-Schmidt step as three launches with an explicit norm pass (rounds 1-4) instead of
+ *                            two launches with one reduction and the stored vectors' exact norms carried beside the basis (read per solve; A/B)
+ *   no_rocblas            deprecated alias (rounds 1-3) of vendor_gemm with the inverted meaning; still accepted */
 int chebhip_set_option(const char *name, int value);
 int chebhip_get_option(const char *name, int *value);
 const char *chebhip_option_name(int index);     /* "" past the last option: enumerate from 0 */
