@@ -83,17 +83,30 @@ __global__ __launch_bounds__(256) void k_st_local4(long N, const int *__restrict
   }
 }
 
+// Interior indices of the node pair (2t, 2t + 1) of a serial 3-D grid with an even last extent, by arithmetic instead of from the table
+// ixL (4 B/node of every gather and scatter: 1.2 % of the bytes of a 128^3 callback): n(i, j, k) = ((i-1) M1 + (j-1)) M2 + (k-1) for
+// interior nodes (BlockIt order, stokes.C:791-879), -1 on the boundary.  P2 == 0: read the table (slab handles, odd extents, d = 2).
+struct StGrid { unsigned P0, P1, P2; };
+__device__ __forceinline__ int2 st_pair_ix(const int *__restrict__ ixL, long t, const StGrid g) {
+  if (g.P2 == 0) return ((const int2 *)ixL)[t];
+  const unsigned l = (unsigned)(2 * t), q = l / g.P2, k = l - q * g.P2;          // k even: the pair shares its line
+  const unsigned i = q / g.P1, j = q - i * g.P1;
+  if (i == 0 || i == g.P0 - 1 || j == 0 || j == g.P1 - 1) return make_int2(-1, -1);
+  const int base = (int)(((i - 1) * (g.P1 - 2) + (j - 1)) * (g.P2 - 2)) - 1;
+  return make_int2(k == 0 ? -1 : base + (int)k, k + 2 == g.P2 ? -1 : base + (int)k + 1);
+}
+
 // ... and on node PAIRS (N even): the two nodes (l, l+1) of a pair are neighbours in every local field, so each field
 // leaves as one 16-byte store per pair instead of two 8-byte ones (a CU's store path moves 8-byte accesses at ~0.6x the
 // rate of 16-byte ones, sweep_vec.hip); UN pairs in flight per thread.
 template <int UN>
 __global__ __launch_bounds__(256) void k_st_local4p(long N, const int *__restrict__ ixL, const double *__restrict__ src,
-                                                    const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL) {
+                                                    const double *__restrict__ dirloc, double *__restrict__ xL, double *__restrict__ pL, const StGrid sg) {
   const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
   for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
     int2 n[UN];
 #pragma unroll
-    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? st_pair_ix(ixL, t, sg) : make_int2(-1, -1); }
     double2 a[UN][2], b[UN][2];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -422,14 +435,14 @@ __global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict_
                                                   const double *__restrict__ yL1, const double *__restrict__ yL2,
                                                   const double *__restrict__ gp0, const double *__restrict__ gp1, const double *__restrict__ gp2,
                                                   const double *__restrict__ p2, const double *__restrict__ force, double *__restrict__ out,
-                                                  const double *__restrict__ G, const double *__restrict__ p2b, const double *__restrict__ p2c) {
+                                                  const double *__restrict__ G, const double *__restrict__ p2b, const double *__restrict__ p2c, const StGrid sg) {
   // p2b, p2c (may be null): the pressure rows are (p2 + p2b) + p2c -- the divergence as the sum of its three terms
   const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
   const double *gp[3] = {gp0, gp1, gp2};
   for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
     int2 n[UN];
 #pragma unroll
-    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? st_pair_ix(ixL, t, sg) : make_int2(-1, -1); }
     double2 v[UN][4];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -470,12 +483,12 @@ __global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict_
 // pairs: the full-grid side moves 16 bytes per access, the interior side 8 bytes with neighbouring lanes on neighbouring
 // addresses (an interior run of the last dimension is contiguous in both).  N even.  The same sums in the same order as k_st_out.
 template <int UN>
-__global__ __launch_bounds__(256) void k_st_local_cm3p(long N, long I, const int *__restrict__ ixL, const double *__restrict__ src, double *__restrict__ xL) {
+__global__ __launch_bounds__(256) void k_st_local_cm3p(long N, long I, const int *__restrict__ ixL, const double *__restrict__ src, double *__restrict__ xL, const StGrid sg) {
   const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
   for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
     int2 n[UN];
 #pragma unroll
-    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? st_pair_ix(ixL, t, sg) : make_int2(-1, -1); }
     double2 v[UN][3];
 #pragma unroll
     for (int u = 0; u < UN; u++)
@@ -495,12 +508,12 @@ __global__ __launch_bounds__(256) void k_st_local_cm3p(long N, long I, const int
 }
 struct StTerms3 { const double *p[4][3]; int n; };      // up to four terms of three component fields each, summed in order
 template <int UN>
-__global__ __launch_bounds__(256) void k_st_out_cm3p(long N, long I, const int *__restrict__ ixL, StTerms3 tm, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_st_out_cm3p(long N, long I, const int *__restrict__ ixL, StTerms3 tm, double *__restrict__ out, const StGrid sg) {
   const long T = (long)gridDim.x * blockDim.x, half = N >> 1;
   for (long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x; t0 < half; t0 += UN * T) {
     int2 n[UN];
 #pragma unroll
-    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? ((const int2 *)ixL)[t] : make_int2(-1, -1); }
+    for (int u = 0; u < UN; u++) { const long t = t0 + u * T; n[u] = t < half ? st_pair_ix(ixL, t, sg) : make_int2(-1, -1); }
     double2 v[UN][3];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -1002,51 +1015,6 @@ static int st_create(int d, const int *gdims, int lo, int hi, stokes_dim0_fn dim
     }
   }
   OPCHK(hipDeviceSynchronize());
-  // Placement trials (round 5; large 3-D handles only -- where the fused-z route runs).  Where the ~20 work arrays land in physical
-  // memory decides 5-7 % of every callback for the life of the handle (128^3 StokesMatMult 275 .. 293 us; not a matter of
-  // virtual offsets, and not visible when launches are serialised).  Nothing but a measurement tells a good set from a bad one, so the
-  // handle makes up to `stokes_placement_trials` (default 3) complete sets -- each allocated while the incumbent is still held, so that
-  // it lands elsewhere -- times the general-route StokesMatMult on each (zero data: a few ms per set) and keeps the fastest.
-  {
-    const int trials = opt(OPT_STOKES_PLACEMENT_TRIALS);
-    if (trials > 1 && st_zfused_ok(op)) {
-      const long g = op->I * (d + 1);
-      double *xg = nullptr, *yg = nullptr;
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      bool ok = hipMalloc((void **)&xg, (size_t)g * sizeof(double)) == hipSuccess && hipMalloc((void **)&yg, (size_t)g * sizeof(double)) == hipSuccess &&
-                hipMemset(xg, 0, (size_t)g * sizeof(double)) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-      auto probe = [&](float *ms) -> bool {            // the general route (26 streams in its node loop), as a power-law state takes it
-        const bool eu = op->eta_uniform, dn = op->deta_nonzero;
-        op->eta_uniform = false; op->deta_nonzero = true;
-        bool good = true;
-        for (int it = 0; it < 9 && good; it++) {
-          if (it == 3) good = hipEventRecord(e0, nullptr) == hipSuccess;
-          good = good && stokes_op_mult(op, xg, yg, nullptr) == 0;
-        }
-        good = good && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
-        op->eta_uniform = eu; op->deta_nonzero = dn;
-        return good;
-      };
-      float best = 0.0f;
-      ok = ok && probe(&best);
-      for (int t = 1; t < trials && ok; t++) {
-        std::vector<double *> cand(reqs.size(), nullptr), keep(reqs.size());
-        bool got = true;
-        for (size_t i = 0; i < reqs.size() && got; i++) got = st_alloc(&cand[i], reqs[i].n) == 0;
-        if (!got) { for (double *q : cand) st_free(q); (void)hipGetLastError(); break; }      // (out of memory: keep what we have)
-        for (size_t i = 0; i < reqs.size(); i++) { keep[i] = *reqs[i].p; *reqs[i].p = cand[i]; }
-        hipLaunchKernelGGL(k_st_fill, dim3(sgrid(N)), dim3(256), 0, nullptr, N, 1.0, op->eta);
-        float ms = 0.0f;
-        const bool timed = probe(&ms);
-        if (timed && ms < best) { best = ms; for (double *q : keep) st_free(q); }
-        else { for (size_t i = 0; i < reqs.size(); i++) *reqs[i].p = keep[i]; (void)hipDeviceSynchronize(); for (double *q : cand) st_free(q); }
-      }
-      if (e0) (void)hipEventDestroy(e0);
-      if (e1) (void)hipEventDestroy(e1);
-      st_free(xg); st_free(yg);
-      (void)hipDeviceSynchronize(); (void)hipGetLastError();
-    }
-  }
 #undef OPCHK
 #undef OPRC
   *out = op;
@@ -1153,6 +1121,12 @@ static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *
 #define ST_D(KERNEL, ...) do { if (d == 2) hipLaunchKernelGGL((KERNEL<2>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); \
                                else hipLaunchKernelGGL((KERNEL<3>), dim3(sgrid(op->N)), dim3(256), 0, st, op->N, __VA_ARGS__); } while (0)
 
+// the grid of st_pair_ix: serial 3-D handles with an even last extent (option "general_kernels": the table)
+static inline StGrid st_grid(const stokes_op *op) {
+  StGrid g = {0u, 0u, 0u};
+  if (op->d == 3 && !op->slab && (op->dims[2] & 1) == 0 && !opt(OPT_GENERAL_KERNELS)) { g.P0 = (unsigned)op->dims[0]; g.P1 = (unsigned)op->dims[1]; g.P2 = (unsigned)op->dims[2]; }
+  return g;
+}
 // xL / pL <- global vector (either may be null)
 static inline unsigned ugrid(long n, int un) { long g = (n + 256L * un - 1) / (256L * un); return (unsigned)(g < 1 ? 1 : g); }
 static inline bool st_al16(const void *q) { return ((size_t)q & 15) == 0; }
@@ -1161,7 +1135,7 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
   // (k_st_local4 loads node 0 of src for boundary nodes too: not for a slab without unknowns, whose src may be NULL)
   if (d == 3 && gs == 4 && go == 3 && xL && pL && op->I > 0 && st_al16(src)) {
     if ((op->N & 1) == 0 && st_al16(xL) && st_al16(pL) && (!dirloc || st_al16(dirloc)))
-      hipLaunchKernelGGL((k_st_local4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
+      hipLaunchKernelGGL((k_st_local4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL, st_grid(op));
     else
       hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
     return;
@@ -1178,7 +1152,7 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
   const int d = op->d;
   if (p3) {                                                 // (the caller has checked st_out_pairs)
     hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
-                       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], p3, force, out, G, p3 + op->N, p3 + 2 * op->N);
+                       (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], p3, force, out, G, p3 + op->N, p3 + 2 * op->N, st_grid(op));
     return;
   }
   if (!y0) { y0 = op->yL; y1 = op->yLx[1]; y2 = op->yLx[2]; }
@@ -1186,7 +1160,7 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
     if ((op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G)))      // (the handle's own arrays: always)
       hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                          (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G,
-                         (const double *)nullptr, (const double *)nullptr);
+                         (const double *)nullptr, (const double *)nullptr, st_grid(op));
     else
       hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                          (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
@@ -1514,7 +1488,7 @@ static int st_join(stokes_op *op, hipStream_t st) {
 // component-major d = 3 vectors on node pairs (k_st_local_cm3p / k_st_out_cm3p): N even, the handle's arrays are 16-B aligned
 static inline bool st_cm_pairs(const stokes_op *op, bool cm) { return cm && op->d == 3 && (op->N & 1) == 0 && op->I > 0; }
 static void st_local_cm(stokes_op *op, const double *v_cm, hipStream_t st) {
-  hipLaunchKernelGGL((k_st_local_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, v_cm, op->xL);
+  hipLaunchKernelGGL((k_st_local_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, v_cm, op->xL, st_grid(op));
 }
 static void st_out_cm(stokes_op *op, int nterms, const double *t0, const double *t1, const double *t2, const double *t3, double *out_cm, hipStream_t st,
                       bool separate_fields = false) {      // separate_fields: t0, t1, t2 are the three component fields of ONE term (gp[])
@@ -1526,7 +1500,7 @@ static void st_out_cm(stokes_op *op, int nterms, const double *t0, const double 
     tm.n = nterms;
     for (int q = 0; q < nterms; q++) for (int c = 0; c < 3; c++) tm.p[q][c] = t[q] + (size_t)c * N;
   }
-  hipLaunchKernelGGL((k_st_out_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, tm, out_cm);
+  hipLaunchKernelGGL((k_st_out_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, tm, out_cm, st_grid(op));
 }
 
 static int st_mult_vv(stokes_op *op, const double *vG, double *out, hipStream_t st, bool cm) {
