@@ -1135,7 +1135,8 @@ static void st_local(stokes_op *op, int gs, int go, const double *src, const dou
   // (k_st_local4 loads node 0 of src for boundary nodes too: not for a slab without unknowns, whose src may be NULL)
   if (d == 3 && gs == 4 && go == 3 && xL && pL && op->I > 0 && st_al16(src)) {
     if ((op->N & 1) == 0 && st_al16(xL) && st_al16(pL) && (!dirloc || st_al16(dirloc)))
-      hipLaunchKernelGGL((k_st_local4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL, st_grid(op));
+      // (one pair per thread, as the scatter: 128^3 StokesMatMult 272.5 -> 271.1 us, StokesFunction 288.0 -> 285.5 us against two)
+      hipLaunchKernelGGL((k_st_local4p<1>), dim3(ugrid(op->N >> 1, 1)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL, st_grid(op));
     else
       hipLaunchKernelGGL((k_st_local4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, src, dirloc, xL, pL);
     return;
@@ -1157,10 +1158,13 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
   }
   if (!y0) { y0 = op->yL; y1 = op->yLx[1]; y2 = op->yLx[2]; }
   if (d == 3 && y1 && y2 && st_al16(out) && (!force || st_al16(force))) {
-    if ((op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G)))      // (the handle's own arrays: always)
-      hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
+    if ((op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G))) {     // (the handle's own arrays: always)
+      // (one pair per thread: twice the waves in flight of the two-pair form for the same loads per CU -- 128^3 StokesMatMult 282.4 ->
+      // 279.2 us, StokesFunction 296.1 -> 292.7 us in one process; four pairs per thread: 286.6 / 294.8)
+      hipLaunchKernelGGL((k_st_out4p<1>), dim3(ugrid(op->N >> 1, 1)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                          (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G,
                          (const double *)nullptr, (const double *)nullptr, st_grid(op));
+    }
     else
       hipLaunchKernelGGL((k_st_out4<4>), dim3(ugrid(op->N, 4)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                          (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G);
@@ -1488,7 +1492,7 @@ static int st_join(stokes_op *op, hipStream_t st) {
 // component-major d = 3 vectors on node pairs (k_st_local_cm3p / k_st_out_cm3p): N even, the handle's arrays are 16-B aligned
 static inline bool st_cm_pairs(const stokes_op *op, bool cm) { return cm && op->d == 3 && (op->N & 1) == 0 && op->I > 0; }
 static void st_local_cm(stokes_op *op, const double *v_cm, hipStream_t st) {
-  hipLaunchKernelGGL((k_st_local_cm3p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, v_cm, op->xL, st_grid(op));
+  hipLaunchKernelGGL((k_st_local_cm3p<1>), dim3(ugrid(op->N >> 1, 1)), dim3(256), 0, st, op->N, op->I, (const int *)op->ixL, v_cm, op->xL, st_grid(op));
 }
 static void st_out_cm(stokes_op *op, int nterms, const double *t0, const double *t1, const double *t2, const double *t3, double *out_cm, hipStream_t st,
                       bool separate_fields = false) {      // separate_fields: t0, t1, t2 are the three component fields of ONE term (gp[])
