@@ -464,6 +464,10 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   full_stress_storage   1: Stokes handles keep all 9 stress / strain components instead of the 6 distinct ones (read at create)
  *   stokes_pressure_stream 1: where the fused-z route runs, the pressure-gradient sweeps go to a second stream between the gather and the
  *                            final scatter (rounds 2-4) instead of being jobs of the route's first launch (read at create; A/B: a tie)
+ *   stokes_pressure_sweeps 1: where the fused-z route runs, StokesMatMult / StokesFunction run the three pressure-gradient sweeps and add grad p in
+ *                            the final scatter (rounds 1-4), instead of subtracting the pressure -- face values extrapolated along each line, one
+ *                            small launch -- from the diagonal stress so that the three divergence sweeps deliver -div tau + grad p at once
+ *                            (read per call; A/B: the two agree to rounding, 4e-16 observed)
  *   krylov_exact_norm     1: chebhip_fgmres runs its Gram-Schmidt step as three launches with an explicit norm pass (rounds 1-4) instead of
  *                            two launches with one reduction and the stored vectors' exact norms carried beside the basis (read per solve; A/B)
  *   no_rocblas            deprecated alias (rounds 1-3) of vendor_gemm with the inverted meaning; still accepted */

@@ -182,6 +182,58 @@ __global__ __launch_bounds__(256) void k_st_preduce_contig(double *__restrict__ 
   }
 }
 
+// The end values of every INTERIOR grid line of a 3-D pressure field along each of the three directions -- the face-interior nodes -- by
+// extrapolation along the line, in ONE launch (blockIdx.y = direction; the three families write disjoint nodes, edges and corners
+// stay as they are: they only end lines that lie in the boundary, whose results nobody reads).  This is what the fused pressure
+// route needs of StokesPressureReduceOrder (st_viscous_jacobian_zfused): -D_k tau_kk + DP_k p = -D_k (tau_kk - p_ext).
+// z lines: one wave per line, lanes along it; x and y lines: 32 neighbouring lines per block, 8 parts each, fixed-order sums.
+__global__ __launch_bounds__(256) void k_st_pfaces(double *__restrict__ pres, int P0, int P1, int P2,
+                                                   const double *__restrict__ w0x, const double *__restrict__ w1x,
+                                                   const double *__restrict__ w0y, const double *__restrict__ w1y,
+                                                   const double *__restrict__ w0z, const double *__restrict__ w1z) {
+  const int dir = blockIdx.y;
+  if (dir == 2) {
+    const int lane = threadIdx.x & 63, m = P2 - 2;
+    const long nb = P1 - 2, nlines = (long)(P0 - 2) * nb;
+    for (long t = blockIdx.x * 4L + (threadIdx.x >> 6); t < nlines; t += (long)gridDim.x * 4) {
+      const long a = t / nb, b = t - a * nb;
+      double *line = pres + ((a + 1) * P1 + (b + 1)) * (long)P2;
+      double f0 = 0.0, f1 = 0.0;
+      for (int j = lane; j < m; j += 64) { const double v = line[j + 1]; f0 += w0z[j] * v; f1 += w1z[j] * v; }
+      for (int o = 32; o > 0; o >>= 1) { f0 += __shfl_down(f0, o, 64); f1 += __shfl_down(f1, o, 64); }
+      if (lane == 0) { line[0] = f0; line[P2 - 1] = f1; }
+    }
+    return;
+  }
+  __shared__ double s0[8][32], s1[8][32];
+  const int tb = threadIdx.x & 31, part = threadIdx.x >> 5;
+  // dir 1: lines (a, :, b), a in 1..P0-2, b in 1..P2-2, element stride P2;  dir 0: lines (:, a, b), a in 1..P1-2, b in 1..P2-2, stride P1 P2
+  const long nb = P2 - 2, na = dir == 1 ? P0 - 2 : P1 - 2, nlines = na * nb;
+  const long sa = dir == 1 ? (long)P1 * P2 : (long)P2, se = dir == 1 ? (long)P2 : (long)P1 * P2;
+  const int len = dir == 1 ? P1 : P0, m = len - 2, chunk = (m + 7) / 8;
+  const double *w0 = dir == 1 ? w0y : w0x, *w1 = dir == 1 ? w1y : w1x;
+  for (long g = blockIdx.x; g * 32 < nlines; g += gridDim.x) {
+    const long t = g * 32 + tb;
+    double f0 = 0.0, f1 = 0.0;
+    double *line = nullptr;
+    if (t < nlines) {
+      const long a = t / nb, b = t - a * nb;
+      line = pres + (a + 1) * sa + (b + 1);
+      const int j0 = part * chunk, j1 = (j0 + chunk < m) ? j0 + chunk : m;
+      for (int j = j0; j < j1; j++) { const double v = line[(long)(j + 1) * se]; f0 += w0[j] * v; f1 += w1[j] * v; }
+    }
+    s0[part][tb] = f0; s1[part][tb] = f1;
+    __syncthreads();
+    if (part == 0 && t < nlines) {
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { r0 += s0[q][tb]; r1 += s1[q][tb]; }
+      line[0] = r0; line[(long)(len - 1) * se] = r1;
+    }
+    __syncthreads();
+  }
+}
+
 // Node loop of StokesMatMultVV, stokes.C:647-662.  V[j], S[j]: d stacked fields (component k of direction j).
 // DETA = false when deta is identically zero (linear rheology): the deta * S0 * z term vanishes and S0 is not
 // read.  The trace of the velocity gradient is the divergence StokesMatMult needs for the pressure rows
@@ -454,8 +506,7 @@ __global__ __launch_bounds__(256) void k_st_out4p(long N, const int *__restrict_
         s.x = s.x + b.x; s.y = s.y + b.y;
         s.x = s.x + c.x; s.y = s.y + c.y;
         if (G) { const double2 g = ((const double2 *)(G + k * N))[t]; s.x = s.x + g.x; s.y = s.y + g.y; }
-        const double2 q = ((const double2 *)gp[k])[t];
-        s.x += 1.0 * q.x; s.y += 1.0 * q.y;
+        if (gp0) { const double2 q = ((const double2 *)gp[k])[t]; s.x += 1.0 * q.x; s.y += 1.0 * q.y; }      // (null: grad p is inside the y terms)
         v[u][k] = s;
       }
       v[u][3] = ((const double2 *)p2)[t];
@@ -566,11 +617,14 @@ struct ZfParams {
   // eta_w / deta_w and the six-slot stress T are written; the rheology of stokes.C:1920-1944
   double *Sz, *eta_w, *deta_w, *T;
   int kind; double hardness, expo, eps, gamma0;
+  // pL (may be null): the pressure with its face values extrapolated (k_st_pfaces) -- the stress leaves as tau - p I, so that the
+  // three divergence sweeps deliver -div tau + grad p and neither the pressure-gradient sweeps nor their term in the scatter exist
+  const double *pL;
 };
 constexpr int ZF_KS = 16, ZF_LDJ = 4 * ZF_KS + 2, ZF_NT = 16, ZF_PG = 130;   // k-steps; image row pitch (HP + 2); lines per tile; row pitch of G_z
 // MODE 0 / 1: the node loop of StokesMatMultVV without / with the eta' S0 z term (k_st_node_vv_pair); 2: the node loop of
 // StokesFunction with the six-component storage (k_st_node_fn_pair<true>: rheology, eta, eta', symmetrised strain as state)
-template <int MODE>
+template <int MODE, bool FOLD>
 __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
   constexpr bool DETA = MODE == 1;
   // Two workgroups of 256 threads per CU (out of phase with each other: one waits for memory while the other computes), 50.7 KB of
@@ -579,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
   constexpr int IMG = ZF_NT * ZF_LDJ, GPL = ZF_NT * ZF_PG;
   static_assert(3 * GPL <= 6 * IMG, "G_z must fit in the image space");
   __shared__ __attribute__((aligned(16))) double sI[6 * IMG];
+  __shared__ __attribute__((aligned(16))) double sP[FOLD ? GPL : 2];   // FOLD: the tile's pressure in node order (16.6 KB)
   const int tid = threadIdx.x, lane = tid & 63, mt = tid >> 6;         // wave = m-tile; every wave runs the three fields
   const int kq = lane >> 4, l16 = lane & 15;
   const int P = p.P, H = p.H, nn = P - 1;
@@ -626,6 +681,14 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
           rj[u][c] = make_double2(0.0, 0.0); rm[u][c] = rj[u][c];
           if (live[u]) { rj[u][c] = *(const double2 *)(p.xL + c * N + a[u]); rm[u][c] = *(const double2 *)(p.xL + c * N + m[u]); }
         }
+      double2 pj[2], pm[2];
+      if (FOLD) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          pj[u] = make_double2(0.0, 0.0); pm[u] = pj[u];
+          if (live[u]) { pj[u] = *(const double2 *)(p.pL + a[u]); pm[u] = *(const double2 *)(p.pL + m[u]); }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -633,6 +696,14 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
           *(double2 *)(sI + c * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(rj[u][c].x + rm[u][c].y, rj[u][c].y + rm[u][c].x);
           *(double2 *)(sI + (3 + c) * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(rj[u][c].x - rm[u][c].y, rj[u][c].y - rm[u][c].x);
         }
+      if (FOLD) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          if (live[u]) {                                               // (a dead slot's mirror index would land on a live slot's points)
+            *(double2 *)(sP + sl[u] * ZF_PG + sj[u]) = pj[u];
+            *(double2 *)(sP + sl[u] * ZF_PG + (nn - sj[u] - 1)) = pm[u];
+          }
+      }
     }
     __syncthreads();
     // ---- B: G_z,c = D_z v_c, to LDS in node order (over the images, once every wave has finished its chains)
@@ -710,6 +781,11 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
             for (int k = 0; k < 3; k++) *(double2 *)(p.Vx + k * N + off[h]) = sv[0][k];
             *(double2 *)(p.Vy + 1 * N + off[h]) = sv[1][1]; *(double2 *)(p.Vy + 2 * N + off[h]) = sv[1][2];
             *(double2 *)(p.Sz + 2 * N + off[h]) = sv[2][2];
+            if (FOLD) {                                                // the stress the divergence sweeps read: tau - p I
+              const double2 pp = *(const double2 *)(sP + sl[u] * ZF_PG + (h ? nn - sj[u] - 1 : sj[u]));
+#pragma unroll
+              for (int k = 0; k < 3; k++) { tv[k][k].x -= pp.x; tv[k][k].y -= pp.y; }
+            }
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -755,6 +831,11 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
                 for (int k = 0; k < 3; k++) comp(out[j][k], q) = DETA ? eq * strain[j][k] + deq * comp(s0[j][k][h], q) * z : eq * strain[j][k];
               double tr = comp(g[0][0][h], q) + comp(g[1][1][h], q); tr += comp(g[2][2][h], q);
               comp(dv, q) = tr;
+            }
+            if (FOLD) {                                                // tau - p I
+              const double2 pp = *(const double2 *)(sP + sl[u] * ZF_PG + (h ? nn - sj[u] - 1 : sj[u]));
+#pragma unroll
+              for (int k = 0; k < 3; k++) { out[k][k].x -= pp.x; out[k][k].y -= pp.y; }
             }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -1149,8 +1230,8 @@ static inline bool st_out_pairs(const stokes_op *op, const double *y0, const dou
   return op->d == 3 && y1 && y2 && st_al16(out) && (!force || st_al16(force)) && (op->N & 1) == 0 && st_al16(y0) && st_al16(y1) && st_al16(y2) && (!G || st_al16(G));
 }
 static void st_out_full(stokes_op *op, const double *force, double *out, hipStream_t st, const double *y0 = nullptr, const double *y1 = nullptr,
-                        const double *y2 = nullptr, const double *G = nullptr, const double *p3 = nullptr) {      // p3: three stacked terms of the pressure rows instead of p2
-  const int d = op->d;
+                        const double *y2 = nullptr, const double *G = nullptr, const double *p3 = nullptr, bool no_gp = false) {      // p3: three stacked terms of the pressure rows instead of p2
+  const int d = op->d;                                      // no_gp: grad p is inside the y terms (the folded pressure route: pair kernel only)
   if (p3) {                                                 // (the caller has checked st_out_pairs)
     hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                        (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], p3, force, out, G, p3 + op->N, p3 + 2 * op->N, st_grid(op));
@@ -1162,7 +1243,7 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
       // (one pair per thread: twice the waves in flight of the two-pair form for the same loads per CU -- 128^3 StokesMatMult 282.4 ->
       // 279.2 us, StokesFunction 296.1 -> 292.7 us in one process; four pairs per thread: 286.6 / 294.8)
       hipLaunchKernelGGL((k_st_out4p<1>), dim3(ugrid(op->N >> 1, 1)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
-                         (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G,
+                         (const double *)(no_gp ? nullptr : op->gp[0]), (const double *)op->gp[1], (const double *)op->gp[2], (const double *)op->p2, force, out, G,
                          (const double *)nullptr, (const double *)nullptr, st_grid(op));
     }
     else
@@ -1360,9 +1441,34 @@ static int st_zfused_launch(stokes_op *op, int mode, ZfParams zp, hipStream_t st
   zp.fragE = m.fragE; zp.fragO = m.fragO;
   hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err); SHIPCHK(cu_err);
   const unsigned grid = zp.ntiles < 2u * (unsigned)ncu ? zp.ntiles : 2u * (unsigned)ncu;      // two workgroups per CU
-  if (mode == 2) hipLaunchKernelGGL((k_st_zfused16<2>), dim3(grid), dim3(256), 0, st, zp);
-  else if (mode == 1) hipLaunchKernelGGL((k_st_zfused16<1>), dim3(grid), dim3(256), 0, st, zp);
-  else hipLaunchKernelGGL((k_st_zfused16<0>), dim3(grid), dim3(256), 0, st, zp);
+  if (zp.pL) {
+    if (mode == 2) hipLaunchKernelGGL((k_st_zfused16<2, true>), dim3(grid), dim3(256), 0, st, zp);
+    else if (mode == 1) hipLaunchKernelGGL((k_st_zfused16<1, true>), dim3(grid), dim3(256), 0, st, zp);
+    else hipLaunchKernelGGL((k_st_zfused16<0, true>), dim3(grid), dim3(256), 0, st, zp);
+  } else {
+    if (mode == 2) hipLaunchKernelGGL((k_st_zfused16<2, false>), dim3(grid), dim3(256), 0, st, zp);
+    else if (mode == 1) hipLaunchKernelGGL((k_st_zfused16<1, false>), dim3(grid), dim3(256), 0, st, zp);
+    else hipLaunchKernelGGL((k_st_zfused16<0, false>), dim3(grid), dim3(256), 0, st, zp);
+  }
+  SHIPCHK(hipGetLastError());
+  return 0;
+}
+// Round 5: the pressure inside the stress.  -sum_j D_j tau_jk + DP_k p = -(sum_{j != k} D_j tau_jk + D_k (tau_kk - p_ext)) with p_ext the
+// pressure whose line-end values are extrapolated (StokesPressureReduceOrder, stokes.C:1029-1080; DP_k of stokes.C:609-614 is D_k on
+// that field): k_st_pfaces fills the face-interior nodes of pL in one small launch, the fused z launch subtracts p from the diagonal
+// stress as it leaves the node loop, and the three divergence sweeps deliver the velocity rows of MatVV + MatVP at once -- the three
+// pressure-gradient sweeps (48 B/node, 25 us at 128^3) and their term in the scatter (24 B/node) are gone for one more 8-byte read.
+// Same operator to rounding (sums in another order; observed <= 1e-14 against the separate route).  Where the fused-z route runs
+// with 16-byte-aligned even grids (the pair scatter); option "stokes_pressure_sweeps" = 1 keeps the separate sweeps (A/B).
+static bool st_fold_pressure(stokes_op *op) {
+  return !op->aux && !op->slab && op->d == 3 && (op->N & 1) == 0 && !opt(OPT_STOKES_PRESSURE_SWEEPS) && st_zfused_ok(op);
+}
+static int st_pressure_faces(stokes_op *op, hipStream_t st) {
+  const int P0 = op->dims[0], P1 = op->dims[1], P2 = op->dims[2];
+  long lines = (long)(P0 - 2) * (P1 - 2); if ((long)(P0 - 2) * (P2 - 2) > lines) lines = (long)(P0 - 2) * (P2 - 2); if ((long)(P1 - 2) * (P2 - 2) > lines) lines = (long)(P1 - 2) * (P2 - 2);
+  long g = (lines + 3) / 4; if (g > 4096) g = 4096; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_st_pfaces, dim3((unsigned)g, 3), dim3(256), 0, st, op->pL, P0, P1, P2, (const double *)op->w0[0], (const double *)op->w1[0],
+                     (const double *)op->w0[1], (const double *)op->w1[1], (const double *)op->w0[2], (const double *)op->w1[2]);
   SHIPCHK(hipGetLastError());
   return 0;
 }
@@ -1391,9 +1497,11 @@ static int st_xy_gradient(stokes_op *op, double *const *out, bool with_pressure,
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
   return 0;
 }
-static int st_viscous_jacobian_zfused(stokes_op *op, double *div, hipStream_t st, bool with_pressure = false) {
-  int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->V, with_pressure, st); if (rc) return rc;            // V[0] = D_x xL, V[1] = D_y xL (+ gp[])
+static int st_viscous_jacobian_zfused(stokes_op *op, double *div, hipStream_t st, bool with_pressure = false, bool fold = false) {
+  int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->V, with_pressure && !fold, st); if (rc) return rc;   // V[0] = D_x xL, V[1] = D_y xL (+ gp[])
+  if (fold && (rc = st_pressure_faces(op, st))) return rc;
   ZfParams zp = {};
+  zp.pL = fold ? op->pL : nullptr;
   zp.xL = op->xL; zp.Vx = op->V[0]; zp.Vy = op->V[1];
   zp.S0 = op->strain[0]; zp.S1 = op->strain[1]; zp.S2 = op->strain[2]; zp.eta = op->eta; zp.deta = op->deta;
   zp.div = div;
@@ -1618,6 +1726,11 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   if (op->slab) {
     if ((rc = st_gradient_and_pressure_gradient_slab(op, op->V, st))) return rc;                                                 // MatVP (:512) + :639
     if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
+  } else if (st_fold_pressure(op)) {                          // the fused-z route with the pressure inside the stress
+    if ((rc = st_viscous_jacobian_zfused(op, op->p2, st, false, true))) return rc;                                               // MatVP (:512) + MatVV
+    if (!ST_ABL(4)) st_out_full(op, nullptr, yG, st, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+    SHIPCHK(hipGetLastError());
+    return 0;
   } else if (!op->aux && st_zfused_ok(op)) {                  // the fused-z route with the pressure-gradient sweeps inside its first launch
     if (!op->pext) st_pressure_extrapolate(op, op->pL, st);
     if ((rc = st_viscous_jacobian_zfused(op, op->p2, st, !ST_ABL(5)))) return rc;                                                // MatVP (:512) + MatVV
@@ -1662,13 +1775,16 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   if (!op->slab && op->sym && st_zfused_ok(op)) {
     // the z direction in one launch (k_st_zfused16, MODE 2): gradient along x, y -> strain[0], strain[1]; the fused launch leaves eta,
     // eta', the symmetrised strain (upper triangle) and the stress slots the x / y divergence reads, and returns -D_z tau_z. in yLx[2]
+    const bool fold = st_fold_pressure(op);
     if (op->aux && !ST_ABL(5)) { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                             // :747 (second stream: A/B)
-    if (!op->aux && !op->pext) st_pressure_extrapolate(op, op->pL, st);
-    int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->strain, !op->aux && !ST_ABL(5), st); if (rc) return rc;                      // :701 (x, y), :747
+    if (!op->aux && !op->pext && !fold) st_pressure_extrapolate(op, op->pL, st);
+    int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->strain, !op->aux && !ST_ABL(5) && !fold, st); if (rc) return rc;             // :701 (x, y), :747
+    if (fold && (rc = st_pressure_faces(op, st))) return rc;
     ZfParams zp = {};
     zp.xL = op->xL; zp.Vx = op->strain[0]; zp.Vy = op->strain[1]; zp.Sz = op->strain[2];
     zp.eta_w = op->eta; zp.deta_w = op->deta; zp.T = op->T; zp.div = op->p2;
     zp.kind = op->rh_kind; zp.hardness = op->rh_hard; zp.expo = op->rh_expo; zp.eps = op->rh_eps; zp.gamma0 = op->rh_g0;
+    zp.pL = fold ? op->pL : nullptr;
     if (!ST_ABL(2) && (rc = st_zfused_launch(op, 2, zp, st))) return rc;
     op->deta_nonzero = (op->rh_kind == 1);
     op->eta_uniform = (op->rh_kind == 0); op->eta_value = 1.0;
@@ -1676,7 +1792,7 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
     const double *t[3] = {op->T, op->T + op->N, op->T + 2 * op->N};
     if (!ST_ABL(3) && (rc = sweeps_multi(op, true, 0, t, y, -1.0, st, true, false, 2))) return rc;                               // :737-740 (x, y)
     if (!ST_ABL(5) && (rc = st_join(op, st))) return rc;
-    if (!ST_ABL(4)) st_out_full(op, op->force, yG, st);                                                                            // :750-756
+    if (!ST_ABL(4)) st_out_full(op, op->force, yG, st, nullptr, nullptr, nullptr, nullptr, nullptr, fold);                          // :750-756
     SHIPCHK(hipGetLastError());
     return 0;
   }

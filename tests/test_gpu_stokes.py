@@ -198,6 +198,7 @@ def test_z_direction_in_one_launch_equals_the_separate_passes(dims, state):
     outs = []
     for sep in (0, 1):
         sp.set_option("stokes_z_separate", sep)
+        sp.set_option("stokes_pressure_sweeps", 1)            # (like with like: the folded pressure route exists on the fused-z route only)
         try:
             st = sp.StokesOp(dims)
             fn = None
@@ -217,9 +218,38 @@ def test_z_direction_in_one_launch_equals_the_separate_passes(dims, state):
             outs.append((y.clone(), w.clone(), fn))
             st.destroy()
         finally:
-            sp.set_option("stokes_z_separate", 0)
+            sp.set_option("stokes_z_separate", 0); sp.set_option("stokes_pressure_sweeps", 0)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (
         float((outs[0][0] - outs[1][0]).norm() / outs[1][0].norm()), float((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm()))
     if outs[0][2] is not None:                                # residual, eta, eta', the three strain blocks
         for k, (p_, q_) in enumerate(zip(outs[0][2], outs[1][2])):
             assert np.array_equal(p_, q_), k
+
+
+@pytest.mark.parametrize("dims", [(128, 128, 128), (120, 121, 68), (150, 97, 100), (120, 120, 72)], ids=lambda d: "x".join(map(str, d)))
+def test_pressure_inside_the_stress_equals_the_pressure_sweeps(dims):
+    """Round 5: on the fused-z route StokesMatMult / StokesFunction deliver -div(tau - p_ext I) from the three divergence sweeps -- the
+    face-interior values of p extrapolated along each line by k_st_pfaces (StokesPressureReduceOrder, stokes.C:1029-1080), p subtracted
+    from the diagonal stress inside k_st_zfused16 -- instead of running the three pressure-gradient sweeps and adding grad p in the
+    scatter (option `stokes_pressure_sweeps` = 1).  Same operator, sums in another order: <= 1e-13; short z lines (dead loader slots),
+    partial tiles, odd extents; non-zero Dirichlet values and force.  (Against the oracle: the 128^3 tests above run the folded route.)"""
+    sp = ge.load()
+    import torch
+    st = sp.StokesOp(dims)
+    st.set_rheology(1, 1.0, 3.0, 1e-2, 1.0)
+    st.set_dirichlet(np.random.default_rng(1).standard_normal(st.dirichlet_size)); st.set_force(np.random.default_rng(6).standard_normal(st.global_size))
+    x0 = torch.from_numpy(np.random.default_rng(2).standard_normal(st.global_size)).cuda()
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal(st.global_size)).cuda()
+    res = []
+    try:
+        for sw in (1, 0):
+            sp.set_option("stokes_pressure_sweeps", sw)
+            r0 = torch.full_like(x0, float("nan")); y = torch.full_like(x, float("nan"))
+            st.function(x0, r0); st.mult(x, y); torch.cuda.synchronize()
+            res.append((r0.cpu().numpy(), y.cpu().numpy(), [st.get_state(w) for w in range(5)]))
+    finally:
+        sp.set_option("stokes_pressure_sweeps", 0)
+    st.destroy()
+    assert relerr(res[1][0], res[0][0]) < 1e-13 and relerr(res[1][1], res[0][1]) < 1e-13
+    for a, b in zip(res[0][2], res[1][2]):                    # the state StokesFunction leaves (eta, eta', strain) is untouched by the route
+        assert np.array_equal(a, b)

@@ -11,7 +11,7 @@ import __graft_entry__ as ge
 sp = ge.load()
 optname = sys.argv[1]; P = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 LIN = len(sys.argv) > 3 and sys.argv[3] == 'lin'
-CALL_TIME = optname in ("stokes_z_separate",)          # options read per call: one handle, the option toggled around the timed loops
+CALL_TIME = optname in ("stokes_z_separate", "stokes_pressure_sweeps")          # options read per call: one handle, the option toggled around the timed loops
 ops = []
 for v in (0, 1):
     sp.set_option(optname, 0 if CALL_TIME else v)
