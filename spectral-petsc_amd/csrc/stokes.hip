@@ -1460,8 +1460,10 @@ static int st_zfused_launch(stokes_op *op, int mode, ZfParams zp, hipStream_t st
 // pressure-gradient sweeps (48 B/node, 25 us at 128^3) and their term in the scatter (24 B/node) are gone for one more 8-byte read.
 // Same operator to rounding (sums in another order; observed <= 1e-14 against the separate route).  Where the fused-z route runs
 // with 16-byte-aligned even grids (the pair scatter); option "stokes_pressure_sweeps" = 1 keeps the separate sweeps (A/B).
-static bool st_fold_pressure(stokes_op *op) {
-  return !op->aux && !op->slab && op->d == 3 && (op->N & 1) == 0 && !opt(OPT_STOKES_PRESSURE_SWEEPS) && st_zfused_ok(op);
+static bool st_fold_pressure(stokes_op *op, const double *out, const double *force) {
+  // (the scatter without a grad p term is the pair kernel: a result or force vector that is only 8-byte aligned keeps the sweeps)
+  return !op->aux && !op->slab && op->d == 3 && (op->N & 1) == 0 && !opt(OPT_STOKES_PRESSURE_SWEEPS) && st_zfused_ok(op) &&
+         st_al16(out) && (!force || st_al16(force));
 }
 static int st_pressure_faces(stokes_op *op, hipStream_t st) {
   const int P0 = op->dims[0], P1 = op->dims[1], P2 = op->dims[2];
@@ -1726,7 +1728,7 @@ extern "C" int stokes_op_mult(stokes_op *op, const double *xG, double *yG, void 
   if (op->slab) {
     if ((rc = st_gradient_and_pressure_gradient_slab(op, op->V, st))) return rc;                                                 // MatVP (:512) + :639
     if ((rc = st_viscous_jacobian(op, op->p2, st, true))) return rc;
-  } else if (st_fold_pressure(op)) {                          // the fused-z route with the pressure inside the stress
+  } else if (st_fold_pressure(op, yG, nullptr)) {             // the fused-z route with the pressure inside the stress
     if ((rc = st_viscous_jacobian_zfused(op, op->p2, st, false, true))) return rc;                                               // MatVP (:512) + MatVV
     if (!ST_ABL(4)) st_out_full(op, nullptr, yG, st, nullptr, nullptr, nullptr, nullptr, nullptr, true);
     SHIPCHK(hipGetLastError());
@@ -1775,7 +1777,7 @@ extern "C" int stokes_op_function(stokes_op *op, const double *xG, double *yG, v
   if (!op->slab && op->sym && st_zfused_ok(op)) {
     // the z direction in one launch (k_st_zfused16, MODE 2): gradient along x, y -> strain[0], strain[1]; the fused launch leaves eta,
     // eta', the symmetrised strain (upper triangle) and the stress slots the x / y divergence reads, and returns -D_z tau_z. in yLx[2]
-    const bool fold = st_fold_pressure(op);
+    const bool fold = st_fold_pressure(op, yG, op->force);
     if (op->aux && !ST_ABL(5)) { int rc = st_pressure_gradient_forked(op, st); if (rc) return rc; }                             // :747 (second stream: A/B)
     if (!op->aux && !op->pext && !fold) st_pressure_extrapolate(op, op->pL, st);
     int rc = ST_ABL(1) ? 0 : st_xy_gradient(op, op->strain, !op->aux && !ST_ABL(5) && !fold, st); if (rc) return rc;             // :701 (x, y), :747
