@@ -490,6 +490,7 @@ extern "C" int chebhip_fgmres_create(long n, int restart, chebhip_fgmres **out) 
   KC(hipHostMalloc((void **)&k->res, (size_t)(m + 2) * sizeof(double)));
   k->ev.assign(m, nullptr);
   for (int j = 0; j < m; j++) KC(hipEventCreateWithFlags(&k->ev[j], hipEventDisableTiming));
+  KC(hipStreamSynchronize(nullptr));      // the ticket was cleared on the null stream, which a caller's non-blocking stream does not wait for
 #undef KC
   *out = k;
   return 0;
