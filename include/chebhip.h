@@ -223,6 +223,9 @@ int stokes_op_create_slab(int d, const int *dims, int lo, int hi, stokes_dim0_fn
 /* Pencil side: arrays (nfields, dims[0], ncol), lines along dimension 0 with stride ncol. */
 int stokes_op_pencil_sweep(stokes_op *op, int nfields, long ncol, const double *in_dev, double *out_dev, void *stream);
 int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil_dev, double *gp0_pencil_dev, void *stream);
+/* Kind 2 on the pencils in ONE launch: nvel stacked velocity fields swept with D and, behind them, the pressure field treated as
+ * stokes_op_pencil_pressure treats it (two jobs of one launch where the kernels allow it, otherwise the two calls above). */
+int stokes_op_pencil_sweep_pressure(stokes_op *op, int nvel, long ncol, double *in_dev, double *out_dev, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Multi-GPU host for BASELINE config 3: the linear 3-D Poisson    */

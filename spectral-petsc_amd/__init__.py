@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "stokes_op_create", "stokes_op_destroy", "stokes_op_size", "stokes_op_set_rheology",
     "stokes_op_set_dirichlet", "stokes_op_set_force", "stokes_op_mult", "stokes_op_mult_vv",
     "stokes_op_mult_pv", "stokes_op_mult_vp", "stokes_op_mult_vv_cm", "stokes_op_mult_pv_cm", "stokes_op_mult_vp_cm", "stokes_op_mult_schur_cm", "stokes_op_function", "stokes_op_get_state",
-    "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations", "stokes_op_set_inner_reduce",
+    "stokes_op_set_state", "stokes_op_create_slab", "stokes_op_pencil_sweep", "stokes_op_pencil_pressure", "stokes_op_pencil_sweep_pressure", "stokes_op_mult_schur", "stokes_op_set_inner_solver", "stokes_op_inner_iterations", "stokes_op_set_inner_reduce",
     "chebhip_fgmres_create", "chebhip_fgmres_destroy", "chebhip_fgmres_set_tolerances", "chebhip_fgmres_solve",
     "chebhip_fgmres_iterations", "chebhip_fgmres_residual", "chebhip_fgmres_reason", "chebhip_fgmres_set_reduce",
     "ell_pc_create", "stokes_pc_create", "chebhip_fdpc_destroy", "chebhip_fdpc_update", "chebhip_fdpc_set_sweeps",

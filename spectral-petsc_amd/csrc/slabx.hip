@@ -209,8 +209,7 @@ static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const dou
   if (kind == 0) rc = stokes_op_pencil_sweep(D->op, nf, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);     // DV[0] / DP[0]
   else if (kind == 1) rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);  // x-line extrapolation + DP[0]
   else {                                                     // kind 2: nf - 1 velocity fields and the pressure field in one round trip
-    rc = stokes_op_pencil_sweep(D->op, nf - 1, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);
-    if (!rc) rc = stokes_op_pencil_pressure(D->op, D->x.ncol, D->x.pen_in + (size_t)(nf - 1) * D->x.Np, D->x.pen_out + (size_t)(nf - 1) * D->x.Np, stream);
+    rc = stokes_op_pencil_sweep_pressure(D->op, nf - 1, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);      // (two jobs of one launch)
   }
   if (!rc) rc = D->x.to_slab(nf, acc, alpha, out, st);
   if (rc) chebhip::comm_abort(D->x.comm);

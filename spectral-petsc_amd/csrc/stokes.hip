@@ -1,9 +1,13 @@
-// stokes.hip -- the Stokes operator callbacks (stokes.C:499-758) over the sweep kernel:
-// StokesMatMult / VV / PV / VP and StokesFunction with the linear and power-law rheologies,
-// -boundary 0 (all-Dirichlet velocity).  Every ChebMult of the reference is one
-// cheb_sweep_kernel launch (DV[i]: rank d+1 tensor with the d components innermost,
-// stokes.C:284-290; DP[i]: scalar rank d); the vector passes between them are the small
-// node-local kernels below.
+// stokes.hip -- the Stokes operator callbacks (stokes.C:499-758) over the sweep kernels:
+// StokesMatMult / VV / PV / VP / Schur and StokesFunction with the linear and power-law rheologies,
+// -boundary 0 (all-Dirichlet velocity).  The ChebMults of the reference (DV[i]: rank d+1 tensor with the d
+// components innermost, stokes.C:284-290; DP[i]: scalar rank d) run as multi-job sweep launches on
+// component-major work vectors, the vector passes between them as the node-local kernels below.  Routes
+// (DESIGN.md 4.3): the general viscous block -- gather, x / y gradient launch, k_st_pfaces, k_st_zfused16 (z
+// gradient + node loop + z divergence in one launch, the pressure subtracted from the diagonal stress), x / y
+// divergence launch, scatter -- on 3-D grids with 68..128-point contiguous lines; separate passes elsewhere;
+// -eta/2 (sum D_j D_j v + grad div v) without a node loop for a uniform viscosity; slab-mode handles whose
+// dimension-0 work goes through the driver's callback (slabx.hip).
 #include "../../include/chebhip.h"
 #include "sweep.h"
 #include "ops.h"
@@ -1895,6 +1899,28 @@ extern "C" int stokes_op_pencil_sweep(stokes_op *op, int nfields, long ncol, con
 }
 
 // x-line pressure extrapolation (stokes.C:1064-1074) in place on a pencil, then gp0 = DP[0] p
+extern "C" int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil, double *gp0_pencil, void *stream);
+// Both of a slab callback's pencil sweeps (kind 2 of the dimension-0 callback) as two jobs of ONE launch: at 8 ranks a 128^3 callback
+// is a dozen latency-bound launches of 5-12 us, and these two were separate only because their matrices differ (D, and D with the
+// end-point extrapolation folded in).
+extern "C" int stokes_op_pencil_sweep_pressure(stokes_op *op, int nvel, long ncol, double *in, double *out, void *stream) {
+  ARGCHK(op && in && out);
+  if (nvel < 1 || ncol < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad pencil geometry");
+  if (ncol == 0) return 0;
+  const size_t Np = (size_t)op->gP0 * (size_t)ncol;
+  if (op->pext) {
+    const DiffMat *m[2] = {&op->mats[op->gP0], &op->matsP[op->gP0]};
+    SweepParams sp[2] = {};
+    sp[0].ncols = (unsigned)(nvel * ncol); sp[0].inner = (unsigned)ncol;
+    sp[0].in0 = in; sp[0].in_mode = IN_PLAIN; sp[0].out = out; sp[0].out_mode = OUT_STORE; sp[0].alpha = 1.0;
+    sp[1].ncols = (unsigned)ncol; sp[1].inner = (unsigned)ncol;
+    sp[1].in0 = in + (size_t)nvel * Np; sp[1].in_mode = IN_PLAIN; sp[1].out = out + (size_t)nvel * Np; sp[1].out_mode = OUT_STORE; sp[1].alpha = 1.0;
+    SHIPCHK(sweep_launch_multi(2, m, sp, (hipStream_t)stream));      // (one launch where the 16-byte kernels run, else one each)
+    return 0;
+  }
+  int rc = stokes_op_pencil_sweep(op, nvel, ncol, in, out, stream); if (rc) return rc;
+  return stokes_op_pencil_pressure(op, ncol, in + (size_t)nvel * Np, out + (size_t)nvel * Np, stream);
+}
 extern "C" int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil, double *gp0_pencil, void *stream) {
   ARGCHK(op && p_pencil && gp0_pencil);
   if (ncol <= 0) return ncol == 0 ? 0 : chebhip_fail(CHEBHIP_ERR_ARG, "bad pencil geometry");
