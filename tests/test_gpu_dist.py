@@ -310,6 +310,14 @@ def _distc_worker(rank, world, port, dims, q, backend):
         Ul = torch.from_numpy(U[lo:lo + n].copy()).cuda(); Vl = torch.full_like(Ul, float("nan"))
         for _ in range(3):                       # repeated applies: buffers and events are reused correctly
             op.mult(Ul, Vl)
+        if backend == "nccl":
+            # chebhip_dist_mult_batch on the REAL transport: three vectors per exchange = three ncclSend / ncclRecv pairs per peer in
+            # ONE group (here the peer is the rank itself: rccl_self_messages) -- the message pattern of a batched multi-GPU run
+            Ub = torch.stack([Ul, 2.0 * Ul, -Ul]).contiguous(); Vb = torch.full_like(Ub, float("nan"))
+            op.mult_batch(Ub, Vb); op.mult_batch(Ub, Vb)
+            torch.cuda.synchronize()
+            for q_, f in enumerate((1.0, 2.0, -1.0)):
+                assert float((Vb[q_] - f * Vl).abs().max()) <= 1e-12 * float(Vl.abs().max()), q_
         # Krylov on slabs with the C-side reduction where there is one (RCCL), else torch's
         b = torch.from_numpy(np.random.default_rng(SEED + 1).standard_normal(G)[lo:lo + n].copy()).cuda(); x = torch.empty_like(b)
         ks = sp.Fgmres(n, restart=60, rtol=1e-11, max_it=3000)
