@@ -253,6 +253,71 @@ __device__ void gs_norm_and_givens(int j, int m, const double *hcol, const doubl
   }
   givens_column(j, m, hcol, hn, H, cs, sn, G, res);
 }
+// Block versions for the last workgroup of k_gs_dots / k_gs_update.  A serial finish is a chain of dependent global round trips (one per
+// entry of the column: hcol, rn, cs, sn, G) on the critical path of every iteration; here every thread fetches one entry into LDS and
+// thread 0 does the arithmetic out of LDS, in the same order as the serial versions (the same bits).  GSF = entries of a column + 2.
+constexpr int GSF = RT + 4;
+struct GsShared { double a[GSF], b[GSF], c[GSF], d[GSF]; };
+__device__ void gs_coefficients_block(int k, double *hcol, double *coef, const double *rn, double *scal, GsShared &S) {
+  for (int i = threadIdx.x; i <= k; i += blockDim.x) { S.a[i] = hcol[i]; if (i < k) S.b[i] = rn[i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += blockDim.x) { const double h = S.a[i] / S.b[i]; hcol[i] = h; coef[i] = h / S.b[i]; S.a[i] = h; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ww = S.a[k];
+    double ssq = 0.0;
+    for (int i = 0; i < k; i++) ssq += S.a[i] * S.a[i];
+    double e2 = ww - ssq;
+    if (!(e2 >= 1.0e-12 * ww)) e2 = 1.0e-12 * ww;
+    scal[0] = ww;
+    scal[1] = (e2 > 0.0 && e2 <= 1.7976931348623157e308) ? 1.0 / sqrt(e2) : 0.0;
+    S.d[0] = ww; S.d[1] = scal[1];                         // (for a Givens step that follows in the same kernel)
+  }
+  __syncthreads();
+}
+// S.a[0..j] must hold column j of H before the rotations (h[kk]); ww / f in S.d[0..1] or read from scal
+__device__ void gs_norm_and_givens_block(int j, int m, const double *hcol, bool col_in_lds, double ww, double f, double nsq, int est, double *rn,
+                                         double *H, double *cs, double *sn, double *G, double *res, GsShared &S) {
+  const double *g0 = G + (long)j * (m + 2);
+  for (int i = threadIdx.x; i <= j; i += blockDim.x) {
+    if (!col_in_lds) S.a[i] = hcol[i];
+    S.c[i] = g0[i];
+    if (i < j) { S.b[i] = cs[i]; S.d[i + 2] = sn[i]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double hn;
+    if (est) hn = f > 0.0 ? 1.0 / f : (ww == 0.0 ? 0.0 : nan(""));
+    else {
+      const double r = sqrt(nsq);
+      rn[j + 1] = (r > 0.0 && r <= 1.7976931348623157e308) ? r : 1.0;
+      hn = f > 0.0 ? r / f : (ww == 0.0 ? 0.0 : nan(""));
+    }
+    S.a[j + 1] = hn;
+    for (int i = 0; i < j; i++) {
+      const double t = S.b[i] * S.a[i] + S.d[i + 2] * S.a[i + 1];
+      S.a[i + 1] = -S.d[i + 2] * S.a[i] + S.b[i] * S.a[i + 1]; S.a[i] = t;
+    }
+    const double den = hypot(S.a[j], S.a[j + 1]);
+    if (den == 0.0 || !(den == den)) { res[j] = nan(""); S.d[0] = 0.0; }
+    else {
+      const double c = S.a[j] / den, s_ = S.a[j + 1] / den;
+      cs[j] = c; sn[j] = s_;
+      S.a[j] = den; S.a[j + 1] = 0.0;
+      const double gj = S.c[j];
+      S.c[j] = c * gj; S.c[j + 1] = -s_ * gj;
+      res[j] = fabs(S.c[j + 1]);
+      S.d[0] = 1.0;
+    }
+  }
+  __syncthreads();
+  double *hc = H + (long)j * (m + 1), *g1 = G + (long)(j + 1) * (m + 2);
+  const bool ok = S.d[0] != 0.0;
+  for (int i = threadIdx.x; i <= j + 1; i += blockDim.x) {
+    hc[i] = S.a[i];
+    if (i < j || ok) g1[i] = S.c[i];                       // (breakdown: as the serial version, only the first j entries are copied)
+  }
+}
 // The LAST block to arrive (device-scope ticket: no block ever waits for another) sums the 256 partials of `rows` rows in a fixed order
 // (wave q of 16 takes rows q, q + 16, ..; a lane adds its four partials in order, then the wave tree) into out[0..rows-1].
 // Every partial was written before its writer's ticket, and every ticket before this block's.
@@ -311,19 +376,34 @@ __global__ __launch_bounds__(ST) void k_gs_dots(long n, int k, const double *__r
       for (int q = 0; q < KB; q++) if (q < cnt) s[q] += v[q][i] * wi;
     }
   }
+  // the KB block sums with ONE barrier (wave trees, the 16 wave sums of every row through LDS, row q finished by thread q in the
+  // order block_sum_t uses: the same bits) instead of KB reductions of two barriers each -- on the 6-MB vectors of a 64^3 Schur
+  // solve the kernel is all latency
+  {
+    __shared__ double shq[KB][ST / 64];
+    const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
 #pragma unroll
-  for (int q = 0; q < KB; q++) {
-    const double r = block_sum_t<ST>(s[q], sh);
-    if (threadIdx.x == 0 && q < cnt) __hip_atomic_store(part + (long)(kk0 + q) * RB + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < KB; q++) {
+      double v = s[q];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane_ == 0) shq[q][w_] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)cnt) {
+      double r = 0.0;
+      for (int w2 = 0; w2 < ST / 64; w2++) r += shq[threadIdx.x][w2];
+      __hip_atomic_store(part + (long)(kk0 + threadIdx.x) * RB + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                      // thread 0 takes the ticket after every row's store has been issued ...
+    (void)sh;
   }
   if (!gs_last_block(ticket, (int)(gridDim.x * gridDim.y), &last)) return;
   gs_row_sums(part, rows, hcol);
-  if (threadIdx.x == 0) {
-    *ticket = 0;
-    if (finish) {
-      gs_coefficients(k, hcol, coef, rn, scal);
-      if (finish == 2) gs_norm_and_givens(j, m, hcol, scal, 0.0, 1, rn, H, cs, sn, G, res);
-    }
+  if (threadIdx.x == 0) *ticket = 0;
+  if (finish) {
+    __shared__ GsShared S;
+    gs_coefficients_block(k, hcol, coef, rn, scal, S);
+    if (finish == 2) gs_norm_and_givens_block(j, m, hcol, true, S.d[0], S.d[1], 0.0, 1, rn, H, cs, sn, G, res, S);
   }
 }
 // several ranks: hcol[0..k] / nsq have been summed over the ranks by the reduction callback
@@ -384,9 +464,10 @@ __global__ __launch_bounds__(ST) void k_gs_update(long n, int k, const double *_
   if (threadIdx.x == 0) __hip_atomic_store(npart + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!gs_last_block(ticket, (int)gridDim.x, &last)) return;
   gs_row_sums(npart, 1, nsq);
-  if (threadIdx.x == 0) {
-    *ticket = 0;
-    if (finish) gs_norm_and_givens(j, m, hcol, scal, nsq[0], 0, rn, H, cs, sn, G, res);
+  if (threadIdx.x == 0) *ticket = 0;
+  if (finish) {
+    __shared__ GsShared S;
+    gs_norm_and_givens_block(j, m, hcol, false, scal[0], scal[1], nsq[0], 0, rn, H, cs, sn, G, res, S);
   }
 }
 
