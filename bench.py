@@ -85,11 +85,16 @@ def launch_selftest(args, world, rank):
     backend = os.environ.get("BENCH_DIST_BACKEND", "gloo")
     if backend == "nccl":
         raise SystemExit("--launch-selftest is a CPU check of the launcher: BENCH_DIST_BACKEND=gloo")
+    wd = Watchdog(rank)
+    wd.enter("--launch-selftest: rendezvous and one all-reduce", int(os.environ.get("BENCH_WATCHDOG_S", "600")))
     if world > 1:
         dist.init_process_group(backend=backend)
+    if os.environ.get("BENCH_SELFTEST_HANG_RANK", "") == str(rank):     # tests/test_bench_launch.py: a rank that never joins the collective
+        time.sleep(1e6)
     t = torch.tensor([rank + 1], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(t)
+    wd.leave()
     if rank == 0:
         print(json.dumps({"launch_selftest": True, "n_gpus": world, "rank_sum": int(t.item()), "backend": backend,
                           "spawned_by_bench": "BENCH_SPAWNED_BY" in os.environ}), flush=True)
@@ -97,6 +102,66 @@ def launch_selftest(args, world, rank):
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+class Watchdog:
+    """N > 1 only: a rank that sits in a collective its peers never join (first RCCL contact, a peer that died) would hang until the
+    caller's own limit kills it without a trace.  After `seconds` in one phase this prints which phase it was and ends the process
+    with status 3 -- never 0: a hang must not read as success.  (No re-exec, no signal: os._exit from a timer thread.)"""
+
+    def __init__(self, rank):
+        self.rank, self.timer, self.phase = rank, None, None
+
+    def enter(self, phase, seconds):
+        import threading
+        self.leave()
+        self.phase = phase
+
+        def fire():
+            print("bench.py: WATCHDOG -- rank %d: %s did not return within %d s; ending this rank with status 3" % (self.rank, phase, seconds),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        self.timer = threading.Timer(float(seconds), fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def leave(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+def roofline_record(P, world, steps, dev_ms, launches_per_step, traffic):
+    """The `roofline` object of the line.
+    N = 1: the dominant kernel is cheb_sweep_vec4_kernel, 3 launches per matvec, one per direction (each replaces 2 of the reference's 6
+    ChebMult + its share of the vector passes) on torch's current stream, timed with HIP events around the K steps; algorithmic bytes per
+    launch = 112 P^3 / 3.
+    N > 1: a step is pack + the slab launch + exchange + the pencil launch + exchange + the final sum: there is no dominant kernel's launch
+    to price, so the object prices the whole STEP of one GPU (its share of the algorithmic bytes and of the flops over the step time) and
+    the per-launch fields are null.
+    bound: the resource that binds at this size -- FP64 MFMA at P = 256 ((P-2) flop/point per direction against 8-24 B/point), HBM
+    at P <= 128.  achieved / peak / frac stay the figure BASELINE.json's metric names ("GB/s vs HBM roofline": SURVEY 8(d) algorithmic bytes
+    over time); mfma_f64_frac is the binding one at 256."""
+    npts = float(P) ** 3
+    step_s = (dev_ms * 1e-3) / steps
+    per_launch = world == 1
+    unit_s = step_s / launches_per_step if per_launch else step_s
+    alg_bytes = BYTES_PER_POINT * npts / (launches_per_step if per_launch else 1) / world
+    achieved = alg_bytes / unit_s
+    # FP64 MFMA work actually issued: one (P-2)-point even/odd product per direction: 2 (P/2)^2 x 2 halves per line = (P-2) flop/point
+    flops = float(P - 2) * (float(P - 2) ** 3) / world * (1.0 if per_launch else 3.0)
+    return {"bound": "mfma" if P > 128 else "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "frac_is": "model figure of merit: SURVEY 8(d) algorithmic bytes (112 B/point) / time / 8 TB/s, not bytes moved; the binding resource is `bound`: see mfma_f64_frac (FP64 MFMA issued / 78.6 TF) and hbm_real_frac (bytes moved / time / 8 TB/s)",
+            "hbm_real_frac": (traffic / unit_s / HBM_PEAK) if traffic else None,
+            "kernel": "cheb_sweep_vec4_kernel" if per_launch else
+                      "slab route, whole step of one GPU: k_pack, cheb_sweep_multi_kernel (local directions on the slab), cheb_sweep_vec4_kernel (pencil), k_combine, 2 exchanges",
+            "priced_per": "launch" if per_launch else "step of one GPU",
+            "launches_per_step": launches_per_step, "exchanges_per_step": 0 if per_launch else 2,
+            "avg_launch_us": unit_s * 1e6 if per_launch else None, "step_us": step_s * 1e6,
+            "algorithmic_bytes_per_launch": alg_bytes if per_launch else None,
+            "algorithmic_bytes_per_gpu_step": alg_bytes * (launches_per_step if per_launch else 1),
+            "mfma_f64_tflops": flops / unit_s / 1e12, "mfma_f64_frac": flops / unit_s / FP64_MFMA_PEAK}
 
 
 def csrc_hash():
@@ -534,6 +599,10 @@ def main():
 
     P = args.size
     dims = (P, P, P)
+    wd = Watchdog(rank)
+    wd_s = int(os.environ.get("BENCH_WATCHDOG_S", "600"))
+    if world > 1:
+        wd.enter("transport setup and the reduced-size parity check of the %d-rank matvec" % world, wd_s)
     if world == 1:
         op = sp.EllipticOp(dims)
         g = torch.Generator(device="cuda").manual_seed(SEED)
@@ -567,8 +636,10 @@ def main():
         U = op.random_input(SEED)
         V = torch.empty_like(U)
         step = lambda: op.mult(U, V)
-        launches_per_step = 3
+        # pack, the local directions (ONE launch of d - 1 jobs on a slab of fewer than 6 M values, csrc/dist.hip), the pencil launch, the final sum
+        launches_per_step = 4 if getattr(op, "local_size", 0) < 6000000 else 5
         parallelism = "slab%d+all2all(%s, %s)" % (world, "C host" if impl == "c" else "python host", backend)
+        wd.enter("spin-up, warm-up and the %d timed steps of the %d-rank matvec" % (args.steps, world), wd_s)
 
     def barrier():
         torch.cuda.synchronize()
@@ -598,31 +669,22 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = t.item()
+    wd.leave()
     assert torch.isfinite(V).all()
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = args.steps / wall
         npts = float(P) ** 3
-        # dominant kernel: 3 launches per matvec, one per direction (each replaces 2 of the reference's
-        # 6 ChebMult + its share of the vector passes) on torch's current stream, timed with HIP events
-        # around the K steps; algorithmic bytes per launch = 112*P^3/3
-        launch_s = (dev_ms * 1e-3) / (args.steps * launches_per_step)
-        alg_bytes_launch = BYTES_PER_POINT * npts / launches_per_step / world
-        achieved = alg_bytes_launch / launch_s
-        two_stage = False                                   # (the two-stage A/B path of rounds 1-2 is gone: one kernel per state)
         # HBM bytes per launch from the committed PMC profile -- only if it was taken on the very kernel sources
         # being timed (hash of csrc/), otherwise null
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if (tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step and not two_stage
+            if (tj.get("P") == P and world == 1 and tj.get("launches_per_matvec") == launches_per_step
                     and tj.get("csrc_sha256") == csrc_hash()):
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        # FP64 MFMA work actually issued: constant-coefficient path = one (P-2)-point even/odd product per
-        # direction ((P-2) flop/point); two-stage path = two P-point products per direction (2P flop/point)
-        flops_launch = ((2.0 * P) if two_stage else float(P - 2)) * (float(P - 2) ** 3) / world     # 2 * (P/2)^2 * 2 halves per line of P points = P flop/point
         out = {
             "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
             "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
@@ -630,17 +692,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D Poisson MatMult_Elliptic -dim %d,%d,%d (gamma=0), global N(0,1) input seed %d" % (P, P, P, SEED),
                        "P": P, "parallelism": parallelism, "launches_per_step": launches_per_step},
-            # bound: the resource that binds the dominant kernel at this size -- FP64 MFMA at P = 256 ((P-2) flop/point per launch
-            # against 8-24 B/point), HBM at P <= 128.  achieved / peak / frac stay the figure BASELINE.json's metric
-            # names ("GB/s vs HBM roofline": SURVEY 8(d) algorithmic bytes over time); mfma_f64_frac is the binding one at 256.
-            "roofline": {"bound": "mfma" if P > 128 else "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "frac_is": "model figure of merit: SURVEY 8(d) algorithmic bytes (112 B/point) / time / 8 TB/s, not bytes moved; the binding resource is `bound`: see mfma_f64_frac (FP64 MFMA issued / 78.6 TF) and hbm_real_frac (bytes moved / time / 8 TB/s)",
-                         "hbm_real_frac": (traffic / launch_s / HBM_PEAK) if traffic else None,
-                         "kernel": "cheb_fused_kernel" if two_stage else "cheb_sweep_vec4_kernel", "avg_launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "mfma_f64_tflops": flops_launch / launch_s / 1e12,
-                         "mfma_f64_frac": flops_launch / launch_s / FP64_MFMA_PEAK},
+            "roofline": roofline_record(P, world, args.steps, dev_ms, launches_per_step, traffic),
             "device_ms_per_step": dev_ms / args.steps,
         }
         if world > 1:
@@ -688,16 +740,24 @@ def main():
                 out["dist_rank_compute"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
-        # After the line has left (nothing below can cost it): the same matvec on 4 vectors per exchange (chebhip_dist_mult_batch), reported
-        # on stderr.  The RCCL peer path of this library has never met more than one rank on hardware (no multi-GPU box for the builder), so
-        # a watchdog ends the process if this informational leg -- or the final barrier -- does not return.
-        import threading
-        wd = threading.Timer(180.0, lambda: os._exit(0)); wd.daemon = True; wd.start()
+        # After the line has left (nothing below can cost it), opt-in (BENCH_BATCHED=1): the same matvec on 4 vectors per exchange
+        # (chebhip_dist_mult_batch), reported on stderr.  The ranks agree on an error flag after the first batched call, so a rank that
+        # failed does not leave its peers in a collective; a leg -- or a final barrier -- that does not return ends under the watchdog
+        # with a diagnostic and a NON-ZERO status.
         batched = None
-        if hasattr(op, "mult_batch") and os.environ.get("BENCH_NO_BATCHED", "0") != "1":
+        if hasattr(op, "mult_batch") and os.environ.get("BENCH_BATCHED", "0") == "1":
+            wd.enter("the informational batched leg (BENCH_BATCHED=1: 4 vectors per exchange)", min(wd_s, 180))
+            nrhs = 4
+            err = None
             try:
-                nrhs = 4
                 Ub = torch.stack([U] * nrhs).contiguous(); Vb = torch.empty_like(Ub)
+                op.mult_batch(Ub, Vb)
+                torch.cuda.synchronize()
+            except Exception as e:
+                err = repr(e)[:200]
+            if not _all_ok(err is None, dist, torch, backend):
+                batched = {"error": err or "failed on another rank"}
+            else:
                 kb = max(args.steps // nrhs, 2)
                 for _ in range(max(args.warmup // nrhs, 2)):
                     op.mult_batch(Ub, Vb)
@@ -710,13 +770,12 @@ def main():
                 dist.all_reduce(tb, op=dist.ReduceOp.MAX)
                 batched = {"nrhs": nrhs, "steps": kb, "matvecs_per_s": kb * nrhs / tb.item(), "ms_per_batch": tb.item() * 1e3 / kb,
                            "vectors_agree": bool(torch.equal(Vb[0], Vb[nrhs - 1]))}
-            except Exception as e:
-                batched = {"error": repr(e)[:200]}
-        if rank == 0:
-            print("bench.py (informational, not part of the line): %d vectors per exchange: %s" % (4, json.dumps(batched)), file=sys.stderr, flush=True)
+            if rank == 0:
+                print("bench.py (informational, not part of the line): %d vectors per exchange: %s" % (nrhs, json.dumps(batched)), file=sys.stderr, flush=True)
+        wd.enter("the final barrier", 120)
         dist.barrier()
         dist.destroy_process_group()
-        wd.cancel()
+        wd.leave()
 
 
 if __name__ == "__main__":

@@ -119,17 +119,19 @@ struct chebhip_dist {
   Split split;
 };
 
+static void dist_work_free(chebhip_dist::Work *W) {
+  if (!W) return;
+  for (auto p : W->slab_plan) if (p) cheb_plan_destroy(p);
+  if (W->pencil_plan) cheb_plan_destroy(W->pencil_plan);
+  for (auto p : W->A) if (p) (void)hipFree(p);
+  double *all[] = {W->sendbuf, W->recvbuf, W->UT, W->TT};
+  for (double *p : all) if (p) (void)hipFree(p);
+  delete W;
+}
+
 extern "C" int chebhip_dist_destroy(chebhip_dist *D) {
   if (!D) return 0;
-  for (auto &kv : D->w) {
-    chebhip_dist::Work *W = kv.second;
-    for (auto p : W->slab_plan) if (p) cheb_plan_destroy(p);
-    if (W->pencil_plan) cheb_plan_destroy(W->pencil_plan);
-    for (auto p : W->A) if (p) (void)hipFree(p);
-    double *all[] = {W->sendbuf, W->recvbuf, W->UT, W->TT};
-    for (double *p : all) if (p) (void)hipFree(p);
-    delete W;
-  }
+  for (auto &kv : D->w) dist_work_free(kv.second);
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->ev_in) (void)hipEventDestroy(D->ev_in);
   if (D->ev_out) (void)hipEventDestroy(D->ev_out);
@@ -138,14 +140,9 @@ extern "C" int chebhip_dist_destroy(chebhip_dist *D) {
   return 0;
 }
 
-// the work set for `nrhs` vectors per call (made on first use)
-static int dist_work(chebhip_dist *D, int nrhs, chebhip_dist::Work **out) {
-  auto it = D->w.find(nrhs);
-  if (it != D->w.end()) { if (out) *out = it->second; return 0; }
-  chebhip_dist::Work *W = new (std::nothrow) chebhip_dist::Work;
-  if (!W) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+// builds the work set for `nrhs` vectors; on any failure everything made so far is released and nothing is kept
+static int dist_work_build(chebhip_dist *D, int nrhs, chebhip_dist::Work *W) {
   W->nrhs = nrhs;
-  D->w[nrhs] = W;                                  // (owned by the handle from here on: chebhip_dist_destroy frees what exists)
   const int d = D->d, rank = D->rank;
   if ((double)D->local * nrhs > 2.0e9 || (double)D->pencil * nrhs > 2.0e9) return chebhip_fail(CHEBHIP_ERR_DIMS, "batch of %d vectors: more than 2^31 values per rank", nrhs);
   {  // plans on the stored (interior) tensors: slabs (nrhs m0, M1, M2..), pencils (nrhs, M0, m1, M2..)
@@ -162,6 +159,20 @@ static int dist_work(chebhip_dist *D, int nrhs, chebhip_dist::Work **out) {
   for (int k = 0; k < d - 1; k++) DHIPCHK(hipMalloc((void **)&W->A[k], lb));
   DHIPCHK(hipMalloc((void **)&W->sendbuf, lb)); DHIPCHK(hipMalloc((void **)&W->recvbuf, lb));
   DHIPCHK(hipMalloc((void **)&W->UT, pb)); DHIPCHK(hipMalloc((void **)&W->TT, pb));
+  return 0;
+}
+
+// the work set for `nrhs` vectors per call (made on first use).  It enters the handle's map only when it is COMPLETE: a set whose
+// size check, plans or allocations failed is released at once, so that a later call with the same nrhs starts from nothing instead
+// of finding a half-built entry (an out-of-memory failure followed by a retry would have launched on NULL buffers).
+static int dist_work(chebhip_dist *D, int nrhs, chebhip_dist::Work **out) {
+  auto it = D->w.find(nrhs);
+  if (it != D->w.end()) { if (out) *out = it->second; return 0; }
+  chebhip_dist::Work *W = new (std::nothrow) chebhip_dist::Work;
+  if (!W) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  const int rc = dist_work_build(D, nrhs, W);
+  if (rc) { dist_work_free(W); return rc; }
+  D->w[nrhs] = W;
   if (out) *out = W;
   return 0;
 }

@@ -11,7 +11,11 @@
 // Round 5: ONE reduction per Gram-Schmidt step (k_gs_dots / k_gs_update below): w.w is taken in the same pass as V^T w and
 // w.w - |h|^2 ~ h_{j+1,j}^2 supplies the scale of the new vector, so that the update and the normalisation are one pass over the
 // basis and the step is two launches instead of three; the stored vector's exact norm comes out of that pass and is carried beside
-// it (gs_coefficients), so nothing rests on the cancelling difference.  Option "krylov_exact_norm" = 1: the three-launch step.
+// it (gs_coefficients), so nothing of a cycle's interior rests on the cancelling difference.  The ONE place that does: the last column a
+// cycle can take (the end of the restart, or the iteration limit) runs no update pass, and its h_{j+1,j} IS sqrt(w.w - |h|^2), whose
+// error is (orthogonality loss) x w.w -- after 30-60 vectors the residual estimate of that column can read low.  Convergence read off
+// such a column is therefore never returned as it stands: the true residual b - A x is formed first (the top of the cycle loop) and
+// decides.  Option "krylov_exact_norm" = 1: the three-launch step (every column's norm exact).
 #include "../../include/chebhip.h"
 #include "timers.h"
 #include "sweep.h"
@@ -321,9 +325,20 @@ __device__ void gs_norm_and_givens_block(int j, int m, const double *hcol, bool 
 // The LAST block to arrive (device-scope ticket: no block ever waits for another) sums the 256 partials of `rows` rows in a fixed order
 // (wave q of 16 takes rows q, q + 16, ..; a lane adds its four partials in order, then the wave tree) into out[0..rows-1].
 // Every partial was written before its writer's ticket, and every ticket before this block's.
+//
+// The premises of this fence-free form -- change any of them and the ticket must become an
+// __ATOMIC_ACQ_REL one (with the L2 write-back it implies):
+//   (1) every partial is stored by a lane of WAVE 0, the wave of the ticket-taking thread 0: s_waitcnt is a per-wave counter, so
+//       thread 0's wait covers exactly the stores of its own wave (k_gs_dots: threads 0 .. cnt-1 <= KB-1; k_gs_update: thread 0);
+//   (2) gfx942 / gfx950 count stores in vmcnt (gfx10+ has a separate vscnt, which s_waitcnt(0) would not drain), and their agent-scope
+//       (sc1) stores write through to memory while agent-scope loads bypass the non-coherent caches.
+static_assert(KB <= 64, "k_gs_dots: the partials of a block must all be stored by lanes of wave 0 (threads 0 .. KB-1), see gs_last_block");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "krylov.hip: the fence-free last-block ticket is valid on gfx942 / gfx950 only (stores counted in vmcnt): use an acq_rel ticket on other targets"
+#endif
 __device__ __forceinline__ bool gs_last_block(int *ticket, int nblocks, int *sh_last) {
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_s_waitcnt(0);                    // this thread's agent-scope stores of its partials have been acknowledged
+    __builtin_amdgcn_s_waitcnt(0);                    // wave 0's agent-scope stores of the partials have been acknowledged (premise 1)
     *sh_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
   }
   __syncthreads();
@@ -729,6 +744,8 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
       if (j >= 1) { KHIPCHK(hipEventSynchronize(k->ev[j - 1])); examine(j - 1); }
     }
     if (!stop && enq > 0) { KHIPCHK(hipEventSynchronize(k->ev[enq - 1])); examine(enq - 1); }
+    // was the last accepted column one whose h_{j+1,j} is the one-pass estimate (no update pass: `use_next` = 0 above)?
+    const bool last_est = !k->exact && kk > 0 && !(kk < m && k->its + kk < k->max_it);
     k->its += kk;
     // y = R^{-1} g (leading kk columns, right-hand side G_kk), x += Z y
     if (kk > 0) {
@@ -738,8 +755,9 @@ extern "C" int chebhip_fgmres_solve(chebhip_fgmres *k, chebhip_apply_fn A, void 
     }
     KHIPCHK(hipStreamSynchronize(st));      // a speculative iteration may still be running: drain before V is reused
     if (k->reason == -9) return clear_x();
-    if (k->rnorm <= tol) { k->reason = k->rnorm <= k->atol ? 3 : 2; return clear_x(); }
-    if (k->its >= k->max_it) { k->reason = -3; return clear_x(); }
+    // convergence read off an estimated column is checked on the true residual (top of the loop: converged, iteration limit, or on)
+    if (k->rnorm <= tol && !last_est) { k->reason = k->rnorm <= k->atol ? 3 : 2; return clear_x(); }
+    if (k->its >= k->max_it && !(k->rnorm <= tol)) { k->reason = -3; return clear_x(); }
     // otherwise restart: the true residual is recomputed at the top
   }
 }

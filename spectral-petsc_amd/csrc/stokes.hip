@@ -1184,12 +1184,17 @@ extern "C" int stokes_op_set_force(stokes_op *op, const double *force) {
 }
 
 // ---- building blocks ------------------------------------------------------------------------
-// Diagnostic (tools/stokes_ablate.py; not in the header): launches of the 128^3 callbacks left out one at a time -- results are wrong,
-// the timings give each launch's MARGINAL cost in the pipelined callback (a profiler serialises the launches and both streams).
+// Diagnostic builds only (-DCHEBHIP_DIAG: `make diag` -> tools/libchebhip_diag.so, tools/stokes_ablate.py; the shipped library has
+// neither the symbol nor the tests): launches of the 128^3 callbacks left out one at a time -- results are wrong, the timings give
+// each launch's MARGINAL cost in the pipelined callback (a profiler serialises the launches and both streams).
 // bit 0 gather, 1 x/y gradient, 2 fused z launch, 3 x/y divergence, 4 scatter, 5 pressure chain
+#ifdef CHEBHIP_DIAG
 static int g_st_ablate = 0;
 extern "C" void chebhip_debug_stokes_ablate(int mask) { g_st_ablate = mask; }
 #define ST_ABL(bit) (g_st_ablate & (1 << (bit)))
+#else
+#define ST_ABL(bit) 0
+#endif
 // DP[k] (scalar field) or DV[k] (d stacked fields: same lines, d times as many)
 static int sweep_plain(stokes_op *op, bool vec, int k, const double *x, double *y, int out_mode, const double *acc,
                        double alpha, hipStream_t st, bool pext = false) {       // pext: the pressure matrices (stokes_op::matsP)

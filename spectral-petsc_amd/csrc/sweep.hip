@@ -499,8 +499,8 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   }
   {
     if (!opt(OPT_GENERAL_KERNELS) && sweep_vec_eligible(m, p)) {
-      // diagnostic builds: three stamp areas of 256 x 8 x 8 words, used round-robin (one per launch of a 3-D matvec)
-      if (chebhip_stamp_buf()) p.in4 = chebhip_stamp_buf() + (size_t)(chebhip_stamp_next() % 3) * (256 * 8 * 8);
+      // diagnostic builds: three stamp areas of 256 x 8 x 16 words, used round-robin (one per launch of a 3-D matvec)
+      if (chebhip_stamp_buf()) p.in4 = chebhip_stamp_buf() + (size_t)(chebhip_stamp_next() % 3) * (256 * 8 * 16);
       return sweep_vec_launch(m, p, stream);
     }
   }

@@ -345,7 +345,7 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
 #ifdef CHEB_STAMPS
   STAMP(st_end);
   if (lane == 0 && p.in4) {
-    unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 8;
+    unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 16;
     dbg[0] = st_pre; dbg[1] = st_chain; dbg[2] = st_post; dbg[3] = st_bar;
     dbg[4] = st_loop - st_begin; dbg[5] = st_end - st_loop; dbg[6] = st_begin; dbg[7] = st_end;
   }
@@ -405,6 +405,17 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p
 #ifndef V4_STORE_AUX
 #define V4_STORE_AUX 0
 #endif
+// 1 (shipped): the matrix fragments are requested in the order the chains consume them and the first tile's chains
+// start on the k-steps that have landed (no wait for the whole set); 0: the round 2-5 prologue (rotated fetch order,
+// vmcnt(0) before the first tile) -- kept for the A/B builds of tools/v4_overlap_ab.sh
+#ifndef V4_OVERLAP
+#define V4_OVERLAP 1
+#endif
+// fragment pairs requested ahead of the first tile's first chain; the rest is requested INSIDE that chain, one pair
+// per MFMA group, V4_FRAG_AHEAD groups ahead of its use (KS / 2 and more: all of them up front)
+#ifndef V4_FRAG_AHEAD
+#define V4_FRAG_AHEAD 2
+#endif
 
 // MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 3 = ACC2 (out = (acc + acc2) + alpha r, KS = 16 only), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
 // preconditioner's fast diagonalisation folded into its last forward transform -- RAW = 1 only)
@@ -437,7 +448,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   static_assert(KS >= 16 && CH >= 1, "v4 needs two sub-tiles per tile");
 
 #ifdef CHEB_STAMPS
-  unsigned long long st_seg[5] = {0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0, st_loop = 0;   // diagnostic build only (tools/stamp_probe3.py)
+  unsigned long long st_seg[5] = {0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0, st_loop = 0, st_first = 0;   // diagnostic build only (tools/stamp_probe3.py)
   const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();                     // 100 MHz: the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz
 #endif
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -595,6 +606,44 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   if (tile >= t_hi) return;                            // whole workgroup: no barrier is skipped by part of it
   // the first tile's lines are requested BEFORE the matrix fragments: one memory round trip instead of two
   issue_loads(tile, true, 0, rjA, rmA); issue_loads(tile, true, 1, rjB, rmB);
+  // The matrix halves: 256 KiB per CU at P = 256.  A CU reads from its L2 at ~25-30 B/clk (MI355X_MICROARCH.md "Indexed
+  // rows": 66-73 GB/s per CU), so the set takes ~10-12 k cycles however it is asked for, and a wave that asks for all of
+  // it at once sits in the ISSUE of those loads for that long (in-kernel stamps, profiles/r06_prologue_stamps.txt: the
+  // 36 requests of a wave were issued after 11.6 k cycles, landed after 12.1 k) -- longer than an MFMA chain.  So the
+  // fetch is PACED: up front only what the first chain's first groups need (FA pairs) and the odd-half fragments that
+  // live in LDS (their ds_write needs them early; temporaries that are dead before the tile loop), behind the first
+  // tile's lines; the other pairs are requested inside the first tile's first chain, one pair per MFMA group, FA groups
+  // ahead of their use.  The first tile is a peeled copy of the loop body (`run`): in its straight-line code hipcc counts
+  // vmcnt exactly, so MFMA group g waits for pair g only.  (Rounds 2-5, V4_OVERLAP = 0: everything up front in a rotated
+  // order per CU, vmcnt(0).)
+  constexpr int FA = (V4_FRAG_AHEAD < KS / 2) ? V4_FRAG_AHEAD : KS / 2;
+  // pair g of both halves -> registers (the odd half's LDS-resident members have been dealt with up front)
+  auto frag_pair = [&](int g) {
+    const d2 ve = ((const d2 *)p.fragE2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+    ae[2 * g] = ve.x; ae[2 * g + 1] = ve.y;
+    if (2 * g + 1 < KR) {
+      const d2 vo = ((const d2 *)p.fragO2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+      ao[2 * g] = vo.x; ao[2 * g + 1] = vo.y;
+    }
+  };
+  if constexpr (V4_OVERLAP != 0) {
+    constexpr int GL = KR / 2;                         // first pair with an LDS-resident member
+    constexpr int NTL = (NFL > 0) ? KS / 2 - GL : 1;
+    d2 tl[NTL];
+    if constexpr (NFL > 0) {
+#pragma unroll
+      for (int g = GL; g < KS / 2; g++) tl[g - GL] = ((const d2 *)p.fragO2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
+    }
+#pragma unroll
+    for (int g = 0; g < FA; g++) frag_pair(g);
+    if constexpr (NFL > 0) {
+#pragma unroll
+      for (int g = GL; g < KS / 2; g++) {
+        if (2 * g >= KR) aoL[(2 * g - KR) * 64] = tl[g - GL].x; else ao[2 * g] = tl[g - GL].x;
+        if (2 * g + 1 >= KR) aoL[(2 * g + 1 - KR) * 64] = tl[g - GL].y; else ao[2 * g + 1] = tl[g - GL].y;
+      }
+    }
+  } else {
   // Every workgroup of the chip fetches the same 256 KiB at the same moment.  The CUs of an XCD start at four
   // different places of their fragment sets (a static rotation per code path: the registers are fixed), which
   // spreads the requests over the L2 channels instead of queueing them on one line at a time.
@@ -602,7 +651,6 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     constexpr int ROT = decltype(ROT_)::value;
 #pragma unroll
     for (int g0 = 0; g0 < KS / 2; g0++) {              // two fragments per 16-byte load
-      constexpr int dummy = 0; (void)dummy;
       const int g = (g0 + ROT) % (KS / 2);
       const d2 ve = ((const d2 *)p.fragE2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
       const d2 vo = ((const d2 *)p.fragO2)[((long)(mt * (KS / 2) + g)) * 64 + lane];
@@ -618,6 +666,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     default: load_frags(std::integral_constant<int, 3 * KS / 8>{}); break;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see sweep.hip
+  }
 #ifdef CHEB_STAMPS
   unsigned long long st_wait = 0, st_park = 0;
   STAMP3_MARK(st_wait);
@@ -627,13 +676,15 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   STAMP3_MARK(st_park);
 #endif
 
-  auto chain = [&](const double *sE, const double *sO, int sub, int g_issue, int g_park, v4d &ce, v4d &co, auto &&issue_fn, auto &&park_fn) {
+  auto chain = [&](const double *sE, const double *sO, int sub, int g_issue, int g_park, v4d &ce, v4d &co, auto &&issue_fn, auto &&park_fn, auto &&grp_fn) {
     const int nb = (ng * NSUB + sub) * 16;
     ce = v4d{0.0, 0.0, 0.0, 0.0}; co = v4d{0.0, 0.0, 0.0, 0.0};
     const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
     const double *fE = sE + frag, *fO = sO + frag;
     if constexpr (V4_ABLATE & 16) {                    // no matrix work: what the memory streams cost alone
       issue_fn(); park_fn();
+#pragma unroll
+      for (int g = 0; g < KS / 2; g++) grp_fn(g);
       ce[0] = fE[0] + ae[0]; co[0] = fO[KSTR] + AO(KS - 1); ce[1] = fE[2 * KSTR]; co[2] = fO[3 * KSTR];
       return;
     }
@@ -647,6 +698,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
         fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
       }
       __builtin_amdgcn_sched_barrier(0);               // fragment reads stay one group ahead of their MFMAs
+      grp_fn(g);
       if (g == g_issue) issue_fn();
       if (g == g_park) park_fn();
       if (!JFAST) {
@@ -726,37 +778,50 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     lds_barrier_v();
     STAMP3_MARK(st_loop);
     int cur = 0;
-    for (; tile < t_hi; tile += t_step) {
+    auto tile_body = [&](auto FIRST_) {
+      constexpr bool FIRST = decltype(FIRST_)::value;
       const u32 nxt = tile + t_step, nxt2 = nxt + t_step;
       const bool v1 = nxt < t_hi, v2 = nxt2 < t_hi;
       const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
       v4d ce, co;
       chain(sE, sO, 0, G_ISSUE, G_PARK, ce, co,
             [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
-            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); });
+            [&] { park_chunk(cur ^ 1, 0, rjA, rmA); },
+            [&](int g) { if constexpr (FIRST) { if (g + FA < KS / 2) frag_pair(g + FA); } });
       STAMP3(0);
       epilogue(tile, 0, ce, co, accX_hi, accX_lo);
       STAMP3(1);
       chain(sE, sO, 1, G_ISSUE, G_PARK, ce, co,
             [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
-            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); });
+            [&] { park_chunk(cur ^ 1, 1, rjB, rmB); }, [](int) {});
       STAMP3(2);
       epilogue(tile, 1, ce, co, accY_hi, accY_lo);
       STAMP3(3);
       lds_barrier_v();
       STAMP3(4);
       cur ^= 1;
+    };
+    if constexpr (V4_OVERLAP != 0) {
+      // the first tile, peeled: the same body in straight-line code behind the fragment requests, so that every MFMA
+      // group waits for its own fragments only; the loop below then starts from the state of its own back edge
+      tile_body(std::true_type{});
+      tile += t_step;
+      STAMP3_MARK(st_first);
     }
+#pragma unroll 1
+    for (; tile < t_hi; tile += t_step) tile_body(std::false_type{});
   };
   if (w >= 4) run(std::true_type{}); else run(std::false_type{});
 #ifdef CHEB_STAMPS
   {
     unsigned long long st_end; STAMP3_MARK(st_end);
     if (lane == 0 && p.in4) {
-      unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 8;
+      unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 16;
       dbg[0] = st_seg[0]; dbg[1] = st_seg[1]; dbg[2] = st_seg[2]; dbg[3] = st_seg[3]; dbg[4] = st_seg[4];
       // [5] prologue, [6] whole kernel in shader cycles, [7] whole kernel in 100 MHz ticks (MI355X_MICROARCH.md, DVFS note 6)
-      dbg[5] = st_loop - st_begin; dbg[6] = st_end - st_begin; dbg[7] = __builtin_amdgcn_s_memrealtime() - rt_begin; (void)st_wait; (void)st_park;
+      dbg[5] = st_loop - st_begin; dbg[6] = st_end - st_begin; dbg[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+      // [8] fragments requested (V4_OVERLAP) / landed (0), [9] first tile's lines parked, [10] first tile done (V4_OVERLAP), [11] / [12] begin / end (absolute, s_memtime)
+      dbg[8] = st_wait - st_begin; dbg[9] = st_park - st_begin; dbg[10] = st_first ? st_first - st_begin : 0; dbg[11] = st_begin; dbg[12] = st_end;
     }
   }
 #endif

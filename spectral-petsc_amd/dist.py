@@ -171,9 +171,11 @@ class DistPoissonC:
     a transport -- an RCCL communicator made from a unique id that rank 0 broadcasts through the process group
     (backend "nccl"), or, for rehearsals on one GPU under gloo, a callback that stages the exchange through the host."""
 
-    def __init__(self, dims, sp, group=None, comm=None, force_a2a=False):
+    def __init__(self, dims, sp, group=None, comm=None, force_a2a=False, legacy_exchange=False):
         """comm: a Comm (e.g. one rank of a LocalGroup) instead of the process group's transport; force_a2a: go through
-        the transport even with one rank (one-rank rehearsals of the real backend)."""
+        the transport even with one rank (one-rank rehearsals of the real backend); legacy_exchange: under gloo, plug the
+        host staging in as a chebhip_exchange_fn (chebhip_dist_set_exchange: one vector per exchange, every block moved)
+        instead of a chebhip_comm callback transport (which also carries chebhip_dist_mult_batch)."""
         import ctypes as C
         self.sp, self.group = sp, group
         self.dims = tuple(int(v) for v in dims)
@@ -190,6 +192,7 @@ class DistPoissonC:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._comm = None
         self._cb = None
+        self._own_comm = None
         forced = bool(force_a2a) and dist.is_initialized()
         if comm is not None:
             sp._chk(L.chebhip_dist_use_comm(h, comm._h))
@@ -204,9 +207,12 @@ class DistPoissonC:
                 sp._chk(L.chebhip_rccl_comm_create(self.G, self.rank, C.create_string_buffer(box[0], 128), C.byref(comm)))
                 self._comm = comm
                 sp._chk(L.chebhip_dist_use_rccl(h, comm))
-            else:
+            elif legacy_exchange:
                 self._cb = self._host_exchange()
                 sp._chk(L.chebhip_dist_set_exchange(h, C.cast(self._cb, C.c_void_p), None))
+            else:
+                self._own_comm = Comm(sp, group=group)       # gloo: chebhip_comm callback transport staged through the host
+                sp._chk(L.chebhip_dist_use_comm(h, self._own_comm._h))
 
     def _host_exchange(self):
         """chebhip_exchange_fn under gloo: device -> host, all_to_all_single, host -> device, ordered on `stream`."""
@@ -267,6 +273,9 @@ class DistPoissonC:
         if getattr(self, "_comm", None):
             self.sp.lib().chebhip_rccl_comm_destroy(self._comm)
             self._comm = None
+        if getattr(self, "_own_comm", None):
+            self._own_comm.destroy()
+            self._own_comm = None
 
 
 class _SlabPencil:

@@ -58,6 +58,45 @@ def test_world_size_mismatch_is_refused():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_watchdog_ends_a_hung_rank_with_a_diagnostic_and_a_nonzero_status():
+    """VERDICT r5 item 5 / ADVICE r5: a rank that never joins a collective must not read as success.  Rank 1 of the launcher self-test
+    sleeps instead of joining the all-reduce; the watchdog of the ranks names the phase on stderr and ends them with status 3."""
+    r = run_bench(["--gpus", "2", "--launch-selftest"], {"BENCH_DIST_BACKEND": "gloo", "BENCH_SELFTEST_HANG_RANK": "1", "BENCH_WATCHDOG_S": "8"}, 300)
+    assert r.returncode != 0
+    assert "WATCHDOG" in r.stderr and "did not return within 8 s" in r.stderr and "status 3" in r.stderr
+    assert not json_lines(r.stdout)
+
+
+def test_roofline_object_of_the_multi_gpu_line_prices_the_step_not_a_launch():
+    """for N > 1 the line must not report the single-GPU kernel's per-launch fields."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    one = b.roofline_record(256, 1, 20, 20 * 0.248, 3, 354.7e6)
+    assert one["kernel"] == "cheb_sweep_vec4_kernel" and one["priced_per"] == "launch" and abs(one["avg_launch_us"] - 248.0 / 3) < 1e-9
+    assert abs(one["frac"] - 112.0 * 256 ** 3 / 0.248e-3 / 8e12) < 1e-12 and one["hbm_real_frac"] is not None
+    many = b.roofline_record(256, 8, 20, 20 * 0.060, 4, None)
+    assert many["priced_per"] == "step of one GPU" and many["kernel"].startswith("slab route")
+    assert many["avg_launch_us"] is None and many["algorithmic_bytes_per_launch"] is None and many["traffic"] is None
+    assert many["launches_per_step"] == 4 and many["exchanges_per_step"] == 2 and abs(many["step_us"] - 60.0) < 1e-9
+    # one GPU's share of the model bytes and of the three directions' flops over the whole step
+    assert abs(many["achieved"] * 1e9 - 112.0 * 256 ** 3 / 8 / 60e-6) < 1.0
+    assert abs(many["mfma_f64_frac"] - 3 * 254.0 ** 4 / 8 / 60e-6 / 78.6e12) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_batched_leg_runs_under_the_gloo_rehearsal():
+    """BENCH_BATCHED=1: the informational 4-vectors-per-exchange leg through the chebhip_comm callback transport (it used to need RCCL)."""
+    r = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--spinup", "2", "--size", "40"],
+                  {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1", "BENCH_BATCHED": "1"}, 900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(json_lines(r.stdout)) == 1
+    info = [ln for ln in r.stderr.splitlines() if "vectors per exchange" in ln]
+    assert len(info) == 1, r.stderr[-2000:]
+    rec = json.loads(info[0].split("exchange: ", 1)[1])
+    assert rec.get("nrhs") == 4 and rec.get("vectors_agree") is True and rec["matvecs_per_s"] > 0, rec
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_as_typed_prints_one_parsed_line():
     r = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "2", "--size", "64"],
@@ -69,3 +108,4 @@ def test_bench_gpus_2_as_typed_prints_one_parsed_line():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
     assert rec["parity"]["rel_l2_vs_oracle"] <= 1e-10 and rec["parity"]["ranks"] == 2
     assert rec["config"]["parallelism"].startswith("slab2+all2all(C host") and "c_host_fallback" not in rec["config"]
+    assert rec["roofline"]["priced_per"] == "step of one GPU" and rec["roofline"]["avg_launch_us"] is None

@@ -292,7 +292,7 @@ def test_dist_c_single_rank(dims):
     par.destroy(); ser.destroy()
 
 
-def _distc_worker(rank, world, port, dims, q, backend):
+def _distc_worker(rank, world, port, dims, q, backend, legacy=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     if backend == "nccl":
@@ -303,16 +303,17 @@ def _distc_worker(rank, world, port, dims, q, backend):
         sp = ge.load(); dsp = ge.load_dist()
         if backend == "nccl":
             sp.set_option("rccl_self_messages", 1)              # one rank on the real transport: its own block through ncclSend / ncclRecv
-        op = dsp.DistPoissonC(dims, sp, force_a2a=(backend == "nccl"))
+        op = dsp.DistPoissonC(dims, sp, force_a2a=(backend == "nccl"), legacy_exchange=legacy)
         G = int(np.prod([v - 2 for v in dims]))
         U = np.random.default_rng(SEED).standard_normal(G)
         lo, n = op.slab_offset, op.local_size
         Ul = torch.from_numpy(U[lo:lo + n].copy()).cuda(); Vl = torch.full_like(Ul, float("nan"))
         for _ in range(3):                       # repeated applies: buffers and events are reused correctly
             op.mult(Ul, Vl)
-        if backend == "nccl":
-            # chebhip_dist_mult_batch on the REAL transport: three vectors per exchange = three ncclSend / ncclRecv pairs per peer in
-            # ONE group (here the peer is the rank itself: rccl_self_messages) -- the message pattern of a batched multi-GPU run
+        if not legacy:
+            # chebhip_dist_mult_batch on the REAL transport: three vectors per exchange = ONE ncclSend / ncclRecv pair per peer in
+            # ONE group (here the peer is the rank itself: rccl_self_messages) -- the message pattern of a batched multi-GPU run;
+            # under gloo: the same through the chebhip_comm callback transport (the bench's N > 1 rehearsal takes this path)
             Ub = torch.stack([Ul, 2.0 * Ul, -Ul]).contiguous(); Vb = torch.full_like(Ub, float("nan"))
             op.mult_batch(Ub, Vb); op.mult_batch(Ub, Vb)
             torch.cuda.synchronize()
@@ -334,7 +335,7 @@ def _distc_worker(rank, world, port, dims, q, backend):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (3, (9, 8, 7), "gloo"), (1, (20, 18, 16), "nccl")], ids=str)
+@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (3, (9, 8, 7), "gloo"), (2, (10, 9, 8), "gloo-legacy"), (1, (20, 18, 16), "nccl")], ids=str)
 def test_dist_c_ranks_match_oracle(world, dims, backend):
     """2-3 ranks sharing the box's one GPU (exchange callback through gloo) and one rank on the REAL transport
     (process group "nccl", unique-id bootstrap, ncclSend / ncclRecv of the own block, ncclAllReduce in the solver):
@@ -342,7 +343,8 @@ def test_dist_c_ranks_match_oracle(world, dims, backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_distc_worker, args=(r, world, port, dims, q, backend)) for r in range(world)]
+    legacy = backend.endswith("-legacy")                    # chebhip_dist_set_exchange (the older callback contract) instead of a chebhip_comm
+    procs = [ctx.Process(target=_distc_worker, args=(r, world, port, dims, q, backend.split("-")[0], legacy)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]

@@ -113,6 +113,28 @@ def test_poisson_batch_thread_ranks(G, dims, nrhs):
         assert relerr(Vb[q], orc.elliptic_mult(dims, U[q], mode=orc.FAST, nthreads=8)) < 1e-10
 
 
+def test_failed_batch_work_set_is_not_kept():
+    """a work set whose build fails (here: more than 2^31 values per rank, refused before any allocation) must
+    not stay in the handle -- the next call with the same nrhs fails the same clean way instead of finding a half-built entry, and
+    the handle keeps working for the sizes that fit."""
+    import ctypes as C
+    sp = ge.load(); dsp = ge.load_dist()
+    dims = (256, 256, 256, 4)                                    # interior 254^3 x 2 = 32.8 M values: 64 of them exceed 2^31
+    D = dsp.DistPoissonC(dims, sp)
+    n = D.local_size
+    U = torch.randn(2 * n, dtype=torch.float64, device="cuda"); V = torch.empty_like(U)
+    L = sp.lib()
+    for _ in range(2):                                           # the second call is the one that used to find the half-built entry
+        rc = L.chebhip_dist_mult_batch(D._h, 64, C.c_void_p(U.data_ptr()), C.c_void_p(V.data_ptr()), sp._stream())
+        assert rc != 0 and "2^31" in sp.lib().chebhip_last_error().decode()
+    D.mult_batch(U.view(2, n), V.view(2, n))
+    ref = torch.empty(n, dtype=torch.float64, device="cuda")
+    D.mult(U[:n], ref)
+    torch.cuda.synchronize()
+    assert torch.equal(V[:n], ref)
+    D.destroy()
+
+
 def test_poisson_256_batch_of_4_over_8_ranks():
     """BASELINE config 3 at its size, four vectors per exchange over 8 thread ranks: each equals the serial handle's matvec (1e-13)."""
     sp = ge.load(); dsp = ge.load_dist()

@@ -119,6 +119,50 @@ def test_fgmres_truncated_solve_is_the_krylov_minimiser(sp, max_it, restart):
     ks.destroy(); op.destroy()
 
 
+@pytest.mark.parametrize("reduce_path", [False, True], ids=["one_rank", "reduce_path"])
+@pytest.mark.parametrize("restart,rtol", [(8, 1e-10), (30, 1e-12), (60, 1e-9)])
+def test_fgmres_one_reduction_step_against_the_three_launch_step(sp, restart, rtol, reduce_path):
+    """the A/B fallback `krylov_exact_norm` = 1 (three launches per Gram-Schmidt step, every norm exact) had no regression
+    test, and the default step's LAST column of a restart cycle takes h_{j+1,j} from the cancelling difference w.w - |h|^2.  Same
+    system, both steps, on the one-rank path and on the path that completes its sums through a reduction callback (here a
+    communicator of one rank): both must return a solution whose TRUE residual meets the tolerance they report, in (nearly) the
+    same number of iterations, and agree with each other.  Short restarts put an estimated column at the end of every cycle."""
+    import torch
+    import __graft_entry__ as ge
+    dsp = ge.load_dist()
+    dims = (20, 18, 16)
+    op = sp.EllipticOp(dims)
+    n = op.global_size
+    bd = torch.from_numpy(np.random.default_rng(SEED + 11).standard_normal(n)).cuda()
+    comm = dsp.Comm(sp, null=(1, 0)) if reduce_path else None
+    res = {}
+    try:
+        for exact in (0, 1):
+            sp.set_option("krylov_exact_norm", exact)
+            ks = sp.Fgmres(n, restart=restart, rtol=rtol, max_it=4000)
+            if comm is not None:
+                ks.set_reduce_raw(*comm.reduce_fn())
+            xd = torch.full_like(bd, float("nan"))
+            ks.solve(op, bd, xd)
+            torch.cuda.synchronize()
+            true_res = float((bd - op.mult(xd, torch.empty_like(bd))).norm())
+            res[exact] = (ks.reason, ks.iterations, xd.clone(), true_res, ks.residual)
+            ks.destroy()
+    finally:
+        sp.set_option("krylov_exact_norm", 0)
+        if comm is not None:
+            comm.destroy()
+        op.destroy()
+    bn = float(bd.norm())
+    for exact in (0, 1):
+        reason, its, x, tr, rep = res[exact]
+        assert reason == 2 and its > restart, (exact, reason, its)
+        assert tr <= 1.05 * rtol * bn, (exact, tr / bn)           # converged means converged on the true residual
+        assert abs(rep - tr) <= 0.05 * rtol * bn + 1e-13 * bn
+    assert abs(res[0][1] - res[1][1]) <= max(2, res[1][1] // 20), (res[0][1], res[1][1])
+    assert float((res[0][2] - res[1][2]).norm()) <= 50 * rtol * float(res[1][2].norm()) * 1e3
+
+
 def test_fgmres_zero_rhs_clears_x(sp):
     """b = 0 with a zero initial guess: the solve ends before any update, and x (never written on the way) must come back 0."""
     import torch

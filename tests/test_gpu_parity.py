@@ -43,6 +43,36 @@ def _cases(g):
     return sorted(out)
 
 
+@pytest.mark.parametrize("n0", [1790, 1800], ids=["just_below_the_32bit_offset_limit", "just_above_it"])
+def test_cheb_arrays_around_the_buffer_offset_limit(n0):
+    """cheb_sweep_vec4_kernel addresses its arrays with 32-bit buffer offsets and takes arrays of less than
+    0x38000000 bytes (939.5 MB; csrc/sweep_vec.hip prepare_v); larger ones go to the general kernel of sweep.hip -- silently, so this
+    is the test that the hand-over is right on BOTH sides of the limit (a 512^3 scalar field is 1 GiB on a 288-GB part):
+    (1790, 256, 256) = 938.5 MB runs the fast kernel with offsets up to the limit, (1800, 256, 256) = 943.7 MB does not qualify.
+    256-point lines along dimension 1 (strided) and 2 (contiguous) of a seeded N(0,1) array, compared with the oracle on sub-blocks
+    of whole lines taken at the start, in the middle and at the very end of the array (lines are independent: chebyshev.c:162-193)."""
+    dims = (n0, 256, 256)
+    nbytes = 8 * n0 * 256 * 256
+    assert (nbytes < 0x38000000) == (n0 == 1790)
+    g = torch.Generator(device="cuda").manual_seed(SEED + n0)
+    xd = torch.randn(dims, dtype=torch.float64, device="cuda", generator=g)
+    yd = torch.empty_like(xd)
+    blocks = [(0, 3), (n0 // 2 - 1, n0 // 2 + 2), (n0 - 3, n0)]
+    for tr in (1, 2):
+        plan = sp.ChebPlan(dims, tr)
+        yd.fill_(float("nan"))
+        plan.mult(xd.view(-1), yd.view(-1))
+        torch.cuda.synchronize()
+        plan.destroy()
+        assert bool(torch.isfinite(yd).all())
+        for lo, hi in blocks:
+            x = xd[lo:hi].cpu().numpy()
+            ref = orc.cheb_mult(x, tr, mode=orc.FAST, nthreads=4)
+            assert relerr(yd[lo:hi].cpu().numpy(), ref) < TOL, (tr, lo)
+    del xd, yd
+    torch.cuda.empty_cache()
+
+
 def test_native_library_loaded():
     L = sp.lib()
     assert L.chebhip_arch() == b"gfx950"

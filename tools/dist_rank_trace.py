@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 sp = ge.load(); dsp = ge.load_dist()
+if os.environ.get("CHEBHIP_LIB_PATH"):      # diagnostic / A-B builds (tools/v4_overlap_ab.sh)
+    sp.LIB_PATH = os.path.join(ROOT, os.environ["CHEBHIP_LIB_PATH"])
 for a in [a for a in sys.argv[1:] if "=" in a]:
     k, v = a.split("="); sp.set_option(k, int(v))
 sys.argv = [a for a in sys.argv if "=" not in a]

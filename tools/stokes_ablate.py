@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import __graft_entry__ as ge
 sp = ge.load()
+sp.LIB_PATH = os.path.join(ROOT, "tools", "libchebhip_diag.so")      # `make -C spectral-petsc_amd/csrc diag`: the hook exists in diagnostic builds only
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 op = sp.StokesOp((P, P, P)); op.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)
 op.set_dirichlet(np.zeros(op.dirichlet_size)); op.set_force(np.zeros(op.global_size))
