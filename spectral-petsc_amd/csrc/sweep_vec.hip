@@ -17,12 +17,31 @@
 #include <cstdlib>
 #include <type_traits>
 
+const double *chebhip_stamp_buf();   // chebhip.hip: diagnostic builds (CHEB_STAMPS) write in-kernel cycle stamps there
+int chebhip_stamp_next();
+
 namespace chebhip {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Pitch of a line of the JFAST tile image in LDS, in doubles beyond the half length HP.  ODD (1): the MFMA operand reads -- lane
+// (l16, kq) reads points kq + 4k, kq + 4k + 4 of line l16 as one ds_read2_b64 -- are free of bank conflicts; with the pitch = 2 mod 32
+// of rounds 1-5 every such read is a 2-way conflict (tools/lds_probe.hip under --pmc, profiles/r06_lds_probe.txt: SQ_LDS_BANK_CONFLICT
+// = half of SQ_LDS_IDX_ACTIVE at pitch 130, 0 at 129, three quarters at 132 -- the 8.26 M conflict cycles of the JFAST launch in every
+// counter record since round 3).  The price: lines start on 8-byte boundaries only, so the parity split parks its 16-byte pieces as
+// ds_write2_b64 instead of ds_write_b128.
+#ifndef V_LDJ_PAD
+#define V_LDJ_PAD 1
+#endif
+// one 16-byte piece into an LDS image whose lines may start on 8-byte boundaries
+template <bool ALIGNED16>
+__device__ __forceinline__ void lds_put2(double *dst, double __attribute__((ext_vector_type(2))) v) {
+  if (ALIGNED16) *(double __attribute__((ext_vector_type(2))) *)dst = v;
+  else { dst[0] = v.x; dst[1] = v.y; }
+}
 
 __device__ __forceinline__ void lds_barrier_v() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -38,33 +57,48 @@ __device__ __forceinline__ double swap1(double v) {
 // LDS-resident matrix fragments at KS = 32
 template <int KS, bool JFAST>
 constexpr int vec_lds_doubles() {
-  constexpr int MTP = KS / 4, NG = 8 / MTP, HP = 4 * KS, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB, LDJ = HP + 2;
+  constexpr int MTP = KS / 4, NG = 8 / MTP, HP = 4 * KS, NSUB = (KS >= 16) ? 2 : 1, NT = 16 * NG * NSUB, LDJ = HP + V_LDJ_PAD;
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
   constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
   return 4 * LDS_ELEMS + 8 * NFL * 64;
 }
 
-// Body of cheb_sweep_vec_kernel: workgroup BID of NBLK (the launch's, or those of one job of a multi-job launch)
-template <int KS, bool JFAST, bool SUM3 = false>
+// Body of cheb_sweep_vec_kernel (lines of at most 64 points, KS <= 8): workgroup BID of NBLK (the launch's, or those of one job
+// of a multi-job launch).
+//
+// At these sizes a launch is all latency (64^3: two tiles per workgroup, the data sits in L2 / the Infinity Cache).  In-kernel stamps of
+// the nine-job launch of a 64^3 StokesMatMult (tools/stamp_probe_multi.py, profiles/r06_multi64_stamps.txt) with the round 1-5 schedule:
+// matrix fragments landed after 2.6-5.3 k cycles, THEN the first tile was requested and the loop entered after 5.6-10 k; each of the two
+// tiles took ~6 k, 2.4-3.4 k of it the wait for the next tile's lines, requested only one short chain earlier -- 17-25 k cycles per
+// workgroup.  Round 6:
+//   * the first TWO tiles are requested before the matrix fragments: one memory round trip in front of the loop instead of two;
+//   * two register sets (A, B) of prefetched lines: tile t + 2 is requested at the top of tile t and split into LDS at the end of tile
+//     t + 1's chain, i.e. it has a whole tile to land instead of a chain of 16-32 MFMAs;
+//   * the loop is unrolled by two (static register sets) and has no branch around a memory instruction (invalid tiles read the zero
+//     line), so hipcc's wait counts are exact: the wait for tile t + 1 does not cover the request for t + 2.
+// Launches with a VecAXPY operand (ACC) and IN_SUM3 (the three-term input of grad div v, whose loads are all in flight before the first
+// sum) have ONE register set -- a second one does not fit 128 VGPRs, i.e. two workgroups per CU -- and request tile t + 2 right after the
+// split of tile t + 1.
+// ACC = false: plain STORE launches only (every job of a multi-job launch) -- no operand registers.
+template <int KS, bool JFAST, bool SUM3 = false, bool ACC = true>
 __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
+  static_assert(KS <= 8, "lines of more than 64 points run vec4_body");
+  static_assert(!SUM3 || !ACC, "IN_SUM3 exists for plain stores only");
   constexpr int MTP = KS / 4;
   constexpr int NG = 8 / MTP;
   constexpr int HP = 4 * KS;
-  constexpr int NSUB = (KS >= 16) ? 2 : 1;
-  constexpr int NT = 16 * NG * NSUB;
-  constexpr int LDJ = HP + 2;
+  constexpr int NT = 16 * NG;
+  constexpr int LDJ = HP + V_LDJ_PAD;
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
-  constexpr int ITEMS = HP * NT / 2 / 512;            // 16-B slots per thread per tile
-  constexpr int CH = ITEMS / NSUB;
+  constexpr int CH = HP * NT / 2 / 512;               // 16-B slots per thread per tile
   constexpr int QSTEP = JFAST ? 512 / (HP / 2) : 512 / (NT / 2);   // line step (JFAST) / j-pair step (COLFAST)
   constexpr int LDS_QSTEP = JFAST ? QSTEP * LDJ : QSTEP * NT;
   constexpr int KSTR = JFAST ? 4 : 4 * NT;
   static_assert(CH >= 1 && (QSTEP % 2 == 0 || JFAST), "tile geometry");
-  // At P = 256 the matrix halves need 128 VGPRs per wave.  The last NFL odd-half fragments live in the LDS
-  // left over by the tile images instead (32 KiB), which frees 2*NFL VGPRs for a deeper operand prefetch.
-  constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
-  constexpr int KR = KS - NFL;                       // odd-half fragments kept in registers
 
+#ifdef CHEB_STAMPS
+  const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mt = w % MTP, ng = w / MTP;
   const int kq = lane >> 4, l16 = lane & 15;
@@ -73,110 +107,118 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
   const u32 inner = p.inner, ncols = p.ncols;
   const u32 lineLen = (u32)p.P * inner;
 
-  double ae[KS], ao[KR > 0 ? KR : 1];
-  double *aoL = smem + 4 * LDS_ELEMS + (w * NFL) * 64 + lane;   // this wave's LDS-resident fragments
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
-    const double v = p.fragO[((long)(mt * KS + s)) * 64 + lane];
-    if (s < KR) ao[s] = v; else aoL[(s - KR) * 64] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see sweep.hip
-
   const u32 tpo = JFAST ? 1u : (inner + NT - 1) / NT;
   const u32 nxcd = (NBLK % 8 == 0) ? 8u : 1u;
   const u32 t_per = (p.ntiles + nxcd - 1) / nxcd;
   const u32 t_lo = (BID % nxcd) * t_per;
   const u32 t_hi = (t_lo + t_per < p.ntiles) ? t_lo + t_per : p.ntiles;
   const u32 t_step = NBLK / nxcd;
+  u32 tile = t_lo + BID / nxcd;
+  if (tile >= t_hi) return;                             // the whole workgroup: no barrier is skipped by part of it
 
   // loader slots: COLFAST (line pair 2*ld_a, j-pair ld_b + s*QSTEP); JFAST (points 2*ld_a, 2*ld_a+1 of line ld_b + s*QSTEP)
   const int ld_a = JFAST ? tid % (HP / 2) : tid % (NT / 2);
   const int ld_b = JFAST ? tid / (HP / 2) : tid / (NT / 2);
   const int ld_lds0 = JFAST ? ld_b * LDJ + 2 * ld_a : ld_b * NT + ((2 * ld_a) ^ ((ld_b & 1) << 4));
 
-  // Two chunks of prefetched lines are in flight at a time (A, B): each rides under TWO MFMA chains
-  // before it is parity-split into LDS -- one chain (~3.5 us) is not enough to cover an HBM round trip
-  // when the whole chip streams.
-  d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
+  // two register sets of prefetched lines where the register file allows it at two workgroups per CU (128 VGPRs): plain stores
+  constexpr bool TWO = !SUM3 && !ACC;
+  struct Lines { d2 j[CH], m[CH]; };
+  Lines LA, LB;
   const d2 *zero2 = (const d2 *)p.zero;
 
   const bool raw_in = p.raw == 2, raw_out = p.raw == 1;   // the line transforms of precond.hip (sweep.h)
-  auto issue_loads = [&](u32 tile, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
+  // the lines of tile `tl` -> registers; !valid (past the workgroup's last tile): every lane reads the zero line
+  auto issue_loads = [&](u32 tl, bool valid, Lines &L) {
+    d2 j1[SUM3 ? CH : 1], m1[SUM3 ? CH : 1], j2[SUM3 ? CH : 1], m2[SUM3 ? CH : 1];
     if (!JFAST) {
-      const u32 o = tile / tpo, q0 = (tile - o * tpo) * NT;
+      const u32 o = tl / tpo, q0 = (tl - o * tpo) * NT;
       const u32 q = q0 + 2 * ld_a;
-      const bool cv = q < inner;                            // inner is even: the pair is in or out together
+      const bool cv = valid && q < inner;                   // inner is even: the pair is in or out together
       const u32 base = o * lineLen + q;
-      int jp = ld_b + chunk * CH * QSTEP;
+      int jp = ld_b;
       u32 rel = (u32)jp * inner;
       const u32 top = base + (u32)nn * inner;
       asm volatile("" : "+v"(rel), "+v"(jp));
 #pragma unroll
       for (int s = 0; s < CH; s++, jp += QSTEP, rel += QSTEP * inner) {
-        const bool ok = cv && jp < H;
-        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
-        rm[s] = *((ok && nn - jp != jp) ? (const d2 *)(p.in0 + (top - rel)) : zero2);
+        const bool ok = cv && jp < H, okm = ok && nn - jp != jp;
+        L.j[s] = *(ok ? (const d2 *)(p.in0 + (base + rel)) : zero2);
+        L.m[s] = *(okm ? (const d2 *)(p.in0 + (top - rel)) : zero2);
         if (SUM3) {                                           // IN_SUM3: (in0 + in1) + in2, the order of the pointwise sum it replaces
-          const d2 j1 = *(ok ? (const d2 *)(p.in1 + (base + rel)) : zero2), m1 = *((ok && nn - jp != jp) ? (const d2 *)(p.in1 + (top - rel)) : zero2);
-          const d2 j2 = *(ok ? (const d2 *)(p.in2 + (base + rel)) : zero2), m2 = *((ok && nn - jp != jp) ? (const d2 *)(p.in2 + (top - rel)) : zero2);
-          rj[s] = (rj[s] + j1) + j2; rm[s] = (rm[s] + m1) + m2;
+          j1[s] = *(ok ? (const d2 *)(p.in1 + (base + rel)) : zero2); m1[s] = *(okm ? (const d2 *)(p.in1 + (top - rel)) : zero2);
+          j2[s] = *(ok ? (const d2 *)(p.in2 + (base + rel)) : zero2); m2[s] = *(okm ? (const d2 *)(p.in2 + (top - rel)) : zero2);
         }
       }
     } else {
       const int j = 2 * ld_a;                               // points j, j+1 and their mirrors n-j-1, n-j
 #pragma unroll
       for (int s = 0; s < CH; s++) {
-        const u32 c = tile * NT + ld_b + (chunk * CH + s) * QSTEP;
-        const bool ok = c < ncols && j < H;
+        const u32 c = tl * NT + ld_b + s * QSTEP;
+        const bool ok = valid && c < ncols && j < H;
         const u32 base = (ok ? c : 0u) * lineLen;
-        rj[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
-        rm[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
+        L.j[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)j)) : zero2);
+        L.m[s] = *(ok ? (const d2 *)(p.in0 + (base + (u32)(nn - j - 1))) : zero2);
         if (SUM3) {
-          const d2 j1 = *(ok ? (const d2 *)(p.in1 + (base + (u32)j)) : zero2), m1 = *(ok ? (const d2 *)(p.in1 + (base + (u32)(nn - j - 1))) : zero2);
-          const d2 j2 = *(ok ? (const d2 *)(p.in2 + (base + (u32)j)) : zero2), m2 = *(ok ? (const d2 *)(p.in2 + (base + (u32)(nn - j - 1))) : zero2);
-          rj[s] = (rj[s] + j1) + j2; rm[s] = (rm[s] + m1) + m2;
+          j1[s] = *(ok ? (const d2 *)(p.in1 + (base + (u32)j)) : zero2); m1[s] = *(ok ? (const d2 *)(p.in1 + (base + (u32)(nn - j - 1))) : zero2);
+          j2[s] = *(ok ? (const d2 *)(p.in2 + (base + (u32)j)) : zero2); m2[s] = *(ok ? (const d2 *)(p.in2 + (base + (u32)(nn - j - 1))) : zero2);
         }
       }
     }
+    if (SUM3) {                                               // all the loads of the tile are in flight together; the sums wait for them here
+#pragma unroll
+      for (int s = 0; s < CH; s++) { L.j[s] = (L.j[s] + j1[s]) + j2[s]; L.m[s] = (L.m[s] + m1[s]) + m2[s]; }
+    }
   };
 
-  auto park_chunk = [&](int buf, int chunk, const d2 (&rj)[CH], const d2 (&rm)[CH]) {
+  // parity split of a register set into tile image `buf`
+  auto park_chunk = [&](int buf, const Lines &L) {
     double *dE = smem + buf * (2 * LDS_ELEMS), *dO = dE + LDS_ELEMS;
 #pragma unroll
     for (int s = 0; s < CH; s++) {
-      const int idx = ld_lds0 + (chunk * CH + s) * LDS_QSTEP;
+      const int idx = ld_lds0 + s * LDS_QSTEP;
+      const d2 rj = L.j[s], rm = L.m[s];
       d2 e, o;
       if (!JFAST) {
-        const bool mid = 2 * (ld_b + (chunk * CH + s) * QSTEP) == nn;   // rm was left 0 there
-        if (raw_in) { e = rj[s]; o = rm[s]; }                           // already split: e_j = x_j, o_j = x_{n-j}
-        else { e = rj[s] + rm[s]; o = rj[s] - rm[s]; }
+        const bool mid = 2 * (ld_b + s * QSTEP) == nn;                  // rm was left 0 there
+        if (raw_in) { e = rj; o = rm; }                                 // already split: e_j = x_j, o_j = x_{n-j}
+        else { e = rj + rm; o = rj - rm; }
         if (mid) o = d2{0.0, 0.0};
       } else {
         // rj = (x_j, x_{j+1}), rm = (x_{n-j-1}, x_{n-j}); point j+1 may be past the half (H odd) -> 0
         const bool v1 = 2 * ld_a + 1 < H;
-        if (raw_in) { e = d2{rj[s].x, v1 ? rj[s].y : 0.0}; o = d2{rm[s].y, v1 ? rm[s].x : 0.0}; }
+        if (raw_in) { e = d2{rj.x, v1 ? rj.y : 0.0}; o = d2{rm.y, v1 ? rm.x : 0.0}; }
         else {
-          e = d2{rj[s].x + rm[s].y, v1 ? rj[s].y + rm[s].x : 0.0};
-          o = d2{rj[s].x - rm[s].y, v1 ? rj[s].y - rm[s].x : 0.0};
+          e = d2{rj.x + rm.y, v1 ? rj.y + rm.x : 0.0};
+          o = d2{rj.x - rm.y, v1 ? rj.y - rm.x : 0.0};
         }
       }
-      *(d2 *)(dE + idx) = e;
-      *(d2 *)(dO + idx) = o;
+      lds_put2<!JFAST || (LDJ % 2 == 0)>(dE + idx, e);
+      lds_put2<!JFAST || (LDJ % 2 == 0)>(dO + idx, o);
     }
   };
 
-  constexpr bool STAG = (KS >= 16);   // staggered in-chain placement needs a chain long enough to hide it
-  const bool grpB = w >= 4;             // second wave of each SIMD
-#define AO(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
+  // the first two tiles and the matrix fragments are requested together: one round trip for all three (IN_SUM3, whose loads are
+  // summed as they land: fragments first, then the tile)
+  double ae[KS], ao[KS];
+  if (!SUM3) issue_loads(tile, true, LA);
+  if (TWO) issue_loads(tile + t_step, tile + t_step < t_hi, LB);
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    ae[s] = p.fragE[((long)(mt * KS + s)) * 64 + lane];
+    ao[s] = p.fragO[((long)(mt * KS + s)) * 64 + lane];
+  }
+  if (SUM3) issue_loads(tile, true, LA);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): retires the fragment loads in front of the loop (see sweep.hip)
+
   const int i0 = mt * 16 + (JFAST ? l16 : kq);
-  const bool mul_on = (p.out_mode == OUT_MUL);            // out = operand * (alpha r): the operand rides the VecAXPY path
-  const bool acc2_on = (p.out_mode == OUT_ACC2);          // out = (acc + acc2) + alpha r
-  const bool acc_on = (p.out_mode == OUT_ACC) || mul_on || acc2_on;
+  const bool mul_on = ACC && (p.out_mode == OUT_MUL);     // out = operand * (alpha r): the operand rides the VecAXPY path
+  const bool acc2_on = ACC && (p.out_mode == OUT_ACC2);   // out = (acc + acc2) + alpha r
+  const bool acc_on = ACC && ((p.out_mode == OUT_ACC) || mul_on || acc2_on);
   const double alpha = p.alpha;
 
 #ifdef CHEB_STAMPS
-  unsigned long long st_pre = 0, st_chain = 0, st_post = 0, st_bar = 0, st_t0, st_t1, st_begin, st_loop, st_end;
+  unsigned long long st_pre = 0, st_chain = 0, st_post = 0, st_bar = 0, st_t0, st_t1, st_begin, st_loop, st_end, st_tiles = 0;
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(v) do { } while (0)
@@ -184,163 +226,151 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
 #ifdef CHEB_STAMPS
   STAMP(st_begin);
 #endif
-  u32 tile = t_lo + BID / nxcd;
-  if (tile < t_hi) {
-#pragma unroll 1
-    for (int ch = 0; ch < NSUB; ch++) { issue_loads(tile, ch, rjA, rmA); park_chunk(0, ch, rjA, rmA); }
-    if (NSUB == 2 && tile + t_step < t_hi) issue_loads(tile + t_step, 0, rjA, rmA);   // rides under the first chain
-  }
+  park_chunk(0, LA);
+  if (!TWO && tile + t_step < t_hi) issue_loads(tile + t_step, true, LA);   // one register set: the next request follows the split
   lds_barrier_v();
 #ifdef CHEB_STAMPS
   STAMP(st_loop);
 #endif
-  int cur = 0;
-  for (; tile < t_hi; tile += t_step) {
-    const u32 nxt = tile + t_step;
-    const bool has_next = nxt < t_hi;
+
+  // one tile: chain on image `cur`, results out; `issue_fn` asks for the tile after next at the top, `park_fn` splits the next
+  // tile's lines into image cur ^ 1 after the chain (before the stores: its wait covers loads only)
+  auto tile_body = [&](int cur, auto &&issue_fn, auto &&park_fn) {
     const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
     const u32 t_o = tile / tpo, t_q0 = (tile - t_o * tpo) * NT;
-    auto do_sub = [&](int sub, auto &&issue_fn, auto &&park_fn) {
 #ifdef CHEB_STAMPS
-      STAMP(st_t0);
+    STAMP(st_t0); st_tiles++;
 #endif
-      if (!STAG) issue_fn();
-      const int nb = (ng * NSUB + sub) * 16;
+    issue_fn();
+    const int nb = ng * 16;
 
-      // After the lane exchange this lane owns, for rp = 0,1: accumulator row r = 2*rp + odd, and of it
-      // the two adjacent columns (COLFAST) / points (JFAST) starting at the even lane of its pair.
-      u32 a_hi[2], a_lo[2];      // element offsets of the two 16-B pieces (row i / mirror row n-i)
-      bool ok_hi[2], ok_lo[2], fold[2];
-      d2 acc_hi[2], acc_lo[2];
+    // After the lane exchange this lane owns, for rp = 0,1: accumulator row r = 2*rp + odd, and of it
+    // the two adjacent columns (COLFAST) / points (JFAST) starting at the even lane of its pair.
+    u32 a_hi[2], a_lo[2];      // element offsets of the two 16-B pieces (row i / mirror row n-i)
+    bool ok_hi[2], ok_lo[2], fold[2];
+    d2 acc_hi[2], acc_lo[2];
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) {
+      const int r = 2 * rp + odd;
+      if (!JFAST) {
+        const u32 q = t_q0 + nb + l16e;
+        const int i = i0 + 4 * r;
+        const u32 b = t_o * lineLen + q;
+        ok_hi[rp] = q < inner && i < H;
+        ok_lo[rp] = ok_hi[rp] && (nn - i != i);
+        fold[rp] = false;
+        a_hi[rp] = b + (u32)i * inner;
+        a_lo[rp] = b + (u32)(nn - i) * inner;
+      } else {
+        const u32 c = tile * NT + nb + 4 * r + kq;
+        const int ie = mt * 16 + l16e;                   // points ie, ie+1 of line c; mirrors n-ie-1, n-ie
+        const u32 b = (c < ncols ? c : 0u) * lineLen;
+        ok_hi[rp] = c < ncols && ie < H;
+        fold[rp] = ok_hi[rp] && (ie + 1 >= H);            // H odd: point ie+1 IS the mirror of ie
+        ok_lo[rp] = ok_hi[rp] && !fold[rp];
+        a_hi[rp] = b + (u32)ie;
+        a_lo[rp] = b + (u32)(nn - ie - 1);
+      }
+      acc_hi[rp] = d2{0.0, 0.0}; acc_lo[rp] = d2{0.0, 0.0};
+    }
+    // the VecAXPY operand of this tile
+    if (acc_on) {
 #pragma unroll
       for (int rp = 0; rp < 2; rp++) {
-        const int r = 2 * rp + odd;
+        acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
+        acc_lo[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
+        if (acc2_on) {
+          acc_hi[rp] = acc_hi[rp] + *(ok_hi[rp] ? (const d2 *)(p.acc2 + a_hi[rp]) : zero2);
+          acc_lo[rp] = acc_lo[rp] + *(ok_lo[rp] ? (const d2 *)(p.acc2 + a_lo[rp]) : zero2);
+        }
+      }
+    }
+
+#ifdef CHEB_STAMPS
+    STAMP(st_t1); st_pre += st_t1 - st_t0;
+#endif
+    v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
+    {
+      const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
+      const double *fE = sE + frag, *fO = sO + frag;
+      double fb[2][4];
+      fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
+#pragma unroll
+      for (int g = 0; g < KS / 2; g++) {
+        const int cb = g & 1, nbuf = cb ^ 1;
+        if (g + 1 < KS / 2) {
+          fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
+          fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
+        }
+        // fence: keep the fragment reads of group g+1 ABOVE the MFMAs of group g (hipcc otherwise sinks
+        // them to just before their use and every group starts with an exposed LDS round trip)
+        __builtin_amdgcn_sched_barrier(0);
         if (!JFAST) {
-          const u32 q = t_q0 + nb + l16e;
-          const int i = i0 + 4 * r;
-          const u32 b = t_o * lineLen + q;
-          ok_hi[rp] = q < inner && i < H;
-          ok_lo[rp] = ok_hi[rp] && (nn - i != i);
-          fold[rp] = false;
-          a_hi[rp] = b + (u32)i * inner;
-          a_lo[rp] = b + (u32)(nn - i) * inner;
+          ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
+          co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g], fb[cb][2], co, 0, 0, 0);
+          ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
+          co = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[2 * g + 1], fb[cb][3], co, 0, 0, 0);
         } else {
-          const u32 c = tile * NT + nb + 4 * r + kq;
-          const int ie = mt * 16 + l16e;                   // points ie, ie+1 of line c; mirrors n-ie-1, n-ie
-          const u32 b = (c < ncols ? c : 0u) * lineLen;
-          ok_hi[rp] = c < ncols && ie < H;
-          fold[rp] = ok_hi[rp] && (ie + 1 >= H);            // H odd: point ie+1 IS the mirror of ie
-          ok_lo[rp] = ok_hi[rp] && !fold[rp];
-          a_hi[rp] = b + (u32)ie;
-          a_lo[rp] = b + (u32)(nn - ie - 1);
-        }
-        acc_hi[rp] = d2{0.0, 0.0}; acc_lo[rp] = d2{0.0, 0.0};
-      }
-      // the VecAXPY operand of this sub-tile: fetched early in the chain (staggered like the loads)
-      auto acc_fn = [&] {
-        if (acc_on) {
-#pragma unroll
-          for (int rp = 0; rp < 2; rp++) {
-            acc_hi[rp] = *(ok_hi[rp] ? (const d2 *)(p.acc + a_hi[rp]) : zero2);
-            acc_lo[rp] = *(ok_lo[rp] ? (const d2 *)(p.acc + a_lo[rp]) : zero2);
-            if (acc2_on) {
-              acc_hi[rp] = acc_hi[rp] + *(ok_hi[rp] ? (const d2 *)(p.acc2 + a_hi[rp]) : zero2);
-              acc_lo[rp] = acc_lo[rp] + *(ok_lo[rp] ? (const d2 *)(p.acc2 + a_lo[rp]) : zero2);
-            }
-          }
-        }
-      };
-      if (!STAG) acc_fn();
-
-#ifdef CHEB_STAMPS
-      STAMP(st_t1); st_pre += st_t1 - st_t0;
-#endif
-      v4d ce = {0.0, 0.0, 0.0, 0.0}, co = {0.0, 0.0, 0.0, 0.0};
-      {
-        const int frag = JFAST ? (nb + l16) * LDJ + kq : kq * NT + ((nb + l16) ^ ((kq & 1) << 4));
-        const double *fE = sE + frag, *fO = sO + frag;
-        double fb[2][4];
-        fb[0][0] = fE[0]; fb[0][1] = fE[KSTR]; fb[0][2] = fO[0]; fb[0][3] = fO[KSTR];
-#pragma unroll
-        for (int g = 0; g < KS / 2; g++) {
-          const int cb = g & 1, nbuf = cb ^ 1;
-          if (g + 1 < KS / 2) {
-            fb[nbuf][0] = fE[(2 * g + 2) * KSTR]; fb[nbuf][1] = fE[(2 * g + 3) * KSTR];
-            fb[nbuf][2] = fO[(2 * g + 2) * KSTR]; fb[nbuf][3] = fO[(2 * g + 3) * KSTR];
-          }
-          // fence: keep the fragment reads of group g+1 ABOVE the MFMAs of group g (hipcc otherwise sinks
-          // them to just before their use and every group starts with an exposed LDS round trip)
-          __builtin_amdgcn_sched_barrier(0);
-          if (STAG) {
-            // The loads of the chunk after next and the parity split of the chunk that has arrived sit
-            // INSIDE the chain, at different places for the two waves of a SIMD (waves 0-3 / 4-7): while
-            // one wave issues its memory and LDS-write instructions the other keeps the MFMA pipe busy.
-            if (g == (grpB ? 0 : KS / 8)) { acc_fn(); issue_fn(); }
-            if (g == (grpB ? KS / 4 : 3 * KS / 8)) park_fn();
-          }
-          if (!JFAST) {
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g], fb[cb][0], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g), fb[cb][2], co, 0, 0, 0);
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[2 * g + 1], fb[cb][1], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(AO(2 * g + 1), fb[cb][3], co, 0, 0, 0);
-          } else {
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], AO(2 * g), co, 0, 0, 0);
-            ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], AO(2 * g + 1), co, 0, 0, 0);
-          }
+          ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][0], ae[2 * g], ce, 0, 0, 0);
+          co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][2], ao[2 * g], co, 0, 0, 0);
+          ce = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][1], ae[2 * g + 1], ce, 0, 0, 0);
+          co = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cb][3], ao[2 * g + 1], co, 0, 0, 0);
         }
       }
-#ifdef CHEB_STAMPS
-      STAMP(st_t0); st_chain += st_t0 - st_t1;
-#endif
-      if (!STAG) park_fn();                                 // before the stores: the wait covers loads only
-
-      // hi = value of row i, lo = value of the mirror row n-i  (D: b - a;  D D: a - b)
-      double hi[4], lo[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        if (raw_out) { hi[r] = ce[r]; lo[r] = co[r]; }
-        else { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
-      }
-#pragma unroll
-      for (int rp = 0; rp < 2; rp++) {
-        // even lane keeps row 2rp and gets the neighbour's row 2rp; odd lane keeps row 2rp+1
-        const double own_hi = odd ? hi[2 * rp + 1] : hi[2 * rp], snd_hi = odd ? hi[2 * rp] : hi[2 * rp + 1];
-        const double own_lo = odd ? lo[2 * rp + 1] : lo[2 * rp], snd_lo = odd ? lo[2 * rp] : lo[2 * rp + 1];
-        const double rcv_hi = swap1(snd_hi), rcv_lo = swap1(snd_lo);
-        d2 vh = odd ? d2{rcv_hi, own_hi} : d2{own_hi, rcv_hi};   // ascending columns / points
-        d2 vl;
-        if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
-        else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};  // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
-        if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};   // (y_ie, y_{n-ie}) : adjacent when H is odd
-        if (mul_on) { vh = acc_hi[rp] * (alpha * vh); vl = acc_lo[rp] * (alpha * vl); }
-        else { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha * vl; }
-        if (ok_hi[rp]) *(d2 *)(p.out + a_hi[rp]) = vh;
-        if (ok_lo[rp]) *(d2 *)(p.out + a_lo[rp]) = vl;
-      }
-#ifdef CHEB_STAMPS
-      STAMP(st_t1); st_post += st_t1 - st_t0;
-#endif
-    };
-    if (NSUB == 2) {
-      const u32 nxt2 = nxt + t_step;
-      do_sub(0, [&] { if (has_next) issue_loads(nxt, 1, rjB, rmB); },
-                [&] { if (has_next) park_chunk(cur ^ 1, 0, rjA, rmA); });
-      do_sub(1, [&] { if (nxt2 < t_hi) issue_loads(nxt2, 0, rjA, rmA); },
-                [&] { if (has_next) park_chunk(cur ^ 1, 1, rjB, rmB); });
-    } else {
-      do_sub(0, [&] { if (has_next) issue_loads(nxt, 0, rjA, rmA); },
-                [&] { if (has_next) park_chunk(cur ^ 1, 0, rjA, rmA); });
     }
 #ifdef CHEB_STAMPS
-    STAMP(st_t0);
+    STAMP(st_t0); st_chain += st_t0 - st_t1;
+#endif
+    park_fn();                                            // before the stores: the wait covers loads only
+
+    // hi = value of row i, lo = value of the mirror row n-i  (D: b - a;  D D: a - b)
+    double hi[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (raw_out) { hi[r] = ce[r]; lo[r] = co[r]; }
+      else { hi[r] = ce[r] + co[r]; lo[r] = p.sym ? ce[r] - co[r] : co[r] - ce[r]; }
+    }
+#pragma unroll
+    for (int rp = 0; rp < 2; rp++) {
+      // even lane keeps row 2rp and gets the neighbour's row 2rp; odd lane keeps row 2rp+1
+      const double own_hi = odd ? hi[2 * rp + 1] : hi[2 * rp], snd_hi = odd ? hi[2 * rp] : hi[2 * rp + 1];
+      const double own_lo = odd ? lo[2 * rp + 1] : lo[2 * rp], snd_lo = odd ? lo[2 * rp] : lo[2 * rp + 1];
+      const double rcv_hi = swap1(snd_hi), rcv_lo = swap1(snd_lo);
+      d2 vh = odd ? d2{rcv_hi, own_hi} : d2{own_hi, rcv_hi};   // ascending columns / points
+      d2 vl;
+      if (!JFAST) vl = odd ? d2{rcv_lo, own_lo} : d2{own_lo, rcv_lo};
+      else vl = odd ? d2{own_lo, rcv_lo} : d2{rcv_lo, own_lo};  // mirrors of (ie, ie+1) are (n-ie, n-ie-1): descending
+      if (JFAST && fold[rp]) vh = d2{vh.x, odd ? rcv_lo : own_lo};   // (y_ie, y_{n-ie}) : adjacent when H is odd
+      if (!ACC) { vh = alpha * vh; vl = alpha * vl; }
+      else if (mul_on) { vh = acc_hi[rp] * (alpha * vh); vl = acc_lo[rp] * (alpha * vl); }
+      else { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha * vl; }
+      if (ok_hi[rp]) *(d2 *)(p.out + a_hi[rp]) = vh;
+      if (ok_lo[rp]) *(d2 *)(p.out + a_lo[rp]) = vl;
+    }
+#ifdef CHEB_STAMPS
+    STAMP(st_t1); st_post += st_t1 - st_t0;
 #endif
     lds_barrier_v();
 #ifdef CHEB_STAMPS
-    STAMP(st_t1); st_bar += st_t1 - st_t0;
+    STAMP(st_t0); st_bar += st_t0 - st_t1;
 #endif
-    cur ^= 1;
+  };
+
+  const u32 t2 = 2 * t_step;
+  if (!TWO) {
+    // one register set: tile t + 2 is requested right after the split of tile t + 1 (it lands under the stores, the barrier and the next chain)
+    for (int cur = 0; tile < t_hi; tile += t_step, cur ^= 1)
+      tile_body(cur, [] {}, [&] {                          // (uniform branches: a workgroup's last tile asks for nothing -- IN_SUM3 would wait for it)
+        if (tile + t_step < t_hi) park_chunk(cur ^ 1, LA);
+        if (tile + t2 < t_hi) issue_loads(tile + t2, true, LA);
+      });
+  } else {
+    for (;;) {
+      tile_body(0, [&] { issue_loads(tile + t2, tile + t2 < t_hi, LA); }, [&] { park_chunk(1, LB); });
+      tile += t_step; if (tile >= t_hi) break;
+      tile_body(1, [&] { issue_loads(tile + t2, tile + t2 < t_hi, LB); }, [&] { park_chunk(0, LA); });
+      tile += t_step; if (tile >= t_hi) break;
+    }
   }
 #ifdef CHEB_STAMPS
   STAMP(st_end);
@@ -348,15 +378,22 @@ __device__ __forceinline__ void vec1_body(const SweepParams &p, double *smem, co
     unsigned long long *dbg = (unsigned long long *)p.in4 + ((size_t)BID * 8 + w) * 16;
     dbg[0] = st_pre; dbg[1] = st_chain; dbg[2] = st_post; dbg[3] = st_bar;
     dbg[4] = st_loop - st_begin; dbg[5] = st_end - st_loop; dbg[6] = st_begin; dbg[7] = st_end;
+    // [8] first tiles and fragments landed, [9] tiles walked, [10] whole kernel in 100 MHz ticks, [11] in shader cycles
+    dbg[8] = st_begin - st_entry; dbg[10] = __builtin_amdgcn_s_memrealtime() - rt_entry; dbg[11] = st_end - st_entry;
+    dbg[9] = st_tiles;
   }
 #endif
 }
 
-template <int KS, bool JFAST>
-__global__ __launch_bounds__(512) void cheb_sweep_vec_kernel(const SweepParams p) {
+// (second launch bound: four waves per SIMD = two workgroups per CU, wgs_per_cu: at most 128 VGPRs)
+template <int KS, bool JFAST, bool ACC>
+__global__ __launch_bounds__(512, 4) void cheb_sweep_vec_kernel(const SweepParams p) {
   __shared__ double smem[vec_lds_doubles<KS, JFAST>()];
-  vec1_body<KS, JFAST>(p, smem, blockIdx.x, gridDim.x);
+  vec1_body<KS, JFAST, false, ACC>(p, smem, blockIdx.x, gridDim.x);
 }
+
+// odd-half fragment s of a wave: a register, or (KS = 32: the last NFL of them) its slot in LDS
+#define AO(s_) (((s_) < KR) ? ao[((s_) < KR) ? (s_) : 0] : aoL[((s_) - KR) * 64])
 
 // Diagnostic builds only (make diag, tools/stamp_probe3.py): in-kernel cycle stamps kept in SGPRs
 #ifdef CHEB_STAMPS
@@ -433,7 +470,7 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   constexpr int HP = 4 * KS;
   constexpr int NSUB = 2;
   constexpr int NT = 16 * NG * NSUB;
-  constexpr int LDJ = HP + 2;
+  constexpr int LDJ = HP + V_LDJ_PAD;
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
   constexpr int ITEMS = HP * NT / 2 / 512;
   constexpr int CH = ITEMS / NSUB;
@@ -552,8 +589,8 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
         e = d2{xj.x + xm.y, xj.y + xm.x};
         o = d2{xj.x - xm.y, xj.y - xm.x};
       }
-      *(d2 *)(dE + idx) = e;
-      *(d2 *)(dO + idx) = o;
+      lds_put2<!JFAST || (LDJ % 2 == 0)>(dE + idx, e);
+      lds_put2<!JFAST || (LDJ % 2 == 0)>(dO + idx, o);
     }
   };
 
@@ -843,7 +880,7 @@ constexpr int MULTI_MAX = 9;
 struct MultiParams { int njobs; unsigned bstart[MULTI_MAX + 1]; SweepParams job[MULTI_MAX]; };
 
 template <int KS, bool SUM3 = false>
-__global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams mp) {
+__global__ __launch_bounds__(512, (KS <= 8 ? 4 : 2)) void cheb_sweep_multi_kernel(const MultiParams mp) {
   constexpr int LDS = vec_lds_doubles<KS, true>() > vec_lds_doubles<KS, false>() ? vec_lds_doubles<KS, true>() : vec_lds_doubles<KS, false>();
   __shared__ double smem[LDS];
   int j = 0;
@@ -851,9 +888,9 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_kernel(const MultiParams
   const SweepParams &p = mp.job[j];
   const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
   if (p.inner < 16) {
-    if constexpr (KS >= 16) vec4_body<KS, true, 0>(p, smem, bid, nblk); else vec1_body<KS, true, SUM3>(p, smem, bid, nblk);
+    if constexpr (KS >= 16) vec4_body<KS, true, 0>(p, smem, bid, nblk); else vec1_body<KS, true, SUM3, false>(p, smem, bid, nblk);
   } else {
-    if constexpr (KS >= 16) vec4_body<KS, false, 0>(p, smem, bid, nblk); else vec1_body<KS, false, SUM3>(p, smem, bid, nblk);
+    if constexpr (KS >= 16) vec4_body<KS, false, 0>(p, smem, bid, nblk); else vec1_body<KS, false, SUM3, false>(p, smem, bid, nblk);
   }
 }
 
@@ -944,7 +981,8 @@ static hipError_t launch_v(const SweepParams &p0, hipStream_t stream) {
     if (p.raw && p.out_mode != OUT_STORE && !(p.out_mode == OUT_MUL && p.raw == 1)) return hipErrorInvalidValue;   // (OUT_ACC2 with raw: refused by sweep_vec_eligible)
     if (p.out_mode == OUT_MUL && p.raw != 1) return hipErrorInvalidValue;
     if (p.in_mode == IN_MUL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST>), dim3(grid), dim3(512), 0, stream, p);
+    if (p.out_mode == OUT_STORE) hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST, false>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((cheb_sweep_vec_kernel<KS, JFAST, true>), dim3(grid), dim3(512), 0, stream, p);
     sweep_note_launch();
     return hipGetLastError();
   }
@@ -1058,6 +1096,14 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
   unsigned b = 0;
   for (int j = 0; j < n; j++) { mp.bstart[j] = b; b += gs[j]; mp.job[j] = jobs[j]; }
   mp.bstart[n] = b;
+#ifdef CHEB_STAMPS
+  // diagnostic builds (tools/stamp_probe_multi.py): one stamp area of 512 x 8 x 16 words per job behind the three areas of the
+  // single launches; two sets of 9, taken in turn by successive multi-job launches (the two launches of a 64^3 StokesMatMult)
+  if (::chebhip_stamp_buf()) {
+    const int set = ::chebhip_stamp_next() & 1;
+    for (int j = 0; j < n; j++) mp.job[j].in4 = ::chebhip_stamp_buf() + (size_t)3 * (256 * 8 * 16) + (size_t)(set * 9 + j) * (512 * 8 * 16);
+  }
+#endif
   if (b == 0) { *done = true; return hipSuccess; }
   if constexpr (KS <= 8) {
     if (sum3) hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS, true>), dim3(b), dim3(512), 0, stream, mp);

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
+if os.environ.get("CHEBHIP_LIB_PATH"):      # diagnostic / A-B builds (tools/v4_overlap_ab.sh)
+    sp.LIB_PATH = os.environ["CHEBHIP_LIB_PATH"]
 for P in [int(a) for a in sys.argv[1:]] or [64, 128, 256]:
     shape = (P, P, P)
     x = torch.randn(shape, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)

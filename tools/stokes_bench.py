@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge
 sp = ge.load()
+if os.environ.get("CHEBHIP_LIB_PATH"):      # diagnostic / A-B builds (tools/v4_overlap_ab.sh)
+    sp.LIB_PATH = os.environ["CHEBHIP_LIB_PATH"]
 
 def timeit(fn, reps=50):
     for _ in range(10):

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B builds for the prologue of cheb_sweep_vec4_kernel (V4_OVERLAP / V4_FRAG_AHEAD, sweep_vec.hip):
 #   tools/libchebhip_ov0.so         the round 2-5 prologue (rotated fragment fetch, vmcnt(0) before the first tile)
+#   tools/libchebhip_ldj2.so        the round 1-5 pitch of the JFAST tile image in LDS (HP + 2 doubles: 2-way bank conflicts on the operand reads)
 #   tools/libchebhip_fa<N>.so       paced fetch with N pairs up front (arguments: the N to build, e.g. 2 4 8 16)
 #   tools/libchebhip_diag.so        shipped kernel with in-kernel cycle stamps (-DCHEB_STAMPS)
 #   tools/libchebhip_diag_ov0.so    the old prologue with stamps
@@ -17,6 +18,7 @@ build() { # name flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libchebhip_$name.so /tmp/sweep_vec_$name.o $OTHERS -ldl
 }
 build ov0 -DV4_OVERLAP=0 &
+build ldj2 -DV_LDJ_PAD=2 &
 build diag -DCHEB_STAMPS &
 build diag_ov0 -DCHEB_STAMPS -DV4_OVERLAP=0 &
 wait
