@@ -449,7 +449,9 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *                            eta' = 0 (linear rheology), instead of -eta/2 (sum_j D_j D_j v + grad div v) (read at create)
  *   poisson_launches      the constant-coefficient MatMult_Elliptic: 0 = by size (below 6 M unknowns: from 1.5 M on, in 3-D with lines of at most 128 points, two
  *                            jobs in one launch and a last direction that adds both terms as it stores, otherwise one launch of d jobs + a sum;
- *                            a launch per direction above), 1 = always the d-job launch, 2 = always a launch per direction
+ *                            above: in 3-D, while the padded field has at most 9 M values, two jobs in one launch + a last direction that adds
+ *                            both terms; otherwise a launch per direction), 1 = always the d-job launch (below 6 M unknowns), 2 = always a
+ *                            launch per direction, 3 = the two-launch form at every large 3-D size (A/B: it loses from 240^3 on)
  *   dist_exact_order      1: chebhip_dist_mult adds its terms in the serial order V = ((T_0 + A_1) + A_2) (elliptic.C:331-334), which
  *                            reproduces the one-GPU vector to the bit; 0 (default): the local terms are accumulated into one array
  *                            by the sweeps themselves, V = T_0 + (A_1 + A_2) -- equal to rounding, one array less to read

@@ -491,6 +491,7 @@ struct ell_op {
   double *W = nullptr;                  // accumulator (c->w[0] after VecZeroEntries)
   unsigned wpad = 0;                    // constant-coefficient path: row pitch of W in its padded interior layout (0: dense)
   double *Wj[2] = {nullptr, nullptr};   // constant-coefficient path, small grids: the other directions' terms of the one-launch apply (G doubles each)
+  double *W2 = nullptr; size_t wsize = 0;   // ... large 3-D grids: the second direction's term in W's padded layout (two-launch apply, made on first use)
   double *w0 = nullptr;                 // local copy of the input (c->w[0] before), lazily allocated
   std::vector<double *> gradu;          // c->gradu[d], lazily allocated
   // slab mode (multi-GPU): the handle owns the planes [lo, lo + dims[0]) of a grid whose dimension 0 has
@@ -684,6 +685,7 @@ static int ell_create(int d, const int *gdims, int lo, int hi, ell_dim0_fn dim0,
     }
   }
   OPCHK(hipMalloc((void **)&op->W, wsize * sizeof(double)));
+  op->wsize = wsize;
 #undef OPCHK
   *out = op;
   return 0;
@@ -717,7 +719,7 @@ extern "C" int ell_op_destroy(ell_op *op) {
   for (auto p : op->g) if (p) (void)hipFree(p);
   for (auto p : op->gradu_alloc) if (p) (void)hipFree(p);
   for (auto p : op->cprod_alloc) if (p) (void)hipFree(p);
-  double *singles[] = {op->W, op->Wj[0], op->Wj[1], op->w0_alloc, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
+  double *singles[] = {op->W, op->W2, op->Wj[0], op->Wj[1], op->w0_alloc, op->eta, op->deta, op->dirloc, op->hU, op->hV, op->hB};
   for (double *p : singles) if (p) (void)hipFree(p);
   if (op->ixL) (void)hipFree(op->ixL);
   delete op;
@@ -952,6 +954,10 @@ static int ell_mult_slab(ell_op *op, const double *U, double *V, hipStream_t st)
   return ell_slab_divergence(op, op->mode == COEFF_UNIT ? IN_PLAIN : IN_FLUX_FULL, op->g.data(), V, st);
 }
 
+// Largest padded field (doubles) for which the large-grid constant-coefficient apply runs as two launches (ell_op_mult): measured on
+// MI355X (profiles/r06_two_launch_ab.txt) -- a win while the four fields of the apply stay in the 256-MB Infinity Cache, a loss at 256^3.
+constexpr size_t TWO_LAUNCH_MAX = 9000000;
+
 extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream) {
   // empty vectors (a slab that owns only boundary planes) may be NULL
   if (!op || ((!U || !V) && !(op->slab && op->G == 0))) return fail(CHEBHIP_ERR_ARG, "NULL argument");
@@ -1027,12 +1033,10 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
       // dense.  Tiles of the strided directions are (outer index, 32 neighbouring points of the last dimension).
       const int d = op->d;
       const unsigned nl = (unsigned)op->dims[d - 1] - 2, nm = d == 3 ? (unsigned)op->dims[1] - 2 : 1u, wp = op->wpad;
-      for (int k = 0; k < d; k++) {
+      // direction k: input U (dense), result / operand in W's padded layout; the caller sets the output side
+      auto dir_params = [&](int k) {
         SweepParams sp = {};
         sp.in0 = U; sp.in_mode = IN_PLAIN; sp.alpha = -1.0;
-        if (k == 0) { sp.out_mode = OUT_STORE; sp.out = op->W; }
-        else if (k == d - 1) { sp.out_mode = OUT_ACC; sp.out = V; sp.acc = op->W; }
-        else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
         if (k == d - 1) {                                          // contiguous lines
           sp.ncols = op->ncols_g[k]; sp.inner = 1;
           sp.in_os = nl; sp.acc_os = wp; sp.out_os = nl;
@@ -1045,6 +1049,35 @@ extern "C" int ell_op_mult(ell_op *op, const double *U, double *V, void *stream)
           sp.acc_rs = sp.out_rs = w_rs; sp.acc_os = sp.out_os = w_os;
           sp.inner = sp.in_rs;
         }
+        return sp;
+      };
+      // d = 3 (round 6): the first two directions as ONE launch of two jobs, each storing its term in the padded layout (W, W2), and
+      // the last direction adds both as it stores, V = (t_0 + t_1) - L_2 U (OUT_ACC2) -- the chain's order, the same bits, the same
+      // 64 B/point, but two launches instead of three: one matrix fetch + pipeline fill and one launch boundary less (~13 us of a
+      // 245-us matvec at 256^3), and every workgroup of the first launch walks 16 tiles per fill instead of 8.  At KS = 32 the
+      // kernel keeps ONE set of the two operands (sweep_vec.hip, ONEBUF).  Option poisson_launches = 2: a launch per direction (A/B).
+      const int pl = opt(OPT_POISSON_LAUNCHES);
+      if (d == 3 && pl != 2 && (pl == 3 || op->wsize <= (size_t)TWO_LAUNCH_MAX) && !opt(OPT_SEPARATE_LAUNCHES) && !opt(OPT_GENERAL_KERNELS)) {
+        if (!op->W2) HIPCHK(hipMalloc((void **)&op->W2, op->wsize * sizeof(double)));
+        SweepParams last = dir_params(2);
+        last.out_mode = OUT_ACC2; last.acc = op->W; last.acc2 = op->W2; last.out = V;
+        if (sweep_vec_eligible(op->laps[op->dims[2]], last)) {
+          const DiffMat *m[2]; SweepParams sp[2];
+          for (int k = 0; k < 2; k++) {
+            sp[k] = dir_params(k);
+            sp[k].out_mode = OUT_STORE; sp[k].out = k == 0 ? op->W : op->W2;
+            m[k] = &op->laps[op->dims[k]];
+          }
+          bool done2 = false;
+          HIPCHK(sweep_launch_multi_try(2, m, sp, st, &done2));
+          if (done2) { HIPCHK(sweep_launch(op->laps[op->dims[2]], last, st)); return 0; }
+        }
+      }
+      for (int k = 0; k < d; k++) {
+        SweepParams sp = dir_params(k);
+        if (k == 0) { sp.out_mode = OUT_STORE; sp.out = op->W; }
+        else if (k == d - 1) { sp.out_mode = OUT_ACC; sp.out = V; sp.acc = op->W; }
+        else { sp.out_mode = OUT_ACC; sp.out = op->W; sp.acc = op->W; }
         HIPCHK(sweep_launch(op->laps[op->dims[k]], sp, st));
       }
       return 0;

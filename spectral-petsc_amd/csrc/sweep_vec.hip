@@ -454,14 +454,18 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_vec_kernel(const SweepParam
 #define V4_FRAG_AHEAD 2
 #endif
 
-// MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 3 = ACC2 (out = (acc + acc2) + alpha r, KS = 16 only), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
+// MODE: 0 = STORE, 1 = ACC (out = acc + alpha r), 3 = ACC2 (out = (acc + acc2) + alpha r), 2 = MUL (out = acc * (alpha r): OUT_MUL, the modal scaling of the
 // preconditioner's fast diagonalisation folded into its last forward transform -- RAW = 1 only)
 // INM: 1 = IN_MUL, every input element is multiplied by the element of in1 at the same place as it is split into LDS (the 1 / eta
 // of the preconditioner's P_1^-1 (r / eta) folded into its first forward transform -- RAW = 1, STORE only)
 template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
   constexpr bool ACC = MODE != 0, MUL = MODE == 2, ACC2 = MODE == 3;   // ACC: the operand stream exists; ACC2: two of them, (acc + acc2) + alpha r
-  static_assert(!ACC2 || (KS == 16 && RAW == 0), "OUT_ACC2: lines of 65 .. 128 points (the KS = 32 kernel has no registers for a second operand)");
+  static_assert(!ACC2 || RAW == 0, "OUT_ACC2 has no raw mode");
+  // KS = 32 has no registers for a second operand set on top of the X / Y pair (238 VGPRs of 256 in ACC mode).  Its OUT_ACC2 keeps ONE
+  // set of both operands instead: requested right after the stores of the previous sub-tile, i.e. one whole chain (~8 k cycles)
+  // before the epilogue that consumes them -- the same 32 VGPRs the X / Y pair takes.
+  constexpr bool ONEBUF = ACC2 && KS == 32;
   static_assert(INM == 0 || (RAW == 1 && MODE == 0), "IN_MUL exists for the raw forward transform with a plain store only");
   static_assert(RAW == 0 || MODE != 1, "the raw modes (sweep.h) are STORE / MUL only");
   static_assert(!MUL || RAW == 1, "OUT_MUL exists for the raw forward transform only");
@@ -807,10 +811,11 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
       // reproduce the in-flight state of the loop's back edge (operand X, chunk A, four stores) so
       // that the wait counts of the loop hold from iteration 0
       const u32 nx = tile + t_step;
-      acc_issue(tile, true, 0, accX_hi, accX_lo);
+      if constexpr (!ONEBUF) acc_issue(tile, true, 0, accX_hi, accX_lo);
       issue_loads(nx, nx < t_hi, 0, rjA, rmA);
 #pragma unroll
       for (int q = 0; q < 4; q++) st16(r_out, INVALID, d2{0.0, 0.0});
+      if constexpr (ONEBUF) acc_issue(tile, true, 0, accX_hi, accX_lo);
     }
     lds_barrier_v();
     STAMP3_MARK(st_loop);
@@ -822,17 +827,19 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
       const double *sE = smem + cur * (2 * LDS_ELEMS), *sO = sE + LDS_ELEMS;
       v4d ce, co;
       chain(sE, sO, 0, G_ISSUE, G_PARK, ce, co,
-            [&] { acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
+            [&] { if constexpr (!ONEBUF) acc_issue(tile, true, 1, accY_hi, accY_lo); issue_loads(nxt, v1, 1, rjB, rmB); },
             [&] { park_chunk(cur ^ 1, 0, rjA, rmA); },
             [&](int g) { if constexpr (FIRST) { if (g + FA < KS / 2) frag_pair(g + FA); } });
       STAMP3(0);
       epilogue(tile, 0, ce, co, accX_hi, accX_lo);
+      if constexpr (ONEBUF) acc_issue(tile, true, 1, accX_hi, accX_lo);      // the set is free again: sub-tile 1's operands ride under chain 1
       STAMP3(1);
       chain(sE, sO, 1, G_ISSUE, G_PARK, ce, co,
-            [&] { acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
+            [&] { if constexpr (!ONEBUF) acc_issue(nxt, v1, 0, accX_hi, accX_lo); issue_loads(nxt2, v2, 0, rjA, rmA); },
             [&] { park_chunk(cur ^ 1, 1, rjB, rmB); }, [](int) {});
       STAMP3(2);
-      epilogue(tile, 1, ce, co, accY_hi, accY_lo);
+      if constexpr (ONEBUF) { epilogue(tile, 1, ce, co, accX_hi, accX_lo); acc_issue(nxt, v1, 0, accX_hi, accX_lo); }
+      else epilogue(tile, 1, ce, co, accY_hi, accY_lo);
       STAMP3(3);
       lds_barrier_v();
       STAMP3(4);
@@ -905,8 +912,8 @@ static hipError_t launch_v4(const SweepParams &p, unsigned grid, hipStream_t str
     hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 2, 1>), dim3(grid), dim3(512), 0, stream, p);
   }
   else if (p.out_mode == OUT_ACC2) {
-    if constexpr (KS == 16) { if (p.raw) return hipErrorInvalidValue; hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 3>), dim3(grid), dim3(512), 0, stream, p); }
-    else return hipErrorInvalidValue;
+    if (p.raw) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 3>), dim3(grid), dim3(512), 0, stream, p);
   }
   else if (p.out_mode == OUT_ACC) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 1>), dim3(grid), dim3(512), 0, stream, p);
   else if (p.raw == 1) hipLaunchKernelGGL((cheb_sweep_vec4_kernel<KS, JFAST, 0, 1>), dim3(grid), dim3(512), 0, stream, p);
@@ -1000,8 +1007,8 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p0) {
   if (p.in_mode == IN_MUL) {                             // lines of more than 64 points, raw forward transform, plain store, dense geometry
     if (m.KS < 16 || p.raw != 1 || p.out_mode != OUT_STORE || p.in_fblocks || p.qmax || p.in_os || !p.in1 || ((size_t)p.in1 & 15)) return false;
   } else
-  if (p.out_mode == OUT_ACC2) {                          // lines of at most 128 points, plain input, no raw mode
-    if (p.in_mode != IN_PLAIN || m.KS > 16 || p.raw || p.in_fblocks || !p.acc || !p.acc2 || ((size_t)p.acc2 & 15)) return false;
+  if (p.out_mode == OUT_ACC2) {                          // plain input, no raw mode
+    if (p.in_mode != IN_PLAIN || p.raw || p.in_fblocks || !p.acc || !p.acc2 || ((size_t)p.acc2 & 15)) return false;
   } else
   if (p.in_mode != IN_PLAIN || (p.out_mode != OUT_STORE && p.out_mode != OUT_ACC && !(p.out_mode == OUT_MUL && p.raw == 1))) return false;
   const bool jfast = p.inner < 16;

@@ -353,6 +353,22 @@ def test_options_and_kernel_families_agree():
         torch.cuda.synchronize()
         assert torch.equal(Va, Vb) and torch.equal(Va, Vc), dims
         op.destroy()
+    # large 3-D grids (6 M unknowns and more, round 6): two jobs in one launch + a last direction with two operands (3: always; 0: while the
+    # padded field has at most 9 M values) against a launch per direction (2): same bits.  256-point lines (ONE operand set in the kernel),
+    # 200-point lines, a last direction of 128 interior points (the operand pair of the 128-point kernel), unequal first extents (the
+    # jobs cannot share a launch: the route falls back)
+    for dims in ((256, 256, 256), (200, 200, 200), (256, 256, 130), (256, 130, 256)):
+        op = sp.EllipticOp(dims)
+        U = torch.randn(op.global_size, dtype=torch.float64, device="cuda"); Va, Vb, Vc = torch.empty_like(U), torch.empty_like(U), torch.empty_like(U)
+        try:
+            sp.set_option("poisson_launches", 0); op.mult(U, Va); op.mult(U, Va)
+            sp.set_option("poisson_launches", 2); op.mult(U, Vb)
+            sp.set_option("poisson_launches", 3); op.mult(U, Vc); op.mult(U, Vc)
+        finally:
+            sp.set_option("poisson_launches", 0)
+        torch.cuda.synchronize()
+        assert torch.equal(Va, Vb) and torch.equal(Vc, Vb), dims
+        op.destroy()
     # the pressure gradient with each direction's end-point extrapolation folded into its matrix (the default) against the
     # three extrapolation passes of StokesPressureReduceOrder followed by plain D (option pressure_passes, read at create)
     for dims in ((48, 40, 36), (30, 41), (66, 68, 72)):
@@ -504,7 +520,7 @@ def test_cheb_apply_on_an_array_of_a_gigabyte():
 def test_fast_paths_are_the_ones_that_run():
     """Sweep-launch counts of the BASELINE-size callbacks (chebhip_launch_count: one per sweep-kernel launch, multi-job launches
     count once): a silent fall-back to a slower route -- an eligibility test that stops matching, a lost alignment -- changes them.
-      256^3 Poisson matvec                3  (one launch per direction)
+      256^3 Poisson matvec                3  (one launch per direction; fields of at most 9 M values take two, profiles/r06_two_launch_ab.txt)
       128^3 Poisson matvec                2  (two jobs + a last direction with a two-operand accumulate)
       64^3 linear StokesMatMult           2  (uniform-viscosity route: nine jobs, then the three sweeps of grad div v)
       128^3 power-law StokesMatMultVV     2  (x / y gradient, x / y divergence; the z direction is k_st_zfused16, not a sweep launch)
@@ -515,7 +531,7 @@ def test_fast_paths_are_the_ones_that_run():
     def count(fn):
         torch.cuda.synchronize(); before = L.chebhip_launch_count(); fn(); torch.cuda.synchronize(); return L.chebhip_launch_count() - before
     rnd = lambda n: torch.randn(n, dtype=torch.float64, device="cuda")
-    for P, expect in ((256, 3), (128, 2)):
+    for P, expect in ((256, 3), (208, 2), (128, 2)):
         op = sp.EllipticOp((P, P, P)); U = rnd(op.global_size); V = torch.empty_like(U)
         op.mult(U, V)
         assert count(lambda: op.mult(U, V)) == expect, P
