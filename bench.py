@@ -362,8 +362,9 @@ def extras_frac(ex):
 
 def dist_rank_compute(sp, dsp, torch, t1_us):
     """The compute side of ONE rank of the slab partition at G = 2, 4, 8, timed alone on this GPU: the handle of rank 0
-    (the largest slab) with a transport that moves nothing (chebhip_comm_create_null), so that a call runs pack, the local
-    sweeps, the pencil launch(es) and the combine / unpack of that rank and no wire.  T_1 / T_rank is the compute-side
+    (the largest slab) with the NULL transport (chebhip_comm_create_null: every "peer" is the rank itself), so that a call runs the
+    launch that fills the pencil (k_pull_pack), the local sweeps, the pencil launch(es) and the final sum (k_pull_combine) of that
+    rank -- the kernels of the direct route of csrc/dist.hip -- with every byte read locally and no wire.  T_1 / T_rank is the compute-side
     bound on the speed-up of G ranks; link time is UNMEASURED on hardware (no multi-GPU box) and comes on top.
     Config 3: chebhip_dist_mult on 256^3; config 5: StokesFunction + StokesMatMult on 128^3 power-law slabs."""
     import numpy as np
@@ -383,24 +384,21 @@ def dist_rank_compute(sp, dsp, torch, t1_us):
         comm = dsp.Comm(sp, null=(G, 0))
         D = dsp.DistPoissonC((256, 256, 256), sp, comm=comm)
         U = torch.randn(D.local_size, dtype=torch.float64, device="cuda"); V = torch.empty_like(U)
+        # default mode (round 6): the stream policy follows the transport -- nothing leaves the device here, so the local sweeps stay on
+        # the caller's stream; rank_us_two_streams (dist_single_stream = 2) is what the side stream costs when there is no wire to hide
         t = t_us(lambda: D.mult(U, V))
-        sp.set_option("dist_single_stream", 1)               # the same kernels back to back on one stream: their plain sum
+        sp.set_option("dist_single_stream", 2)
         try:
-            t1s = t_us(lambda: D.mult(U, V))
+            t2s = t_us(lambda: D.mult(U, V))
         finally:
             sp.set_option("dist_single_stream", 0)
-        rec = {"rank_us": t, "rank_us_single_stream": t1s, "bound_speedup": t1_us / min(t, t1s)}
+        rec = {"rank_us": t, "rank_us_single_stream": t, "rank_us_two_streams": t2s, "bound_speedup": t1_us / t}
         # several vectors per exchange (chebhip_dist_mult_batch): rank time PER VECTOR at nrhs = 2, 4 -- one launch per direction on the
         # stacked slabs / pencils, so the fixed cost of a launch of 256-point lines is shared
         for nrhs in (2, 4):
             Ub = torch.randn((nrhs, D.local_size), dtype=torch.float64, device="cuda"); Vb = torch.empty_like(Ub)
             tb = t_us(lambda: D.mult_batch(Ub, Vb))
-            sp.set_option("dist_single_stream", 1)
-            try:
-                tb1 = t_us(lambda: D.mult_batch(Ub, Vb))
-            finally:
-                sp.set_option("dist_single_stream", 0)
-            rec["nrhs%d_rank_us_per_vector" % nrhs] = min(tb, tb1) / nrhs
+            rec["nrhs%d_rank_us_per_vector" % nrhs] = tb / nrhs
             del Ub, Vb
         rec["bound_speedup_nrhs4"] = t1_us / rec["nrhs4_rank_us_per_vector"]
         out["poisson_256"]["G%d" % G] = rec
@@ -564,8 +562,123 @@ def solves(sp, torch):
     return out
 
 
+def local_threads_main(args):
+    """BENCH_DIST_TRANSPORT=local python bench.py --gpus N: ONE process, N rank THREADS, thread r on device r % (devices on the node) with its
+    own stream, the LOCAL transport of csrc/comm.hip (peer access between the devices; no RCCL, no messages: a rank's kernels read the
+    peers' slabs and pencil results in place, two thread rendezvous per matvec -- csrc/dist.hip "direct").  The same W / K protocol as the
+    process-per-GPU route: thread barrier + device synchronisation on both sides of the K timed steps, the MAX over the ranks, one line.
+    On a one-GPU box every rank lands on device 0: plumbing and parity, not a measurement (labelled in config.parallelism).  Never a re-exec:
+    the threads are started by this process before anything else has touched a GPU."""
+    import threading
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    sp = ge.load(); dsp = ge.load_dist()
+    G, P = args.gpus, args.size
+    ndev = torch.cuda.device_count()
+    lg = dsp.LocalGroup(sp, G)
+    bar = threading.Barrier(G)
+    walls, devms, errs, pieces, box = [0.0] * G, [0.0] * G, [None] * G, [None] * G, {}
+
+    def sync_all():
+        torch.cuda.synchronize(); bar.wait(); torch.cuda.synchronize()
+
+    def worker(r):
+        comm = None
+        try:
+            torch.cuda.set_device(r % ndev)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                comm = lg.comm(r)
+                # reduced-size parity against the oracle (rank 0 checks the concatenated slabs)
+                Ps = 34
+                small = dsp.DistPoissonC((Ps, Ps, Ps), sp, comm=comm)
+                Us = small.random_input(SEED + 1); Vs = torch.empty_like(Us)
+                small.mult(Us, Vs); st.synchronize()
+                pieces[r] = (small.slab_offset, Vs.cpu().numpy())
+                small.destroy()
+                bar.wait()
+                if r == 0:
+                    import oracle_lib as orc
+                    g = torch.Generator(device="cpu").manual_seed(SEED + 1)
+                    Uf = torch.randn((Ps - 2) ** 3, dtype=torch.float64, generator=g).numpy()
+                    ref = orc.elliptic_mult((Ps, Ps, Ps), Uf, mode=orc.FAST, nthreads=4)
+                    got = np.concatenate([p[1] for p in sorted(pieces, key=lambda t: t[0])])
+                    box["parity"] = {"rel_l2_vs_oracle": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "tolerance": 1e-10, "P": Ps, "ranks": G}
+                op = dsp.DistPoissonC((P, P, P), sp, comm=comm)
+                if r == 0:
+                    box["local_size"] = op.local_size
+                U = op.random_input(SEED); V = torch.empty_like(U)
+                for _ in range(args.spinup):
+                    op.mult(U, V)
+                sync_all()
+                for _ in range(args.warmup):
+                    op.mult(U, V)
+                sync_all()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record(st)
+                for _ in range(args.steps):
+                    op.mult(U, V)
+                e1.record(st)
+                sync_all()
+                walls[r] = time.perf_counter() - t0
+                devms[r] = e0.elapsed_time(e1)
+                assert torch.isfinite(V).all()
+                op.destroy()
+        except BaseException as e:                          # noqa: a failing rank must not leave the others at a barrier
+            errs[r] = e
+            lg.abort(); bar.abort()
+        finally:
+            if comm is not None and errs[r] is None:
+                comm.destroy()
+
+    wd = Watchdog(0)
+    wd.enter("the %d thread ranks of the LOCAL transport" % G, int(os.environ.get("BENCH_WATCHDOG_S", "600")))
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wd.leave()
+    lg.destroy()
+    for e in errs:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in errs:
+        if e is not None:
+            raise e
+    par = box["parity"]
+    if not par["rel_l2_vs_oracle"] <= par["tolerance"]:
+        raise SystemExit("parity failure: %d-rank %d^3 matvec differs from the oracle by %.3e" % (G, par["P"], par["rel_l2_vs_oracle"]))
+    wall = max(walls)
+    launches = 4 if box["local_size"] < 6000000 else 5
+    out = {
+        "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
+        "value": args.steps / wall, "unit": "matvecs/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
+        "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "3-D Poisson MatMult_Elliptic -dim %d,%d,%d (gamma=0), global N(0,1) input seed %d" % (P, P, P, SEED), "P": P,
+                   "parallelism": "slab%d+direct-pull(LOCAL transport: %d thread ranks of one process on %d device(s)%s)" % (
+                       G, G, min(G, ndev), "" if ndev >= G else "; ranks SHARE devices: plumbing and parity, not a measurement"),
+                   "launches_per_step": launches, "devices": min(G, ndev)},
+        "roofline": roofline_record(P, G, args.steps, max(devms), launches, None),
+        "device_ms_per_step": max(devms) / args.steps,
+        "parity": par,
+    }
+    out["roofline"]["kernel"] = "slab route, whole step of one GPU: k_pull_pack (reads the peers' slabs in place), cheb_sweep_multi_kernel (local directions), cheb_sweep_vec4_kernel (pencil), k_pull_combine (reads the peers' pencil results in place); 2 rendezvous, no messages"
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and os.environ.get("BENCH_DIST_TRANSPORT", "") == "local" and not args.launch_selftest:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("BENCH_DIST_TRANSPORT=local drives the N GPUs from ONE process (thread ranks): run `python bench.py --gpus N` "
+                             "without a launcher (WORLD_SIZE=%s is set)" % os.environ["WORLD_SIZE"])
+        sys.exit(local_threads_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # typed without a launcher: this process becomes the parent of the N ranks -- decided before torch is imported
         sys.exit(spawn_ranks(args))

@@ -441,7 +441,13 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
  *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
  *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120)
- *   dist_single_stream    1: chebhip_dist_mult keeps its local sweeps on the caller's stream (no overlap with the exchanges)
+ *   dist_single_stream    chebhip_dist_mult's local sweeps: 0 (default) = by transport -- on a side stream (they overlap both exchanges) when
+ *                            data leaves the device (RCCL, a callback transport, thread ranks on several devices), on the caller's stream
+ *                            when it does not (one rank, the NULL transport, thread ranks sharing one device: there the side stream only
+ *                            adds dependencies and costs 8-27 %); 1 = always the caller's stream; 2 = always the side stream
+ *   dist_packed_exchange  1: chebhip_dist_mult on a direct transport (LOCAL thread ranks, NULL) runs pack / segment exchange / final sum
+ *                            as on RCCL instead of reading the peers' slabs and pencil results in place (A/B and tests; set it before
+ *                            the first matvec of a handle, on every rank)
  *   long_lines_gemm       1: lines of 257 .. 1024 points go to rocBLAS instead of the library's own matrix-core kernel (A/B)
  *   pressure_passes       1: Stokes handles run the three boundary-extrapolation passes of StokesPressureReduceOrder before the
  *                            pressure gradient instead of folding each direction's extrapolation into its matrix (read at create)

@@ -96,7 +96,9 @@ struct chebhip_local_group {
   std::condition_variable cv;
   int count = 0; long gen = 0; bool aborted = false;
   double timeout_s = 120.0;
-  struct Slot { const chebhip::XSeg *segs = nullptr; int nseg = 0; hipEvent_t ready = nullptr, done = nullptr; const double *vals = nullptr; int device = -1; bool bound = false; } slot[MAXR];
+  struct Slot { const chebhip::XSeg *segs = nullptr; int nseg = 0; hipEvent_t ready = nullptr, done = nullptr; const double *vals = nullptr; int device = -1; bool bound = false;
+                hipEvent_t xev[chebhip::COMM_NEV] = {nullptr, nullptr, nullptr, nullptr}; const double *xptr[2][chebhip::COMM_NPTR] = {{nullptr, nullptr}, {nullptr, nullptr}};
+                unsigned long rdv = 0; } slot[MAXR];   // rdv: rendezvous this rank has made (all communicators of the group: the ranks call them in lockstep)
 
   // all G threads arrive, or the group is aborted (a rank failed, or did not come within the time limit)
   int barrier() {
@@ -138,6 +140,7 @@ extern "C" int chebhip_local_group_destroy(chebhip_local_group *g) {
   for (int r = 0; r < MAXR; r++) {
     if (g->slot[r].ready) (void)hipEventDestroy(g->slot[r].ready);
     if (g->slot[r].done) (void)hipEventDestroy(g->slot[r].done);
+    for (int k = 0; k < chebhip::COMM_NEV; k++) if (g->slot[r].xev[k]) (void)hipEventDestroy(g->slot[r].xev[k]);
   }
   delete g;
   return 0;
@@ -157,6 +160,11 @@ extern "C" int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebh
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess && !s.ready) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);       // (kept by the group, see its destroy)
   if (e == hipSuccess && !s.done) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+  for (int k = 0; k < chebhip::COMM_NEV; k++)
+    if (e == hipSuccess && !s.xev[k]) {
+      e = hipEventCreateWithFlags(&s.xev[k], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(s.xev[k], nullptr);       // never-recorded events must not be waited for: start them complete
+    }
   if (e == hipSuccess) e = hipMalloc((void **)&c->scratch, MAXR * sizeof(double));
   if (e != hipSuccess) { delete c; return chebhip_fail(CHEBHIP_ERR_DEVICE, "local comm: %s", hipGetErrorString(e)); }
   {
@@ -237,6 +245,53 @@ namespace chebhip {
 int comm_size(const chebhip_comm *c) { return c ? c->G : 1; }
 int comm_rank(const chebhip_comm *c) { return c ? c->rank : 0; }
 void comm_abort(chebhip_comm *c) { if (c && c->kind == KIND_LOCAL && c->lg) c->lg->abort(); }
+
+bool comm_direct(const chebhip_comm *c) { return c && (c->kind == KIND_LOCAL || c->kind == KIND_NULL); }
+bool comm_is_null(const chebhip_comm *c) { return c && c->kind == KIND_NULL; }
+bool comm_overlap_pays(const chebhip_comm *c) {
+  if (!c || c->G == 1 || c->kind == KIND_NULL) return false;
+  if (c->kind != KIND_LOCAL) return true;
+  std::lock_guard<std::mutex> lk(c->lg->mu);
+  const int dev = c->lg->slot[c->rank].device;
+  for (int r = 0; r < c->G; r++) if (c->lg->slot[r].bound && c->lg->slot[r].device != dev) return true;
+  return false;                                   // every rank of the group drives the same device: a side stream only adds dependencies
+}
+int comm_group_barrier(chebhip_comm *c) { return (c && c->kind == KIND_LOCAL) ? c->lg->barrier() : 0; }
+
+int comm_mark(chebhip_comm *c, int slot, hipStream_t st) {
+  if (!c || c->kind != KIND_LOCAL) return 0;
+  if (slot < 0 || slot >= COMM_NEV) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_mark: bad slot");
+  hipError_t e = hipEventRecord(c->lg->slot[c->rank].xev[slot], st);
+  if (e != hipSuccess) { c->lg->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+  return 0;
+}
+
+int comm_rendezvous(chebhip_comm *c, const double *const *ptrs, int n, int slot, int wait_slot, hipStream_t st, PeerView *out) {
+  if (!c || !out || n < 0 || n > COMM_NPTR || slot < 0 || slot >= COMM_NEV || wait_slot >= COMM_NEV) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_rendezvous: bad argument");
+  if (c->kind == KIND_NULL) {                    // one rank stands for all of them: every peer's arrays are this rank's own
+    for (int r = 0; r < c->G; r++) for (int k = 0; k < COMM_NPTR; k++) out->ptr[r][k] = k < n ? ptrs[k] : nullptr;
+    return 0;
+  }
+  if (c->kind != KIND_LOCAL) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_rendezvous: the transport has no directly addressable peers");
+  chebhip_local_group *g = c->lg;
+  auto &me = g->slot[c->rank];
+  hipError_t e = hipEventRecord(me.xev[slot], st);                     // my arrays are complete at this point of my stream
+  if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
+  // ONE host barrier per rendezvous: the pointer tables alternate (a rank that is already posting rendezvous n + 1 writes the other
+  // table than the one a slow rank still reads for n, and nobody reaches n + 2 before everybody has passed the barrier of n + 1);
+  // an event slot is re-recorded two rendezvous later at the earliest, after every peer has enqueued its wait on this record.
+  const int tb = (int)(me.rdv++ & 1);
+  for (int k = 0; k < COMM_NPTR; k++) me.xptr[tb][k] = k < n ? ptrs[k] : nullptr;
+  int rc = g->barrier(); if (rc) return rc;                            // every rank has posted and recorded
+  for (int r = 0; r < g->G; r++) {
+    for (int k = 0; k < COMM_NPTR; k++) out->ptr[r][k] = g->slot[r].xptr[tb][k];
+    if (r == c->rank) continue;
+    e = hipStreamWaitEvent(st, g->slot[r].xev[slot], 0);
+    if (e == hipSuccess && wait_slot >= 0) e = hipStreamWaitEvent(st, g->slot[r].xev[wait_slot], 0);
+    if (e != hipSuccess) { g->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipStreamWaitEvent: %s", hipGetErrorString(e)); }
+  }
+  return 0;
+}
 
 static int self_copies(const chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
   for (int i = 0; i < nseg; i++)

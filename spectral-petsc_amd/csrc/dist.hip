@@ -89,6 +89,49 @@ __global__ __launch_bounds__(256) void k_combine(Split sp, long m0, long M1, lon
     }
   }
 }
+// ---- direct transports (comm.h): no messages -- a rank's kernels read the peers' arrays in place --------------------------------
+// Forward: the pencil of rank r is filled from the slabs of all ranks, plane by plane -- pack and exchange in ONE launch.  One
+// workgroup per global plane i (owner s, its local plane pl = i - s0[s]): the run U_s[pl, c1r : c1r + w, :] of w R doubles lands
+// as row i of the pencil.  NULL transport: every peer pointer is the rank's own slab; pmax[s] clamps the plane so that the reads
+// stay inside it (the timing is that of a rank, the values mean nothing).
+struct PullSrc { const double *p[64]; long s0[65]; long lq[64]; long pmax[64]; long pitch[64]; };
+template <bool V2>
+__global__ __launch_bounds__(256) void k_pull_pack(PullSrc src, int G, long M1, long R, long c1r, long w, double *__restrict__ UT, long pq) {
+  const long i = blockIdx.x, q = blockIdx.z;
+  int s = 0;
+  while (s + 1 < G && i >= src.s0[s + 1]) s++;
+  long pl = i - src.s0[s]; if (pl > src.pmax[s] - 1) pl = src.pmax[s] - 1;
+  const long len = w * R;
+  const double *from = src.p[s] + q * src.lq[s] + (pl * M1 + c1r) * R;
+  double *dst = UT + q * pq + i * len;
+  const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (V2) { for (long t = t0; t < (len >> 1); t += T) ((double2 *)dst)[t] = ((const double2 *)from)[t]; }
+  else { for (long t = t0; t < len; t += T) dst[t] = from[t]; }
+}
+// Backward: V = ((T + A_1) + A_2) + ... with T read straight from the peers' pencil results -- exchange and final sum in ONE launch.
+// One workgroup per (own plane i0, peer s): the run of w_s R doubles at row s0r + i0 of TT_s (row pitch src.pitch[s] doubles).
+template <bool V2>
+__global__ __launch_bounds__(256) void k_pull_combine(Split sp, PullSrc src, long s0r, long M1, long R, APtrs A, double *__restrict__ out, long lq) {
+  const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G;
+  const long q = blockIdx.z;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = q * lq + (i0 * M1 + sp.c1[s]) * R;
+  const double *from = src.p[s] + q * src.lq[s] + (s0r + i0) * src.pitch[s];
+  const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (V2) {
+    for (long t = t0; t < (len >> 1); t += T) {
+      double2 v = ((const double2 *)from)[t];
+      for (int k = 0; k < A.n; k++) { const double2 a = ((const double2 *)(A.p[k] + e0))[t]; v.x = v.x + a.x; v.y = v.y + a.y; }
+      ((double2 *)(out + e0))[t] = v;
+    }
+  } else {
+    for (long t = t0; t < len; t += T) {
+      double v = from[t];
+      for (int k = 0; k < A.n; k++) v = v + A.p[k][e0 + t];
+      out[e0 + t] = v;
+    }
+  }
+}
+
 static void split_sizes(long n, int parts, std::vector<long> &sz) { sz.resize(parts); for (int i = 0; i < parts; i++) sz[i] = n / parts + (i < n % parts ? 1 : 0); }
 
 }  // namespace
@@ -117,6 +160,7 @@ struct chebhip_dist {
   chebhip_comm *comm = nullptr, *own_comm = nullptr;   // transport (comm.hip); own_comm: made by chebhip_dist_use_rccl
   std::vector<XSeg> segs;
   Split split;
+  bool used_direct = false;                   // a matvec has run with the peers reading this rank's arrays in place (chebhip_dist_destroy)
 };
 
 static void dist_work_free(chebhip_dist::Work *W) {
@@ -131,6 +175,12 @@ static void dist_work_free(chebhip_dist::Work *W) {
 
 extern "C" int chebhip_dist_destroy(chebhip_dist *D) {
   if (!D) return 0;
+  if (D->used_direct && D->comm) {
+    // the peers' kernels read this rank's pencil results in place: nothing is freed before every rank has drained its device
+    // (collective among the rank threads; an aborted group returns at once)
+    (void)hipDeviceSynchronize();
+    (void)chebhip::comm_group_barrier(D->comm);
+  }
   for (auto &kv : D->w) dist_work_free(kv.second);
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->ev_in) (void)hipEventDestroy(D->ev_in);
@@ -154,7 +204,9 @@ static int dist_work_build(chebhip_dist *D, int nrhs, chebhip_dist::Work *W) {
     int rc = nrhs == 1 ? cheb_plan_create_trimmed(d, 0, pd.data() + 1, &W->pencil_plan) : cheb_plan_create_trimmed(d + 1, 1, pd.data(), &W->pencil_plan);
     if (rc) return rc;
   }
-  const size_t lb = (size_t)(D->local > 0 ? D->local : 1) * nrhs * sizeof(double), pb = (size_t)(D->pencil > 0 ? D->pencil : 1) * nrhs * sizeof(double);
+  // (the pencils carry one row of slack: with the NULL transport a rank reads its own pencil with the peers' column counts)
+  long wmax = 0; for (int s = 0; s < D->G; s++) wmax = D->m1[s] > wmax ? D->m1[s] : wmax;
+  const size_t lb = (size_t)(D->local > 0 ? D->local : 1) * nrhs * sizeof(double), pb = ((size_t)(D->pencil > 0 ? D->pencil : 1) * nrhs + (size_t)(wmax + 1) * D->R) * sizeof(double);
   W->A.assign(d - 1, nullptr);
   for (int k = 0; k < d - 1; k++) DHIPCHK(hipMalloc((void **)&W->A[k], lb));
   DHIPCHK(hipMalloc((void **)&W->sendbuf, lb)); DHIPCHK(hipMalloc((void **)&W->recvbuf, lb));
@@ -251,7 +303,11 @@ static int exchange(chebhip_dist *D, int nrhs, const double *send, long sq, cons
 }
 
 static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, double *V, hipStream_t st) {
-  const bool one_stream = chebhip::opt(chebhip::OPT_DIST_SINGLE_STREAM) != 0;     // "dist_single_stream": no overlap, no cross-stream dependencies
+  // "dist_single_stream": 1 = the local sweeps stay on the caller's stream, 2 = always on the side stream, 0 (default) = by transport:
+  // the side stream overlaps the local sweeps with the exchanges, and costs 8-27 % when nothing travels off the device (one rank, the
+  // NULL transport, thread ranks sharing one GPU: bench.py dist_rank_compute, round 5) -- there it is not used.
+  const int ss = chebhip::opt(chebhip::OPT_DIST_SINGLE_STREAM);
+  const bool one_stream = ss == 1 || (ss == 0 && !(D->xfn ? D->G > 1 : chebhip::comm_overlap_pays(D->comm)));
   hipStream_t side = one_stream ? st : D->side;
   const int d = D->d, r = D->rank, nrhs = W->nrhs;
   const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
@@ -290,6 +346,54 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
   unsigned gy = 1;
   { long wmax = 0; for (int s = 0; s < D->G; s++) wmax = D->m1[s] > wmax ? D->m1[s] : wmax; const long len = wmax * R; gy = (unsigned)((len + 2047) / 2048); if (gy < 1) gy = 1; if (gy > 64) gy = 64; }
   const dim3 grid(grid1, gy, (unsigned)nrhs);
+  // Direct transports (LOCAL thread ranks with peer access, NULL): no pack, no messages, no unpack -- the forward exchange IS the
+  // launch that fills the pencil from the peers' slabs, the backward exchange IS the final sum reading the peers' pencil results.
+  // Two host rendezvous per matvec.  Option "dist_packed_exchange" = 1: pack / comm_exchange / combine as for RCCL (A/B, tests).
+  const bool direct = !D->xfn && D->comm && chebhip::comm_direct(D->comm) && !chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE) && D->G <= 64;
+  if (direct) {
+    D->used_direct = true;
+    const bool null = chebhip::comm_is_null(D->comm);
+    chebhip::PeerView pv;
+    PullSrc ps;
+    const double *post[1] = {U};
+    // slot 0: "my U is complete"; wait for the peers' slot 3 of the previous matvec: they have finished reading my TT, which the pencil launch below rewrites
+    if (!rc) rc = chebhip::comm_rendezvous(D->comm, post, 1, 0, 3, st, &pv);
+    if (!rc && D->pencil > 0) {
+      for (int s = 0; s < D->G; s++) {
+        ps.p[s] = pv.ptr[s][0]; ps.s0[s] = D->s0[s]; ps.lq[s] = null ? lq : D->m0[s] * M1 * R; ps.pmax[s] = null ? (m0 > 0 ? m0 : 1) : D->m0[s]; ps.pitch[s] = 0;
+      }
+      ps.s0[D->G] = D->s0[D->G];
+      const long wr = D->m1[r]; const long len = wr * R;
+      unsigned gyp = (unsigned)((len + 2047) / 2048); if (gyp < 1) gyp = 1; if (gyp > 64) gyp = 64;
+      const dim3 gridp((unsigned)D->M[0], gyp, (unsigned)nrhs);
+      bool v2p = (((R & 1) == 0) || ((M1 & 1) == 0 && (D->s1[r] & 1) == 0 && (wr & 1) == 0)) && (nrhs == 1 || (pq & 1) == 0);
+      for (int s = 0; s < D->G && v2p; s++) v2p = ((size_t)ps.p[s] & 15) == 0 && (nrhs == 1 || (ps.lq[s] & 1) == 0);
+      if (v2p) hipLaunchKernelGGL((k_pull_pack<true>), gridp, dim3(256), 0, st, ps, D->G, M1, R, D->s1[r], wr, W->UT, pq);
+      else hipLaunchKernelGGL((k_pull_pack<false>), gridp, dim3(256), 0, st, ps, D->G, M1, R, D->s1[r], wr, W->UT, pq);
+      if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pull_pack launch failed");
+    }
+    if (!rc) rc = chebhip::comm_mark(D->comm, 2, st);                                                                     // my reads of the peers' U end here
+    if (!rc) rc = cheb_apply_lap1d(W->pencil_plan, W->UT, nullptr, -1.0, W->TT, st);                                      // TT = -L_0 UT
+    post[0] = W->TT;
+    // slot 1: "my TT is complete"; wait for the peers' slot 2: they have finished reading my U (the caller may rewrite it after this call)
+    if (!rc) rc = chebhip::comm_rendezvous(D->comm, post, 1, 1, 2, st, &pv);
+    hipError_t e2 = one_stream ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
+    if (rc) { chebhip::comm_abort(D->comm); return rc; }
+    if (e1 != hipSuccess || e2 != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream join failed");
+    if (grid1) {
+      for (int s = 0; s < D->G; s++) {
+        const long m1s = null ? D->m1[r] : D->m1[s];
+        ps.p[s] = pv.ptr[s][0]; ps.pitch[s] = m1s * R; ps.lq[s] = null ? pq : D->M[0] * D->m1[s] * R;
+      }
+      APtrs A; A.n = exact ? d - 1 : 1; for (int k = 0; k < 9; k++) A.p[k] = k < A.n ? W->A[k] : nullptr;
+      bool v2c = v2;
+      for (int s = 0; s < D->G && v2c; s++) v2c = ((size_t)ps.p[s] & 15) == 0 && (ps.pitch[s] & 1) == 0 && (nrhs == 1 || (ps.lq[s] & 1) == 0);
+      if (v2c) hipLaunchKernelGGL((k_pull_combine<true>), dim3(grid), dim3(256), 0, st, D->split, ps, D->s0[r], M1, R, A, V, lq);
+      else hipLaunchKernelGGL((k_pull_combine<false>), dim3(grid), dim3(256), 0, st, D->split, ps, D->s0[r], M1, R, A, V, lq);
+    }
+    DHIPCHK(hipGetLastError());
+    return chebhip::comm_mark(D->comm, 3, st);                                                                          // my reads of the peers' TT end here
+  }
   if (!rc && grid1) {
     if (v2) hipLaunchKernelGGL((k_pack<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, W->sendbuf, own, own_in, lq, pq);
     else hipLaunchKernelGGL((k_pack<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, W->sendbuf, own, own_in, lq, pq);

@@ -11,7 +11,7 @@ namespace {
 struct OptDesc { const char *name; int def; };
 const OptDesc g_opt_desc[OPT_COUNT] = {
   {"general_kernels", 0}, {"separate_launches", 0}, {"vendor_gemm", 0}, {"no_raw_transforms", 0}, {"equal_shares", 0}, {"force_gemm", 0},
-  {"stokes_single_stream", 0}, {"eta_from_memory", 0}, {"gather_pass", 0}, {"rccl_self_messages", 0}, {"local_timeout_s", 120}, {"full_stress_storage", 0}, {"dist_single_stream", 0}, {"long_lines_gemm", 0}, {"pressure_passes", 0}, {"general_viscous", 0}, {"poisson_launches", 0}, {"dist_exact_order", 0}, {"fdm_passes", 0}, {"saddle_node_major", 0}, {"stokes_z_separate", 0}, {"fdm_z_separate", 0}, {"stokes_pressure_stream", 0}, {"krylov_exact_norm", 0}, {"stokes_pressure_sweeps", 0},
+  {"stokes_single_stream", 0}, {"eta_from_memory", 0}, {"gather_pass", 0}, {"rccl_self_messages", 0}, {"local_timeout_s", 120}, {"full_stress_storage", 0}, {"dist_single_stream", 0}, {"long_lines_gemm", 0}, {"pressure_passes", 0}, {"general_viscous", 0}, {"poisson_launches", 0}, {"dist_exact_order", 0}, {"fdm_passes", 0}, {"saddle_node_major", 0}, {"stokes_z_separate", 0}, {"fdm_z_separate", 0}, {"stokes_pressure_stream", 0}, {"krylov_exact_norm", 0}, {"stokes_pressure_sweeps", 0}, {"dist_packed_exchange", 0},
 };
 std::atomic<int> g_opt_val[OPT_COUNT];
 std::once_flag g_opt_once;

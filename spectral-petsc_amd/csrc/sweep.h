@@ -173,7 +173,7 @@ int sweep_num_cus(hipError_t *err);
 // Run-time options of the library (chebhip_set_option, include/chebhip.h): named integer switches read where they apply.
 // Nothing in the library reads the environment.
 enum OptId { OPT_GENERAL_KERNELS = 0, OPT_SEPARATE_LAUNCHES, OPT_VENDOR_GEMM, OPT_NO_RAW_TRANSFORMS, OPT_EQUAL_SHARES, OPT_FORCE_GEMM,
-             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_DIST_EXACT_ORDER, OPT_FDM_PASSES, OPT_SADDLE_NODE_MAJOR, OPT_STOKES_Z_SEPARATE, OPT_FDM_Z_SEPARATE, OPT_STOKES_PRESSURE_STREAM, OPT_KRYLOV_EXACT_NORM, OPT_STOKES_PRESSURE_SWEEPS, OPT_COUNT };
+             OPT_STOKES_SINGLE_STREAM, OPT_ETA_FROM_MEMORY, OPT_GATHER_PASS, OPT_RCCL_SELF_MESSAGES, OPT_LOCAL_TIMEOUT_S, OPT_FULL_STRESS, OPT_DIST_SINGLE_STREAM, OPT_LONG_LINES_GEMM, OPT_PRESSURE_PASSES, OPT_GENERAL_VISCOUS, OPT_POISSON_LAUNCHES, OPT_DIST_EXACT_ORDER, OPT_FDM_PASSES, OPT_SADDLE_NODE_MAJOR, OPT_STOKES_Z_SEPARATE, OPT_FDM_Z_SEPARATE, OPT_STOKES_PRESSURE_STREAM, OPT_KRYLOV_EXACT_NORM, OPT_STOKES_PRESSURE_SWEEPS, OPT_DIST_PACKED_EXCHANGE, OPT_COUNT };
 int opt(int id);
 void opt_set(int id, int value);
 const char *opt_name(int id);

@@ -98,6 +98,26 @@ def test_bench_gpus_2_batched_leg_runs_under_the_gloo_rehearsal():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_local_transport_threads_print_one_parsed_line():
+    """BENCH_DIST_TRANSPORT=local -- one process, N thread ranks (device r % count), the LOCAL transport with the
+    peers' arrays read in place.  On the one-GPU box both ranks land on device 0: one parsed line with parity, labelled plumbing."""
+    r = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "2", "--size", "64"], {"BENCH_DIST_TRANSPORT": "local"}, 900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    rec = lines[0]
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["parity"]["rel_l2_vs_oracle"] <= 1e-10 and rec["parity"]["ranks"] == 2
+    assert "direct-pull(LOCAL transport: 2 thread ranks" in rec["config"]["parallelism"] and "not a measurement" in rec["config"]["parallelism"]
+    assert rec["roofline"]["priced_per"] == "step of one GPU" and rec["roofline"]["avg_launch_us"] is None
+
+
+def test_local_transport_refuses_a_process_launcher():
+    r = run_bench(["--gpus", "2", "--steps", "1"], {"BENCH_DIST_TRANSPORT": "local", "WORLD_SIZE": "2", "RANK": "0"}, 120)
+    assert r.returncode != 0 and "ONE process" in r.stderr
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_as_typed_prints_one_parsed_line():
     r = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "2", "--size", "64"],
                   {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1"}, 900)

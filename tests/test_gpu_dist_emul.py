@@ -71,12 +71,65 @@ def poisson_ranks(dims, G, U):
     return np.concatenate([p[1] for p in parts])
 
 
-@pytest.mark.parametrize("G,dims", [(2, (12, 11, 10)), (3, (13, 9)), (4, (34, 31, 18)), (8, (66, 40, 12)), (5, (20, 7, 6, 5))], ids=str)
-def test_poisson_thread_ranks_small(G, dims):
+@pytest.mark.parametrize("packed", [0, 1], ids=["direct_pull", "packed_exchange"])
+@pytest.mark.parametrize("G,dims", [(2, (12, 11, 10)), (3, (13, 9)), (4, (34, 31, 18)), (8, (66, 40, 12)), (5, (20, 7, 6, 5)), (3, (21, 16, 11)), (8, (70, 68, 66))], ids=str)
+def test_poisson_thread_ranks_small(G, dims, packed):
+    """Thread ranks on the LOCAL transport.  direct_pull (default, round 6): no pack, no messages -- the launch that fills a rank's
+    pencil reads the peers' slabs in place and the final sum reads the peers' pencil results (two rendezvous per matvec);
+    packed_exchange (option dist_packed_exchange = 1): pack / segment exchange / combine, the sequence the RCCL transport runs.
+    Even and odd trailing extents (16-byte and 8-byte runs), uneven splits, d = 2 .. 4."""
+    sp = ge.load()
     rng = np.random.default_rng(SEED)
     U = rng.standard_normal(int(np.prod([v - 2 for v in dims])))
-    V = poisson_ranks(dims, G, U)
+    sp.set_option("dist_packed_exchange", packed)
+    try:
+        V = poisson_ranks(dims, G, U)
+    finally:
+        sp.set_option("dist_packed_exchange", 0)
     assert relerr(V, orc.elliptic_mult(dims, U, mode=orc.DIRECT)) < 1e-10
+
+
+def test_poisson_direct_pull_equals_packed_exchange_to_the_bit():
+    """The two LOCAL routes run the same kernels on the same values in the same order (the pulls only move them): with
+    dist_exact_order = 1 both reproduce the serial handle's vector to the bit, at a size where 16-byte runs, uneven column blocks
+    (68 = 4 x 9 + 4 x 8) and the two-job local launch all occur; several calls in a row (events and pointer tables are reused)."""
+    sp = ge.load(); dsp = ge.load_dist()
+    dims, G = (70, 70, 66), 8
+    g = int(np.prod([v - 2 for v in dims]))
+    U = np.random.default_rng(SEED + 9).standard_normal((3, g))
+
+    def body(r, comm):
+        D = dsp.DistPoissonC(dims, sp, comm=comm)
+        o, n = D.slab_offset, D.local_size
+        outs = []
+        for packed in (0, 1):
+            sp_local = packed                                   # (the option is process-wide: every rank sets the same value between collectives)
+            comm.allreduce_sum(0.0)                             # all ranks have finished the previous leg before the switch
+            if r == 0:
+                sp.set_option("dist_packed_exchange", sp_local)
+            comm.allreduce_sum(0.0)
+            Vs = []
+            for k in range(3):
+                Ul = torch.from_numpy(U[k, o:o + n].copy()).cuda(); Vl = torch.full_like(Ul, float("nan"))
+                D.mult(Ul, Vl)
+                Vs.append(Vl)
+            torch.cuda.current_stream().synchronize()
+            outs.append(torch.stack(Vs).cpu().numpy())
+        D.destroy()
+        return (o, outs[0], outs[1])
+    sp.set_option("dist_exact_order", 1)
+    try:
+        parts = sorted(run_ranks(G, body), key=lambda t: t[0])
+    finally:
+        sp.set_option("dist_exact_order", 0); sp.set_option("dist_packed_exchange", 0)
+    Vd = np.concatenate([p[1] for p in parts], axis=1); Vp = np.concatenate([p[2] for p in parts], axis=1)
+    assert np.array_equal(Vd, Vp)
+    ser = sp.EllipticOp(dims)
+    for k in range(3):
+        Ud = torch.from_numpy(U[k]).cuda(); Vd_ = torch.empty_like(Ud)
+        ser.mult(Ud, Vd_); torch.cuda.synchronize()
+        assert np.array_equal(Vd[k], Vd_.cpu().numpy())
+    ser.destroy()
 
 
 @pytest.mark.parametrize("G,dims,nrhs", [(3, (13, 12, 10), 3), (2, (9, 8), 2), (5, (20, 18, 11), 4), (8, (70, 68, 66), 2)], ids=str)
