@@ -31,9 +31,13 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void lds_barrier4() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// pitch of a JFAST tile-image line beyond HP doubles (odd: see sweep_vec.hip V_LDJ_PAD)
+#ifndef F4_LDJ_PAD
+#define F4_LDJ_PAD 1
+#endif
 template <int KS, bool JFAST>
 constexpr int f4_lds_doubles() {
-  constexpr int MTP = KS / 4, NG = 8 / MTP, HP = 4 * KS, NT = 32 * NG, LDJ = HP + 2;
+  constexpr int MTP = KS / 4, NG = 8 / MTP, HP = 4 * KS, NT = 32 * NG, LDJ = HP + F4_LDJ_PAD;
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
   constexpr int NFL = (KS == 32) ? (JFAST ? 7 : 8) : 0;
   return 4 * LDS_ELEMS + 8 * NFL * 64;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
   constexpr int HP = 4 * KS;
   constexpr int NSUB = 2;
   constexpr int NT = 16 * NG * NSUB;
-  constexpr int LDJ = HP + 2;
+  constexpr int LDJ = HP + F4_LDJ_PAD;   // odd: conflict-free operand reads (sweep_vec.hip V_LDJ_PAD); lines start on 8-byte boundaries
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
   constexpr int ITEMS = HP * NT / 2 / 512;            // 16-B input slots per thread per tile
   constexpr int CH = ITEMS / NSUB;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(512) void cheb_fused4_kernel(const Fused4Params p) 
       if (!JFAST) {
         *(d2 *)(inE + idx) = rj[s] + rm[s];
         *(d2 *)(inO + idx) = rj[s] - rm[s];
-      } else if (IT) {                                                   // odd index: two 8-B halves (ds_write2_b64)
+      } else if (IT || (LDJ & 1)) {                                      // odd index or odd pitch: two 8-B halves (ds_write2_b64)
         inE[idx] = rj[s].x + rm[s].y; inE[idx + 1] = rj[s].y + rm[s].x;
         inO[idx] = rj[s].x - rm[s].y; inO[idx + 1] = rj[s].y - rm[s].x;
       } else {

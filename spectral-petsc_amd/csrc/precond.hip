@@ -176,7 +176,14 @@ struct FzParams { int M, H; unsigned ncols, ntiles; const double *x; double *y; 
                   // the modal weights 1 / ((l_0[i] + l_1[j]) + l_z[k]) are formed on the fly (the association of k_modal_weights3: the same
                   // bits as its array W, which cost this launch a third of its bytes): line -> (i, j) within a field of `flines` lines
                   int d, n1; unsigned flines; const double *l0, *l1, *lz; };
-constexpr int FZ_KS = 16, FZ_LDJ = 4 * FZ_KS + 2, FZ_NT = 32;
+// (image row pitch: odd, as in sweep_vec.hip / stokes.hip -- conflict-free operand reads, 8-byte-aligned lines)
+#ifndef FZ_PAD
+#define FZ_PAD 1
+#endif
+constexpr int FZ_KS = 16, FZ_LDJ = 4 * FZ_KS + FZ_PAD, FZ_NT = 32;
+__device__ __forceinline__ void fz_put2(double *dst, double2 v) {
+  if (FZ_LDJ % 2 == 0) *(double2 *)dst = v; else { dst[0] = v.x; dst[1] = v.y; }
+}
 __global__ __launch_bounds__(256, 3) void k_fdm_zsolve16(const FzParams p) {
   // Workgroups of 256 threads (wave = m-tile, two sub-tiles of 16 lines), three per CU, out of phase with each other; the matrix
   // fragments are fetched from L2 per stage (64 KB) rather than held: 168 registers have to do
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(256, 3) void k_fdm_zsolve16(const FzParams p) {
       for (int u = 0; u < 4; u++) {
         const int id = tid + 256 * u, line = id >> 5, j = 2 * (id & 31);
         const bool two = j + 1 < H;                                    // (j + 1 == H: that point belongs to the mirror half)
-        *(double2 *)(sE + line * FZ_LDJ + j) = make_double2(rj[u].x + rm[u].y, two ? rj[u].y + rm[u].x : 0.0);
-        *(double2 *)(sO + line * FZ_LDJ + j) = make_double2(rj[u].x - rm[u].y, two ? rj[u].y - rm[u].x : 0.0);
+        fz_put2(sE + line * FZ_LDJ + j, make_double2(rj[u].x + rm[u].y, two ? rj[u].y + rm[u].x : 0.0));
+        fz_put2(sO + line * FZ_LDJ + j, make_double2(rj[u].x - rm[u].y, two ? rj[u].y - rm[u].x : 0.0));
       }
     }
     __syncthreads();

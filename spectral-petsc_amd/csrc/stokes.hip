@@ -625,7 +625,18 @@ struct ZfParams {
   // three divergence sweeps deliver -div tau + grad p and neither the pressure-gradient sweeps nor their term in the scatter exist
   const double *pL;
 };
-constexpr int ZF_KS = 16, ZF_LDJ = 4 * ZF_KS + 2, ZF_NT = 16, ZF_PG = 130;   // k-steps; image row pitch (HP + 2); lines per tile; row pitch of G_z
+// Image row pitch HP + ZF_PAD doubles.  With an ODD pad the MFMA operand reads (lane (l16, kq) reads points kq + 4k, kq + 4k + 4 of line
+// l16: ds_read2_b64) are free of bank conflicts, with pitch = 2 mod 32 each is a 2-way conflict (tools/lds_probe.hip,
+// profiles/r06_lds_probe.txt).  Measured here (tools/ldspad_ab.sh, profiles/r06_lds_probe.txt): the callback does not change (255.8 / 257.2
+// against 256.9 / 255.6 us at 128^3) -- the launch is a byte stream, the reads sit under it -- while the 8-byte park of an odd pitch costs the
+// FOLD variants four spilled VGPRs at their 256-register limit.  Shipped: 2 (ZF_PAD = 1 builds and passes the suite).
+#ifndef ZF_PAD
+#define ZF_PAD 2
+#endif
+constexpr int ZF_KS = 16, ZF_LDJ = 4 * ZF_KS + ZF_PAD, ZF_NT = 16, ZF_PG = 130;   // k-steps; image row pitch; lines per tile; row pitch of G_z
+__device__ __forceinline__ void zf_put2(double *dst, double2 v) {
+  if (ZF_LDJ % 2 == 0) *(double2 *)dst = v; else { dst[0] = v.x; dst[1] = v.y; }
+}
 // MODE 0 / 1: the node loop of StokesMatMultVV without / with the eta' S0 z term (k_st_node_vv_pair); 2: the node loop of
 // StokesFunction with the six-component storage (k_st_node_fn_pair<true>: rheology, eta, eta', symmetrised strain as state)
 template <int MODE, bool FOLD>
@@ -697,8 +708,8 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
       for (int u = 0; u < 2; u++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          *(double2 *)(sI + c * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(rj[u][c].x + rm[u][c].y, rj[u][c].y + rm[u][c].x);
-          *(double2 *)(sI + (3 + c) * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(rj[u][c].x - rm[u][c].y, rj[u][c].y - rm[u][c].x);
+          zf_put2(sI + c * IMG + sl[u] * ZF_LDJ + sj[u], make_double2(rj[u][c].x + rm[u][c].y, rj[u][c].y + rm[u][c].x));
+          zf_put2(sI + (3 + c) * IMG + sl[u] * ZF_LDJ + sj[u], make_double2(rj[u][c].x - rm[u][c].y, rj[u][c].y - rm[u][c].x));
         }
       if (FOLD) {
 #pragma unroll
@@ -854,8 +865,8 @@ __global__ __launch_bounds__(256, 2) void k_st_zfused16(const ZfParams p) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           const double2 tp = tz[k][0], tm = tz[k][1];
-          *(double2 *)(sI + k * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(tp.x + tm.y, tp.y + tm.x);
-          *(double2 *)(sI + (3 + k) * IMG + sl[u] * ZF_LDJ + sj[u]) = make_double2(tp.x - tm.y, tp.y - tm.x);
+          zf_put2(sI + k * IMG + sl[u] * ZF_LDJ + sj[u], make_double2(tp.x + tm.y, tp.y + tm.x));
+          zf_put2(sI + (3 + k) * IMG + sl[u] * ZF_LDJ + sj[u], make_double2(tp.x - tm.y, tp.y - tm.x));
         }
       }
     }
