@@ -226,6 +226,41 @@ extern "C" int cheb_apply_lap1d(cheb_plan *p, const double *x, const double *acc
   return 0;
 }
 
+// cheb_apply_lap1d along the OUTERMOST stored dimension (tr = 0, or tr = 1 of a batch) with the planes of x scattered over the arrays of
+// `g` (sweep.h GatherSrc): y = alpha * (D D x), y dense.  *done = false: this plan / these arrays cannot take the gather launch.
+namespace chebhip {
+int lap1d_gather_try(cheb_plan *p, const GatherSrc &g, double alpha, double *y, hipStream_t st, bool *done) {
+  *done = false;
+  if (!p || !p->trimmed || !y) return 0;
+  SweepParams sp = {};
+  sp.ncols = p->ncols; sp.inner = p->inner;
+  sp.in_mode = IN_PLAIN; sp.alpha = alpha; sp.out = y; sp.out_mode = OUT_STORE;
+  HIPCHK(sweep_launch_gather(p->lap, sp, g, st, done));
+  return 0;
+}
+}  // namespace chebhip
+
+namespace chebhip {
+int lap1d_multi_gather_try(int n, cheb_plan *const *plans, const double *x, double *const *outs, cheb_plan *gp, const GatherSrc &g, double *gout,
+                           double alpha, hipStream_t st, bool *done) {
+  *done = false;
+  if (n < 1 || n > 8 || !gp || !gp->trimmed || !gout) return 0;
+  const DiffMat *m[9]; SweepParams sp[9];
+  for (int k = 0; k < n; k++) {
+    if (!plans[k] || !plans[k]->trimmed) return 0;
+    sp[k] = SweepParams{};
+    sp[k].ncols = plans[k]->ncols; sp[k].inner = plans[k]->inner;
+    sp[k].in0 = x; sp[k].in_mode = IN_PLAIN; sp[k].alpha = alpha; sp[k].out = outs[k]; sp[k].out_mode = OUT_STORE;
+    m[k] = &plans[k]->lap;
+  }
+  sp[n] = SweepParams{};
+  sp[n].ncols = gp->ncols; sp[n].inner = gp->inner; sp[n].in_mode = IN_PLAIN; sp[n].alpha = alpha; sp[n].out = gout; sp[n].out_mode = OUT_STORE;
+  m[n] = &gp->lap;
+  HIPCHK(sweep_launch_multi_gather_try(n + 1, m, sp, n, g, st, done));
+  return 0;
+}
+}  // namespace chebhip
+
 // n trimmed plans on the same tensor (different directions): outs[k] = alpha * (D_k D_k x) as ONE launch of n jobs where the 16-byte
 // kernels allow it (*done), otherwise nothing is launched.  The local directions of a small slab (dist.hip).
 namespace chebhip {

@@ -303,41 +303,44 @@ static int exchange(chebhip_dist *D, int nrhs, const double *send, long sq, cons
 }
 
 static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, double *V, hipStream_t st) {
+  const int d = D->d, r = D->rank, nrhs = W->nrhs;
+  const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
+  const long lq = D->local, pq = D->pencil;                  // vector q of a batch: slab-sized arrays lq apart, pencils pq apart
+  // Direct transports (LOCAL thread ranks with peer access, NULL): no pack, no messages, no unpack -- a rank's kernels read the peers'
+  // slabs and pencil results in place, ordered by two host rendezvous per matvec.  Option "dist_packed_exchange" = 1: pack /
+  // comm_exchange / combine as for RCCL (A/B, tests).
+  const int pk = chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE);
+  const bool direct = !D->xfn && D->comm && chebhip::comm_direct(D->comm) && pk != 1 && D->G <= 64;
   // "dist_single_stream": 1 = the local sweeps stay on the caller's stream, 2 = always on the side stream, 0 (default) = by transport:
   // the side stream overlaps the local sweeps with the exchanges, and costs 8-27 % when nothing travels off the device (one rank, the
   // NULL transport, thread ranks sharing one GPU: bench.py dist_rank_compute, round 5) -- there it is not used.
   const int ss = chebhip::opt(chebhip::OPT_DIST_SINGLE_STREAM);
   const bool one_stream = ss == 1 || (ss == 0 && !(D->xfn ? D->G > 1 : chebhip::comm_overlap_pays(D->comm)));
   hipStream_t side = one_stream ? st : D->side;
-  const int d = D->d, r = D->rank, nrhs = W->nrhs;
-  const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
-  // side stream: the local directions, each into its own array (they overlap both exchanges); U is ready when the
-  // caller's stream gets here
-  if (!one_stream) { DHIPCHK(hipEventRecord(D->ev_in, st)); DHIPCHK(hipStreamWaitEvent(side, D->ev_in, 0)); }
   // "dist_exact_order" = 0 (default): the local terms are summed by the sweeps, A_1 = -L_1 U (STORE), A_1 -= L_k U (ACC): the
   // final sum reads T and ONE array, V = T + (A_1 + A_2 ..) -- the serial vector to rounding (north_star 1e-10);
   // 1: every term in an array of its own and V = ((T + A_1) + A_2) in the order of elliptic.C:331-334 -- the serial bits.
   bool exact = chebhip::opt(chebhip::OPT_DIST_EXACT_ORDER) != 0;
   int rc = 0;
+  hipError_t e1 = hipSuccess;
   // Small slabs (fewer than 6 M values: 256^3 over 4 ranks and more), d >= 3: the d - 1 local directions are ONE launch of d - 1 jobs
   // into arrays of their own, and the final sum reads them in the serial order -- at these sizes a launch costs its fixed 10-13 us
   // (matrix fetch, fill, drain), not its bytes, and the extra array sits in the Infinity Cache.  The one-GPU bits, as with the option.
-  bool local_done = false;
-  if (d >= 3 && D->local > 0 && D->local * nrhs < 6000000L && !chebhip::opt(chebhip::OPT_SEPARATE_LAUNCHES)) {
-    rc = chebhip::lap1d_multi_try(d - 1, W->slab_plan.data() + 1, U, W->A.data(), -1.0, side, &local_done);
-    if (local_done) exact = true;
-  }
-  for (int k = 1; k < d && !rc && !local_done; k++) {
-    if (exact || k == 1) rc = cheb_apply_lap1d(W->slab_plan[k], U, nullptr, -1.0, W->A[exact ? k - 1 : 0], side);
-    else rc = cheb_apply_lap1d(W->slab_plan[k], U, W->A[0], -1.0, W->A[0], side);
-  }
-  hipError_t e1 = one_stream ? hipSuccess : hipEventRecord(D->ev_out, side);
-  // caller's stream: the exchange chain.  With a chebhip_exchange_fn (the older callback contract moves every block, the
-  // own one included) everything goes through the buffers; otherwise the own block bypasses them.
-  const int own = (D->xfn || chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES)) ? -1 : r;     // (the option: one-rank smoke runs of the transport)
-  double *own_in = W->UT + D->s0[r] * D->m1[r] * R;          // where the own block sits in the pencil: rows s0[r] .. s0[r+1]
-  const double *own_out = W->TT + D->s0[r] * D->m1[r] * R;
-  const long lq = D->local, pq = D->pencil;                  // vector q of a batch: slab-sized arrays lq apart, pencils pq apart
+  const bool small = d >= 3 && D->local > 0 && D->local * nrhs < 6000000L && !chebhip::opt(chebhip::OPT_SEPARATE_LAUNCHES);
+  // the local directions, each into its own array (on the side stream they overlap both exchanges); U is ready when the caller's stream gets here
+  auto local_sweeps = [&]() {
+    if (!one_stream) { hipError_t e = hipEventRecord(D->ev_in, st); if (e == hipSuccess) e = hipStreamWaitEvent(side, D->ev_in, 0); if (e != hipSuccess) { rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream fork failed"); return; } }
+    bool local_done = false;
+    if (small) {
+      rc = chebhip::lap1d_multi_try(d - 1, W->slab_plan.data() + 1, U, W->A.data(), -1.0, side, &local_done);
+      if (local_done) exact = true;
+    }
+    for (int k = 1; k < d && !rc && !local_done; k++) {
+      if (exact || k == 1) rc = cheb_apply_lap1d(W->slab_plan[k], U, nullptr, -1.0, W->A[exact ? k - 1 : 0], side);
+      else rc = cheb_apply_lap1d(W->slab_plan[k], U, W->A[0], -1.0, W->A[0], side);
+    }
+    e1 = one_stream ? hipSuccess : hipEventRecord(D->ev_out, side);
+  };
   // 16-byte accesses: every run (c1[s+1] - c1[s]) R long starting at (i0 M1 + c1[s]) R must be even-aligned
   bool v2 = ((R & 1) == 0 || ((M1 & 1) == 0)) && (((size_t)U | (size_t)V) & 15) == 0 && (nrhs == 1 || ((lq & 1) == 0 && (pq & 1) == 0));
   if (v2 && (R & 1)) for (int s = 0; s <= D->G; s++) v2 = v2 && (D->s1[s] & 1) == 0;
@@ -346,19 +349,39 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
   unsigned gy = 1;
   { long wmax = 0; for (int s = 0; s < D->G; s++) wmax = D->m1[s] > wmax ? D->m1[s] : wmax; const long len = wmax * R; gy = (unsigned)((len + 2047) / 2048); if (gy < 1) gy = 1; if (gy > 64) gy = 64; }
   const dim3 grid(grid1, gy, (unsigned)nrhs);
-  // Direct transports (LOCAL thread ranks with peer access, NULL): no pack, no messages, no unpack -- the forward exchange IS the
-  // launch that fills the pencil from the peers' slabs, the backward exchange IS the final sum reading the peers' pencil results.
-  // Two host rendezvous per matvec.  Option "dist_packed_exchange" = 1: pack / comm_exchange / combine as for RCCL (A/B, tests).
-  const bool direct = !D->xfn && D->comm && chebhip::comm_direct(D->comm) && !chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE) && D->G <= 64;
+
   if (direct) {
     D->used_direct = true;
     const bool null = chebhip::comm_is_null(D->comm);
     chebhip::PeerView pv;
     PullSrc ps;
     const double *post[1] = {U};
-    // slot 0: "my U is complete"; wait for the peers' slot 3 of the previous matvec: they have finished reading my TT, which the pencil launch below rewrites
-    if (!rc) rc = chebhip::comm_rendezvous(D->comm, post, 1, 0, 3, st, &pv);
-    if (!rc && D->pencil > 0) {
+    // slot 0: "my U is complete"; wait for the peers' slot 3 of the previous matvec: they have finished reading my TT, which is rewritten below
+    rc = chebhip::comm_rendezvous(D->comm, post, 1, 0, 3, st, &pv);
+    // The pencil direction reads the peers' slabs IN PLACE where it can (strided lines of 66 .. 256 points, 16-byte geometry, at most
+    // GATHER_MAX ranks): the loader slots of a thread are fixed rows = fixed planes of fixed peers, so the pencil is never materialised.
+    // On a small slab it is one more job of the local directions' launch: the THREE directions of the matvec are then ONE launch
+    // (one matrix fetch, one pipeline fill; the local jobs run while the pencil job's remote reads are in flight) and the matvec is
+    // two kernels.  Otherwise (and with dist_packed_exchange = 2, the A/B switch) k_pull_pack fills UT first.
+    bool gathered = false, fused = false;
+    chebhip::GatherSrc gsrc = {};
+    bool gfits = !rc && D->pencil > 0 && D->G <= chebhip::GATHER_MAX && pk != 2 && M1 * R < 0x7fffffffL;
+    if (gfits) {
+      gsrc.G = D->G; gsrc.rowlen = (unsigned)(M1 * R); gsrc.col0 = (unsigned)(D->s1[r] * R);
+      for (int s = 0; s < D->G; s++) {
+        const long lqs = null ? lq : D->m0[s] * M1 * R;
+        gfits = gfits && lqs < 0x7fffffffL;
+        gsrc.p[s] = pv.ptr[s][0]; gsrc.s0[s] = (int)D->s0[s]; gsrc.lq[s] = (unsigned)lqs; gsrc.pmax[s] = (int)(null ? (m0 > 0 ? m0 : 1) : D->m0[s]);
+      }
+      gsrc.s0[D->G] = (int)D->s0[D->G];
+    }
+    if (!rc && gfits && small && pk != 3) {
+      rc = chebhip::lap1d_multi_gather_try(d - 1, W->slab_plan.data() + 1, U, W->A.data(), W->pencil_plan, gsrc, W->TT, -1.0, st, &fused);
+      if (fused) { exact = true; gathered = true; }
+    }
+    if (!rc && !fused) local_sweeps();
+    if (!rc && gfits && !gathered) rc = chebhip::lap1d_gather_try(W->pencil_plan, gsrc, -1.0, W->TT, st, &gathered);        // TT = -L_0 (the peers' slabs)
+    if (!rc && D->pencil > 0 && !gathered) {
       for (int s = 0; s < D->G; s++) {
         ps.p[s] = pv.ptr[s][0]; ps.s0[s] = D->s0[s]; ps.lq[s] = null ? lq : D->m0[s] * M1 * R; ps.pmax[s] = null ? (m0 > 0 ? m0 : 1) : D->m0[s]; ps.pitch[s] = 0;
       }
@@ -371,13 +394,13 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
       if (v2p) hipLaunchKernelGGL((k_pull_pack<true>), gridp, dim3(256), 0, st, ps, D->G, M1, R, D->s1[r], wr, W->UT, pq);
       else hipLaunchKernelGGL((k_pull_pack<false>), gridp, dim3(256), 0, st, ps, D->G, M1, R, D->s1[r], wr, W->UT, pq);
       if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pull_pack launch failed");
+      if (!rc) rc = cheb_apply_lap1d(W->pencil_plan, W->UT, nullptr, -1.0, W->TT, st);                                    // TT = -L_0 UT
     }
     if (!rc) rc = chebhip::comm_mark(D->comm, 2, st);                                                                     // my reads of the peers' U end here
-    if (!rc) rc = cheb_apply_lap1d(W->pencil_plan, W->UT, nullptr, -1.0, W->TT, st);                                      // TT = -L_0 UT
     post[0] = W->TT;
     // slot 1: "my TT is complete"; wait for the peers' slot 2: they have finished reading my U (the caller may rewrite it after this call)
     if (!rc) rc = chebhip::comm_rendezvous(D->comm, post, 1, 1, 2, st, &pv);
-    hipError_t e2 = one_stream ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
+    hipError_t e2 = (one_stream || fused) ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
     if (rc) { chebhip::comm_abort(D->comm); return rc; }
     if (e1 != hipSuccess || e2 != hipSuccess) return chebhip_fail(CHEBHIP_ERR_DEVICE, "chebhip_dist_mult: stream join failed");
     if (grid1) {
@@ -394,6 +417,14 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
     DHIPCHK(hipGetLastError());
     return chebhip::comm_mark(D->comm, 3, st);                                                                          // my reads of the peers' TT end here
   }
+
+  // Message transports (RCCL, callbacks; LOCAL with dist_packed_exchange = 1).  The exchange chain is the critical path and stays on
+  // the caller's stream.  With a chebhip_exchange_fn (the older callback contract moves every block, the own one included) everything
+  // goes through the buffers; otherwise the own block bypasses them.
+  local_sweeps();
+  const int own = (D->xfn || chebhip::opt(chebhip::OPT_RCCL_SELF_MESSAGES)) ? -1 : r;     // (the option: one-rank smoke runs of the transport)
+  double *own_in = W->UT + D->s0[r] * D->m1[r] * R;          // where the own block sits in the pencil: rows s0[r] .. s0[r+1]
+  const double *own_out = W->TT + D->s0[r] * D->m1[r] * R;
   if (!rc && grid1) {
     if (v2) hipLaunchKernelGGL((k_pack<true>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, W->sendbuf, own, own_in, lq, pq);
     else hipLaunchKernelGGL((k_pack<false>), dim3(grid), dim3(256), 0, st, D->split, m0, M1, R, U, W->sendbuf, own, own_in, lq, pq);

@@ -155,7 +155,19 @@ bool sweep_vec_eligible(const DiffMat &m, const SweepParams &p);
 // ... and may carry p.raw != 0 (the kernel generations that implement the raw modes)
 bool sweep_vec_raw_eligible(const DiffMat &m, const SweepParams &p);
 hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream);
+// Lines along the OUTERMOST dimension of a tensor whose planes live in up to GATHER_MAX different arrays (the pencil of a slab
+// partition read straight from the ranks' slabs, dist.hip): row i of every line is plane i - s0[s] of array p[s] (s: s0[s] <= i <
+// s0[s+1]), the columns [col0, col0 + qmax) of that plane, rowlen doubles per plane; vector o of a batch starts lq[s] doubles further.
+// pmax[s] clamps the plane index (the NULL transport reads one array with every rank's geometry).
+constexpr int GATHER_MAX = 16;
+struct GatherSrc { const double *p[GATHER_MAX]; int s0[GATHER_MAX + 1]; unsigned lq[GATHER_MAX]; int pmax[GATHER_MAX]; int G; unsigned rowlen, col0; };
+// the launch (plain input, STORE, strided lines of 66 .. 256 points, dense output); *done = false: not eligible, nothing launched
+hipError_t sweep_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done);
+hipError_t sweep_vec_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done);
 hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *jobs, hipStream_t stream, bool *done);
+hipError_t sweep_vec_launch_multi_gather(int n, const DiffMat *const *m, SweepParams *jobs, int gjob, const GatherSrc &g, hipStream_t stream, bool *done);
+// n sweeps as ONE launch, job gjob reading its lines through g; *done = false: they cannot share a launch, nothing is launched
+hipError_t sweep_launch_multi_gather_try(int n, const DiffMat *const *m, const SweepParams *p, int gjob, const GatherSrc &g, hipStream_t stream, bool *done);
 // n independent sweeps (plain in, STORE out): one launch when they qualify (sweep_vec.hip), else n launches
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream);
 // ... only if they can share ONE launch (*done = true); otherwise nothing is launched (*done = false)
@@ -167,6 +179,10 @@ struct cheb_plan;
 namespace chebhip {
 // chebhip.hip: the interior second derivative along n directions of one tensor as ONE launch (see there)
 int lap1d_multi_try(int n, cheb_plan *const *plans, const double *x, double *const *outs, double alpha, hipStream_t st, bool *done);
+int lap1d_gather_try(cheb_plan *p, const GatherSrc &g, double alpha, double *y, hipStream_t st, bool *done);
+// the n local directions (x) and the gather direction (plan gp over the arrays of g) as ONE launch of n + 1 jobs
+int lap1d_multi_gather_try(int n, cheb_plan *const *plans, const double *x, double *const *outs, cheb_plan *gp, const GatherSrc &g, double *gout,
+                           double alpha, hipStream_t st, bool *done);
 // compute units of the CURRENT device (cached per device id); 0 on error with *err set
 int sweep_num_cus(hipError_t *err);
 

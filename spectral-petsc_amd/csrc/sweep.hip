@@ -515,6 +515,14 @@ hipError_t sweep_launch(const DiffMat &m, SweepParams p, hipStream_t stream) {
   }
 }
 
+hipError_t sweep_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done) {
+  *done = false;
+  if (m.KS == 0 || opt(OPT_GENERAL_KERNELS)) return hipSuccess;
+  p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink; p.sym = m.sym;
+  p.longDT = m.longDT; p.longD = m.longD;
+  return sweep_vec_launch_gather(m, p, g, stream, done);
+}
+
 static void sweep_fill(const DiffMat &m, SweepParams &p) {
   p.P = m.P; p.H = m.H; p.fragE = m.fragE; p.fragO = m.fragO; p.fragE2 = m.fragE2; p.fragO2 = m.fragO2; p.zero = m.zero; p.sink = m.sink;
   p.sym = m.sym; p.longDT = m.longDT; p.longD = m.longD;
@@ -526,6 +534,14 @@ hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepPar
   SweepParams jobs[9];
   for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); if (m[j]->KS == 0) return hipSuccess; }
   return sweep_vec_launch_multi(n, m, jobs, stream, done);
+}
+
+hipError_t sweep_launch_multi_gather_try(int n, const DiffMat *const *m, const SweepParams *p, int gjob, const GatherSrc &g, hipStream_t stream, bool *done) {
+  *done = false;
+  if (n < 2 || n > 9 || opt(OPT_SEPARATE_LAUNCHES) || opt(OPT_GENERAL_KERNELS)) return hipSuccess;
+  SweepParams jobs[9];
+  for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); if (m[j]->KS == 0) return hipSuccess; }
+  return sweep_vec_launch_multi_gather(n, m, jobs, gjob, g, stream, done);
 }
 
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {

@@ -458,8 +458,12 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_vec_kernel(const SweepParam
 // preconditioner's fast diagonalisation folded into its last forward transform -- RAW = 1 only)
 // INM: 1 = IN_MUL, every input element is multiplied by the element of in1 at the same place as it is split into LDS (the 1 / eta
 // of the preconditioner's P_1^-1 (r / eta) folded into its first forward transform -- RAW = 1, STORE only)
-template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0>
-__device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK) {
+// GATH: the rows of every line come from up to GATHER_MAX different arrays (sweep.h GatherSrc; the pencil of a slab partition read from the
+// ranks' slabs in place, over xGMI for the remote ones): 64-bit global loads from per-thread row bases instead of the buffer loads --
+// COLFAST, plain input, STORE only.  A thread's loader slots are the same rows for every tile, so their bases are found once.
+template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0, bool GATH = false>
+__device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK, const GatherSrc *gs = nullptr) {
+  static_assert(!GATH || (!JFAST && MODE == 0 && RAW == 0 && INM == 0), "the gather loader exists for strided lines, plain input, STORE");
   constexpr bool ACC = MODE != 0, MUL = MODE == 2, ACC2 = MODE == 3;   // ACC: the operand stream exists; ACC2: two of them, (acc + acc2) + alpha r
   static_assert(!ACC2 || RAW == 0, "OUT_ACC2 has no raw mode");
   // KS = 32 has no registers for a second operand set on top of the X / Y pair (238 VGPRs of 256 in ACC mode).  Its OUT_ACC2 keeps ONE
@@ -542,6 +546,26 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     return off;
   };
 
+  // GATH: byte address of (row, first column) in vector 0 of the array that holds the row, and that array's doubles per vector,
+  // for the thread's ITEMS loader slots (row ld_b + sg QSTEP) and their mirrors
+  typedef const d2 __attribute__((address_space(1))) *gd2p;
+  unsigned long long gb_j[GATH ? ITEMS : 1], gb_m[GATH ? ITEMS : 1];
+  u32 glq_j[GATH ? ITEMS : 1], glq_m[GATH ? ITEMS : 1];
+  if constexpr (GATH) {
+    auto locate = [&](int i, unsigned long long &b, u32 &lq) {
+      int s_ = 0;
+      while (s_ + 1 < gs->G && i >= gs->s0[s_ + 1]) s_++;
+      int pl = i - gs->s0[s_]; if (pl > gs->pmax[s_] - 1) pl = gs->pmax[s_] - 1; if (pl < 0) pl = 0;
+      b = (unsigned long long)gs->p[s_] + ((unsigned long long)pl * gs->rowlen + gs->col0) * 8ull;
+      lq = gs->lq[s_];
+    };
+#pragma unroll
+    for (int sg = 0; sg < ITEMS; sg++) {
+      int row = ld_b + sg * QSTEP; if (row > nn) row = nn;       // (rows past the half meet zero columns of the matrix; they stay inside the line)
+      locate(row, gb_j[sg], glq_j[sg]);
+      locate(nn - row, gb_m[sg], glq_m[sg]);
+    }
+  }
   d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
   constexpr int ECH = INM ? CH : 1;
   d2 ejA[ECH], emA[ECH], ejB[ECH], emB[ECH];           // IN_MUL: the multipliers of chunk A / B, in flight beside them
@@ -549,6 +573,20 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   d2 acc2X_hi[2], acc2X_lo[2], acc2Y_hi[2], acc2Y_lo[2];   // ACC2 only
 
   auto issue_loads = [&](u32 tl, bool valid, int chunk, d2 (&rj)[CH], d2 (&rm)[CH]) {
+    if constexpr (GATH) {
+      // a tile past the workgroup's last re-reads tile 0 (never used); lanes past the last column of the block re-read its last pair
+      // (they feed columns that are never stored) -- every address stays inside the arrays
+      const u32 tle = valid ? tl : 0u;
+      const u32 o = tle / tpo, q0 = (tle - o * tpo) * NT;
+      u32 qq = q0 + 2u * (u32)ld_a; if (qq > qmax - 2u) qq = qmax - 2u;
+#pragma unroll
+      for (int s = 0; s < CH; s++) {
+        const int sg = chunk * CH + s;
+        rj[s] = *(gd2p)(gb_j[sg] + ((unsigned long long)o * glq_j[sg] + qq) * 8ull);
+        rm[s] = *(gd2p)(gb_m[sg] + ((unsigned long long)o * glq_m[sg] + qq) * 8ull);
+      }
+      return;
+    }
     const u32 t0 = in_tile_off(tl);
     if constexpr (INM != 0) {
       d2 (&ej)[ECH] = (&rj == &rjA) ? ejA : ejB; d2 (&em)[ECH] = (&rj == &rjA) ? emA : emB;
@@ -877,6 +915,12 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
   vec4_body<KS, JFAST, MODE, RAW, INM>(p, smem, blockIdx.x, gridDim.x);
 }
 
+template <int KS>
+__global__ __launch_bounds__(512) void cheb_sweep_vec4_gather_kernel(const SweepParams p, const GatherSrc g) {
+  __shared__ double smem[vec_lds_doubles<KS, false>()];
+  vec4_body<KS, false, 0, 0, 0, true>(p, smem, blockIdx.x, gridDim.x, &g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-job launch: up to MULTI_MAX independent plain STORE sweeps with the same KS in ONE launch.  The workgroups
 // [bstart[j], bstart[j+1]) run job j with the single-launch code; a job's share is a multiple of 8 workgroups so
@@ -899,6 +943,22 @@ __global__ __launch_bounds__(512, (KS <= 8 ? 4 : 2)) void cheb_sweep_multi_kerne
   } else {
     if constexpr (KS >= 16) vec4_body<KS, false, 0>(p, smem, bid, nblk); else vec1_body<KS, false, SUM3, false>(p, smem, bid, nblk);
   }
+}
+
+// ... with ONE of the jobs reading its lines from the arrays of a GatherSrc (lines of more than 64 points): the three directions of a
+// slab rank's matvec -- the local ones and the pencil direction over the peers' slabs -- as one launch (dist.hip)
+template <int KS>
+__global__ __launch_bounds__(512) void cheb_sweep_multi_gather_kernel(const MultiParams mp, const GatherSrc g, const int gjob) {
+  static_assert(KS >= 16, "the gather loader is part of the long-line kernel");
+  constexpr int LDS = vec_lds_doubles<KS, true>() > vec_lds_doubles<KS, false>() ? vec_lds_doubles<KS, true>() : vec_lds_doubles<KS, false>();
+  __shared__ double smem[LDS];
+  int j = 0;
+  while (j + 1 < mp.njobs && blockIdx.x >= mp.bstart[j + 1]) j++;
+  const SweepParams &p = mp.job[j];
+  const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
+  if (j == gjob) vec4_body<KS, false, 0, 0, 0, true>(p, smem, bid, nblk, &g);
+  else if (p.inner < 16) vec4_body<KS, true, 0>(p, smem, bid, nblk);
+  else vec4_body<KS, false, 0>(p, smem, bid, nblk);
 }
 
 template <int KS, bool JFAST>
@@ -1052,10 +1112,45 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
   }
 }
 
+template <int KS>
+static hipError_t launch_gather_t(SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done) {
+  const int gen = prepare_v<KS, false>(p);
+  if (gen != 4) return hipSuccess;
+  hipError_t cu_err; const int ncu = sweep_num_cus(&cu_err);
+  if (cu_err != hipSuccess) return cu_err;
+  const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
+  *done = true;
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL((cheb_sweep_vec4_gather_kernel<KS>), dim3(grid), dim3(512), 0, stream, p, g);
+  sweep_note_launch();
+  return hipGetLastError();
+}
+
+// The gather launch: the dense geometry of the tensor (qmax = inner = the columns of a block, nouter = vectors of a batch); every
+// array 16-byte aligned, every row start an even number of doubles into it.
+static bool gather_ok(const DiffMat &m, SweepParams &p, const GatherSrc &g) {
+  if (m.KS < 16 || p.inner < 16 || (p.inner & 1) || p.in_mode != IN_PLAIN || p.out_mode != OUT_STORE || p.raw || p.in_fblocks || p.qmax || p.in_os) return false;
+  if (g.G < 1 || g.G > GATHER_MAX || (g.rowlen & 1) || (g.col0 & 1) || (size_t)g.col0 + p.inner > g.rowlen) return false;
+  for (int s = 0; s < g.G; s++) if (!g.p[s] || ((size_t)g.p[s] & 15) || (g.lq[s] & 1) || g.pmax[s] < 1 || g.s0[s + 1] < g.s0[s]) return false;
+  if (g.s0[0] != 0 || g.s0[g.G] != m.P) return false;                    // the planes of the arrays are exactly the rows of a line
+  p.in0 = g.p[0];                                                          // (alignment checks and descriptor sizes of the unused buffer path)
+  return sweep_vec_eligible(m, p);
+}
+hipError_t sweep_vec_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done) {
+  *done = false;
+  if (!gather_ok(m, p, g)) return hipSuccess;
+  switch (m.KS) {
+    case 16: return launch_gather_t<16>(p, g, stream, done);
+    case 32: return launch_gather_t<32>(p, g, stream, done);
+    default: return hipSuccess;
+  }
+}
+
 // n <= MULTI_MAX independent sweeps as ONE launch when they qualify (plain in, STORE out, 16-byte kernel, same KS);
 // *done = false: the caller launches them one by one
 template <int KS>
-static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done) {
+static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done, const GatherSrc *g = nullptr, int gjob = -1) {
+  if (g && KS < 16) { *done = false; return hipSuccess; }
   for (int j = 0; j < n; j++) if (jobs[j].raw || jobs[j].in_mode == IN_MUL) { *done = false; return hipSuccess; }
   bool sum3 = jobs[0].in_mode == IN_SUM3;                  // all jobs or none (stokes.hip: the three sweeps of grad div v)
   for (int j = 1; j < n; j++) if ((jobs[j].in_mode == IN_SUM3) != sum3) { *done = false; return hipSuccess; }
@@ -1098,7 +1193,32 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
       for (int j = 1; j < n; j++) if (rem[j] > rem[best]) best = j;
       u[best]++; rem[best] = 0; used++;
     }
-    if (used == units) for (int j = 0; j < n; j++) if (8u * u[j] < gs[j]) gs[j] = 8u * u[j];
+    if (used == units) {
+      for (int j = 0; j < n; j++) if (8u * u[j] < gs[j]) gs[j] = 8u * u[j];
+      // Shares in whole XCD rounds can leave one job a tile behind (three jobs of 256 / 254 / 254 tiles on 256 CUs: 88 / 88 / 80
+      // workgroups, and a tenth of the last job's walkers take 4 tiles while everybody else takes 3).  When shares counted in single
+      // workgroups shorten the longest walk they are used instead; such a job walks its tiles without the XCD grouping (NBLK % 8 != 0).
+      auto walk = [&](unsigned nt, unsigned g_) -> unsigned {      // tiles of the busiest workgroup of a job
+        if (g_ == 0) return nt ? 0xffffffffu : 0u;
+        if (g_ % 8 == 0) { const unsigned per = (nt + 7) / 8, w8 = g_ / 8; return (per + w8 - 1) / w8; }
+        return (nt + g_ - 1) / g_;
+      };
+      unsigned span_al = 0;
+      for (int j = 0; j < n; j++) { const unsigned w_ = walk(jobs[j].ntiles, gs[j]); span_al = w_ > span_al ? w_ : span_al; }
+      unsigned g1[MULTI_MAX], used1 = 0; unsigned long long rem1[MULTI_MAX];
+      for (int j = 0; j < n; j++) {
+        const unsigned long long x = (unsigned long long)ncu * jobs[j].ntiles;
+        g1[j] = (unsigned)(x / total); rem1[j] = x % total;
+        if (g1[j] == 0 && jobs[j].ntiles) { g1[j] = 1; rem1[j] = 0; }
+        used1 += g1[j];
+      }
+      while (used1 < (unsigned)ncu) { int best = 0; for (int j = 1; j < n; j++) if (rem1[j] > rem1[best]) best = j; g1[best]++; rem1[best] = 0; used1++; }
+      if (used1 == (unsigned)ncu) {
+        unsigned span_1 = 0;
+        for (int j = 0; j < n; j++) { const unsigned w_ = walk(jobs[j].ntiles, g1[j]); span_1 = w_ > span_1 ? w_ : span_1; }
+        if (span_1 < span_al) for (int j = 0; j < n; j++) gs[j] = g1[j] < jobs[j].ntiles ? g1[j] : jobs[j].ntiles;
+      }
+    }
   }
   unsigned b = 0;
   for (int j = 0; j < n; j++) { mp.bstart[j] = b; b += gs[j]; mp.job[j] = jobs[j]; }
@@ -1115,7 +1235,10 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
   if constexpr (KS <= 8) {
     if (sum3) hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS, true>), dim3(b), dim3(512), 0, stream, mp);
     else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
-  } else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
+  } else {
+    if (g) hipLaunchKernelGGL((cheb_sweep_multi_gather_kernel<KS>), dim3(b), dim3(512), 0, stream, mp, *g, gjob);
+    else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
+  }
   sweep_note_launch();
   *done = true;
   return hipGetLastError();
@@ -1132,6 +1255,21 @@ hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *j
     case 8: return launch_multi_t<8>(n, jobs, stream, done);
     case 16: return launch_multi_t<16>(n, jobs, stream, done);
     case 32: return launch_multi_t<32>(n, jobs, stream, done);
+    default: return hipSuccess;
+  }
+}
+
+// ... job `gjob` reading its lines from the arrays of g (all jobs lines of more than 64 points, the same KS)
+hipError_t sweep_vec_launch_multi_gather(int n, const DiffMat *const *m, SweepParams *jobs, int gjob, const GatherSrc &g, hipStream_t stream, bool *done) {
+  *done = false;
+  if (n < 2 || n > MULTI_MAX || gjob < 0 || gjob >= n) return hipSuccess;
+  for (int j = 0; j < n; j++) {
+    if (m[j]->KS != m[0]->KS || jobs[j].out_mode != OUT_STORE) return hipSuccess;
+    if (j == gjob ? !gather_ok(*m[j], jobs[j], g) : !sweep_vec_eligible(*m[j], jobs[j])) return hipSuccess;
+  }
+  switch (m[0]->KS) {
+    case 16: return launch_multi_t<16>(n, jobs, stream, done, &g, gjob);
+    case 32: return launch_multi_t<32>(n, jobs, stream, done, &g, gjob);
     default: return hipSuccess;
   }
 }
