@@ -302,6 +302,8 @@ static int exchange(chebhip_dist *D, int nrhs, const double *send, long sq, cons
   return chebhip::comm_exchange(D->comm, D->segs.data(), (int)D->segs.size(), st);
 }
 
+constexpr long FUSE3_MAX = 12000000L;      // values per rank and batch up to which the three directions of a direct-transport matvec are ONE launch
+
 static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, double *V, hipStream_t st) {
   const int d = D->d, r = D->rank, nrhs = W->nrhs;
   const long m0 = D->m0[r], M1 = D->M[1], R = D->R;
@@ -375,7 +377,10 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
       }
       gsrc.s0[D->G] = (int)D->s0[D->G];
     }
-    if (!rc && gfits && small && pk != 3) {
+    // (the one-launch form pays up to about 12 M values per rank and batch -- 8 B/point more in the final sum for two launches less;
+    // measured at G = 2 and at four vectors per exchange over 8 ranks, profiles/r06_dist/fused_threshold.txt)
+    const bool fuse3 = d >= 3 && D->local > 0 && D->local * nrhs < FUSE3_MAX && !chebhip::opt(chebhip::OPT_SEPARATE_LAUNCHES);
+    if (!rc && gfits && fuse3 && pk != 3) {
       rc = chebhip::lap1d_multi_gather_try(d - 1, W->slab_plan.data() + 1, U, W->A.data(), W->pencil_plan, gsrc, W->TT, -1.0, st, &fused);
       if (fused) { exact = true; gathered = true; }
     }
