@@ -256,7 +256,7 @@ int lap1d_multi_gather_try(int n, cheb_plan *const *plans, const double *x, doub
   sp[n] = SweepParams{};
   sp[n].ncols = gp->ncols; sp[n].inner = gp->inner; sp[n].in_mode = IN_PLAIN; sp[n].alpha = alpha; sp[n].out = gout; sp[n].out_mode = OUT_STORE;
   m[n] = &gp->lap;
-  HIPCHK(sweep_launch_multi_gather_try(n + 1, m, sp, n, g, st, done));
+  HIPCHK(sweep_launch_multi_gather_try(n + 1, m, sp, 1u << n, g, st, done));
   return 0;
 }
 }  // namespace chebhip

@@ -61,6 +61,25 @@ __global__ __launch_bounds__(256) void k_xunpack(Split sp, long m0, long M1, lon
     for (long t = threadIdx.x; t < len; t += blockDim.x) { const double v = alpha * src[t]; out[e0 + t] = acc ? acc[e0 + t] + v : v; }
   }
 }
+// Direct transports (comm.h): out = (acc ? acc : 0) + alpha * T with T read IN PLACE from the peers' pencil results: the run of the
+// (c1[s+1] - c1[s]) R doubles of row s0r + i0 of field f of peer s (field stride src.fs[s], row pitch src.pitch[s]).
+struct XPull { const double *p[64]; long fs[64]; long pitch[64]; };
+template <bool V2>
+__global__ __launch_bounds__(256) void k_xpull_unpack(Split sp, XPull src, long s0r, long M1, long R, long Ns, const double *acc, double alpha, double *out) {
+  const int s = (int)(blockIdx.x % (unsigned)sp.G); const long i0 = blockIdx.x / (unsigned)sp.G, f = blockIdx.y;
+  const long w = sp.c1[s + 1] - sp.c1[s], len = w * R, e0 = f * Ns + (i0 * M1 + sp.c1[s]) * R;
+  const double *from = src.p[s] + f * src.fs[s] + (s0r + i0) * src.pitch[s];
+  if (V2) {
+    for (long t = threadIdx.x; t < (len >> 1); t += blockDim.x) {
+      const double2 b = ((const double2 *)from)[t];
+      double2 v = make_double2(alpha * b.x, alpha * b.y);
+      if (acc) { const double2 a = ((const double2 *)(acc + e0))[t]; v.x = a.x + v.x; v.y = a.y + v.y; }
+      ((double2 *)(out + e0))[t] = v;
+    }
+  } else {
+    for (long t = threadIdx.x; t < len; t += blockDim.x) { const double v = alpha * from[t]; out[e0 + t] = acc ? acc[e0 + t] + v : v; }
+  }
+}
 void split_sizes(long n, int parts, std::vector<long> &sz) { sz.resize(parts); for (int i = 0; i < parts; i++) sz[i] = n / parts + (i < n % parts ? 1 : 0); }
 
 // The slab <-> pencil machinery for fields on the full local grid (P0, P1, R): slabs of planes of dimension 0, pencils
@@ -75,6 +94,7 @@ struct SlabX {
   double *sendbuf = nullptr, *recvbuf = nullptr, *pen_in = nullptr, *pen_out = nullptr;
   Split split;
   std::vector<XSeg> segs;
+  bool used_direct = false;                    // the peers' kernels have read this rank's arrays in place (collective destroy)
 
   ~SlabX() { double *all[] = {sendbuf, recvbuf, pen_in, pen_out}; for (double *p : all) if (p) (void)hipFree(p); }
 
@@ -90,11 +110,61 @@ struct SlabX {
     for (int s = 0; s < G; s++) { s0[s + 1] = s0[s] + m0[s]; s1[s + 1] = s1[s] + m1[s]; }
     Ns = m0[rank] * P1 * R; ncol = m1[rank] * R; Np = P0 * ncol;
     split.G = G; for (int s = 0; s <= G; s++) split.c1[s] = s1[s];
-    const size_t sb = (size_t)nf * (size_t)(Ns > 0 ? Ns : 1) * sizeof(double), pb = (size_t)nf * (size_t)(Np > 0 ? Np : 1) * sizeof(double);
+    // (one row of slack behind the pencils: with the NULL transport a rank reads its own pencil result with the peers' column counts)
+    long wmax = 0; for (int s = 0; s < G; s++) wmax = m1[s] > wmax ? m1[s] : wmax;
+    const size_t sb = (size_t)nf * (size_t)(Ns > 0 ? Ns : 1) * sizeof(double), pb = ((size_t)nf * (size_t)(Np > 0 ? Np : 1) + (size_t)(wmax + 1) * R) * sizeof(double);
     XHIPCHK(hipMalloc((void **)&sendbuf, sb)); XHIPCHK(hipMalloc((void **)&recvbuf, sb));
     XHIPCHK(hipMalloc((void **)&pen_in, pb)); XHIPCHK(hipMalloc((void **)&pen_out, pb));
     return 0;
   }
+
+  // Direct transports: can the dimension-0 sweeps read the ranks' slab fields in place?  Decided from what EVERY rank knows (the
+  // geometry of all ranks), so that all ranks take the same route: 16-byte rows and column blocks of at least 16 doubles on every rank.
+  bool direct_geometry() const {
+    if (!comm || !chebhip::comm_direct(comm) || chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE) || G > chebhip::GATHER_MAX) return false;
+    if (((P1 * R) & 1) || P1 * R >= 0x7fffffffL) return false;
+    for (int s = 0; s < G; s++) if (m0[s] < 1 || m1[s] * R < 16 || ((m1[s] * R) & 1) || ((s1[s] * R) & 1) || ((m0[s] * P1 * R) & 1) || m0[s] * P1 * R >= 0x7fffffffL) return false;
+    return (Np & 1) == 0;
+  }
+  // forward half: rendezvous on `in` (nf slab fields), the GatherSrc of this rank's pencil over the peers' fields
+  int direct_open(const double *in, hipStream_t st, chebhip::GatherSrc *g) {
+    used_direct = true;
+    const bool null = chebhip::comm_is_null(comm);
+    chebhip::PeerView pv;
+    const double *post[1] = {in};
+    int rc = chebhip::comm_rendezvous(comm, post, 1, 0, 3, st, &pv);          // the peers' fields are complete; they have finished reading my previous pencil result
+    if (rc) return rc;
+    *g = chebhip::GatherSrc{};
+    g->G = G; g->rowlen = (unsigned)(P1 * R); g->col0 = (unsigned)(s1[rank] * R);
+    for (int s = 0; s < G; s++) {
+      if (!pv.ptr[s][0] || ((size_t)pv.ptr[s][0] & 15)) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: rank %d posted an unaligned field array", s);
+      g->p[s] = pv.ptr[s][0]; g->s0[s] = (int)s0[s]; g->lq[s] = (unsigned)(null ? Ns : m0[s] * P1 * R); g->pmax[s] = (int)(null ? m0[rank] : m0[s]);
+    }
+    g->s0[G] = (int)s0[G];
+    return 0;
+  }
+  // backward half: my reads of the peers' fields end here; rendezvous on pen_out; out = (acc ? acc : 0) + alpha * (the peers' pencil results)
+  int direct_close(int nf, const double *acc, double alpha, double *out, hipStream_t st) {
+    const bool null = chebhip::comm_is_null(comm);
+    int rc = chebhip::comm_mark(comm, 2, st); if (rc) return rc;
+    chebhip::PeerView pv;
+    const double *post[1] = {pen_out};
+    rc = chebhip::comm_rendezvous(comm, post, 1, 1, 2, st, &pv);              // the peers' pencil results are complete; they have finished reading my fields
+    if (rc) return rc;
+    if (Ns > 0) {
+      XPull xp;
+      for (int s = 0; s < G; s++) { const long m1s = null ? m1[rank] : m1[s]; xp.p[s] = pv.ptr[s][0]; xp.pitch[s] = m1s * R; xp.fs[s] = P0 * m1s * R; }
+      const dim3 grid((unsigned)(m0[rank] * G), (unsigned)nf);
+      bool v2 = vec2(out, acc, nullptr);
+      for (int s = 0; s < G && v2; s++) v2 = ((size_t)xp.p[s] & 15) == 0 && (xp.pitch[s] & 1) == 0 && (xp.fs[s] & 1) == 0;
+      if (v2) hipLaunchKernelGGL((k_xpull_unpack<true>), grid, dim3(256), 0, st, split, xp, s0[rank], P1, R, Ns, acc, alpha, out);
+      else hipLaunchKernelGGL((k_xpull_unpack<false>), grid, dim3(256), 0, st, split, xp, s0[rank], P1, R, Ns, acc, alpha, out);
+      XHIPCHK(hipGetLastError());
+    }
+    return chebhip::comm_mark(comm, 3, st);                                   // my reads of the peers' pencil results end here
+  }
+  // before the arrays go: every rank has drained its device (collective among the rank threads; an aborted group returns at once)
+  void direct_quiesce() { if (used_direct && comm) { (void)hipDeviceSynchronize(); (void)chebhip::comm_group_barrier(comm); used_direct = false; } }
 
   // The same machinery for fields in the INTERIOR layout (M0, M1, R') = dims - 2 of the global vectors, partitioned like the
   // operator's slabs: rank r holds the interior planes that fall into its planes [full_s0[r], full_s0[r+1]) of the full grid
@@ -185,7 +255,7 @@ struct SlabX {
 }  // namespace
 
 // ---- Stokes ------------------------------------------------------------------------------------------------------
-struct chebhip_dist_stokes { SlabX x; stokes_op *op = nullptr; SlabX *xi = nullptr; chebhip_fdpc *pc = nullptr; };
+struct chebhip_dist_stokes { SlabX x; stokes_op *op = nullptr; SlabX *xi = nullptr; chebhip_fdpc *pc = nullptr; bool direct = false; };
 
 // dimension 0 of the slab-mode preconditioner (chebhip_fdpc_dim0_fn): interior fields slab -> pencil, line transform, back
 static int pc_dim0(SlabX *xi, chebhip_fdpc *pc, int backward, int nf, const double *in, double *out, void *stream) {
@@ -204,6 +274,18 @@ static int dstokes_pc_dim0(void *ctx, int backward, int nf, const double *in, do
 static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const double *acc, double alpha, double *out, void *stream) {
   chebhip_dist_stokes *D = (chebhip_dist_stokes *)ctx;
   hipStream_t st = (hipStream_t)stream;
+  // Direct transports (LOCAL thread ranks, NULL): the pencil sweep(s) read the peers' slab fields in place and the unpack reads the
+  // peers' pencil results in place -- no pack, no messages; two rendezvous per round trip (csrc/dist.hip has the protocol).
+  if (D->direct) {
+    chebhip::GatherSrc g;
+    bool done = false;
+    int rc = D->x.direct_open(in, st, &g);
+    if (!rc) rc = chebhip::stokes_pencil_gather_try(D->op, kind, nf, D->x.ncol, g, D->x.pen_out, st, &done);
+    if (!rc && !done) rc = chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: the gather launch refused a geometry the route had accepted");
+    if (!rc) rc = D->x.direct_close(nf, acc, alpha, out, st);
+    if (rc) chebhip::comm_abort(D->x.comm);
+    return rc;
+  }
   // a failure between the two exchanges must not leave the peers of a thread-rank group waiting for this rank
   int rc = D->x.to_pencil(nf, in, st); if (rc) { chebhip::comm_abort(D->x.comm); return rc; }
   if (kind == 0) rc = stokes_op_pencil_sweep(D->op, nf, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);     // DV[0] / DP[0]
@@ -218,6 +300,7 @@ static int dstokes_dim0(void *ctx, int kind, int nf, const double *in, const dou
 
 extern "C" int chebhip_dist_stokes_destroy(chebhip_dist_stokes *D) {
   if (!D) return 0;
+  D->x.direct_quiesce();
   if (D->pc) chebhip_fdpc_destroy(D->pc);
   delete D->xi;
   if (D->op) stokes_op_destroy(D->op);
@@ -233,6 +316,8 @@ extern "C" int chebhip_dist_stokes_create(int d, const int *dims, chebhip_comm *
   if (!rc) rc = stokes_op_create_slab(d, dims, (int)D->x.s0[D->x.rank], (int)D->x.s0[D->x.rank + 1], dstokes_dim0, D, &D->op);
   if (!rc && D->x.G > 1) rc = stokes_op_set_inner_reduce(D->op, chebhip_comm_reduce, comm);
   if (rc) { chebhip_dist_stokes_destroy(D); return rc; }
+  // (every rank decides alike: the geometry of all ranks, the options, and matrices that depend on the global extent only)
+  D->direct = D->x.direct_geometry() && chebhip::stokes_pencil_gather_supported(D->op);
   *out = D;
   return 0;
 }

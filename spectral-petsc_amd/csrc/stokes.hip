@@ -1937,6 +1937,39 @@ extern "C" int stokes_op_pencil_sweep_pressure(stokes_op *op, int nvel, long nco
   int rc = stokes_op_pencil_sweep(op, nvel, ncol, in, out, stream); if (rc) return rc;
   return stokes_op_pencil_pressure(op, ncol, in + (size_t)nvel * Np, out + (size_t)nvel * Np, stream);
 }
+// The same three entry points with the pencil's planes read IN PLACE from the ranks' slab fields (sweep.h GatherSrc; slabx.hip, direct
+// transports): kind 0 = stokes_op_pencil_sweep on nf fields, 1 = stokes_op_pencil_pressure (its one field), 2 = stokes_op_pencil_sweep_pressure
+// (nf - 1 velocity fields and the pressure field, two jobs of one launch).  Needs the extrapolation folded into the pressure matrix (pext:
+// the default) -- the pass form rewrites the pencil, which does not exist here.  out: the pencil result (nf, P0, ncol), dense.
+namespace chebhip {
+bool stokes_pencil_gather_supported(const stokes_op *op) {
+  if (!op || !op->pext || opt(OPT_GENERAL_KERNELS) || opt(OPT_SEPARATE_LAUNCHES)) return false;
+  auto a = op->mats.find(op->gP0); auto b = op->matsP.find(op->gP0);
+  return a != op->mats.end() && b != op->matsP.end() && a->second.KS >= 16 && b->second.KS == a->second.KS;
+}
+int stokes_pencil_gather_try(stokes_op *op, int kind, int nf, long ncol, const GatherSrc &g, double *out, hipStream_t st, bool *done) {
+  *done = false;
+  if (!op || !out || nf < 1 || ncol <= 0 || !op->pext || kind < 0 || kind > 2 || (kind == 1 && nf != 1) || (kind == 2 && nf < 2)) return 0;
+  const size_t Np = (size_t)op->gP0 * (size_t)ncol;
+  if (kind != 2) {
+    SweepParams sp = {};
+    sp.ncols = (unsigned)(nf * ncol); sp.inner = (unsigned)ncol;
+    sp.in_mode = IN_PLAIN; sp.out = out; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+    SHIPCHK(sweep_launch_gather(kind == 1 ? op->matsP[op->gP0] : op->mats[op->gP0], sp, g, st, done));
+    return 0;
+  }
+  const int nvel = nf - 1;
+  const DiffMat *m[2] = {&op->mats[op->gP0], &op->matsP[op->gP0]};
+  SweepParams sp[2] = {};
+  sp[0].ncols = (unsigned)(nvel * ncol); sp[0].inner = (unsigned)ncol;
+  sp[0].in_mode = IN_PLAIN; sp[0].out = out; sp[0].out_mode = OUT_STORE; sp[0].alpha = 1.0;
+  sp[1].ncols = (unsigned)ncol; sp[1].inner = (unsigned)ncol; sp[1].gfield0 = (unsigned)nvel;
+  sp[1].in_mode = IN_PLAIN; sp[1].out = out + (size_t)nvel * Np; sp[1].out_mode = OUT_STORE; sp[1].alpha = 1.0;
+  SHIPCHK(sweep_launch_multi_gather_try(2, m, sp, 3u, g, st, done));
+  return 0;
+}
+}  // namespace chebhip
+
 extern "C" int stokes_op_pencil_pressure(stokes_op *op, long ncol, double *p_pencil, double *gp0_pencil, void *stream) {
   ARGCHK(op && p_pencil && gp0_pencil);
   if (ncol <= 0) return ncol == 0 ? 0 : chebhip_fail(CHEBHIP_ERR_ARG, "bad pencil geometry");

@@ -78,6 +78,7 @@ struct SweepParams {
   // The Stokes stress tensor is stored as its 6 distinct components this way (stokes.hip).
   unsigned in_fblocks, in_fskip;
   unsigned in_fblocks_inv;                   // set by the launcher: ceil(2^32 / in_fblocks)
+  unsigned gfield0;                          // gather launches (GatherSrc): the job's outer blocks are the vectors / fields gfield0, gfield0 + 1, .. of the arrays
 };
 
 // Host description of the even/odd split differentiation matrices for P points.
@@ -165,9 +166,9 @@ struct GatherSrc { const double *p[GATHER_MAX]; int s0[GATHER_MAX + 1]; unsigned
 hipError_t sweep_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done);
 hipError_t sweep_vec_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done);
 hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *jobs, hipStream_t stream, bool *done);
-hipError_t sweep_vec_launch_multi_gather(int n, const DiffMat *const *m, SweepParams *jobs, int gjob, const GatherSrc &g, hipStream_t stream, bool *done);
-// n sweeps as ONE launch, job gjob reading its lines through g; *done = false: they cannot share a launch, nothing is launched
-hipError_t sweep_launch_multi_gather_try(int n, const DiffMat *const *m, const SweepParams *p, int gjob, const GatherSrc &g, hipStream_t stream, bool *done);
+hipError_t sweep_vec_launch_multi_gather(int n, const DiffMat *const *m, SweepParams *jobs, unsigned gmask, const GatherSrc &g, hipStream_t stream, bool *done);
+// n sweeps as ONE launch, the jobs of gmask (bit j = job j) reading their lines through g; *done = false: they cannot share a launch, nothing is launched
+hipError_t sweep_launch_multi_gather_try(int n, const DiffMat *const *m, const SweepParams *p, unsigned gmask, const GatherSrc &g, hipStream_t stream, bool *done);
 // n independent sweeps (plain in, STORE out): one launch when they qualify (sweep_vec.hip), else n launches
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream);
 // ... only if they can share ONE launch (*done = true); otherwise nothing is launched (*done = false)
@@ -176,7 +177,12 @@ hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepPar
 long sweep_launch_count();
 }  // namespace chebhip
 struct cheb_plan;
+struct stokes_op;
 namespace chebhip {
+// stokes.hip: the dimension-0 sweeps of a slab-mode Stokes callback (stokes_op_pencil_sweep / _pressure / _sweep_pressure) with the
+// pencil's planes read from the arrays of g (the ranks' slab fields) instead of a materialised pencil; *done = false: not eligible
+int stokes_pencil_gather_try(stokes_op *op, int kind, int nf, long ncol, const GatherSrc &g, double *out, hipStream_t st, bool *done);
+bool stokes_pencil_gather_supported(const stokes_op *op);     // the matrices of dimension 0 are the long-line kernel's and carry the extrapolation
 // chebhip.hip: the interior second derivative along n directions of one tensor as ONE launch (see there)
 int lap1d_multi_try(int n, cheb_plan *const *plans, const double *x, double *const *outs, double alpha, hipStream_t st, bool *done);
 int lap1d_gather_try(cheb_plan *p, const GatherSrc &g, double alpha, double *y, hipStream_t st, bool *done);

@@ -536,12 +536,12 @@ hipError_t sweep_launch_multi_try(int n, const DiffMat *const *m, const SweepPar
   return sweep_vec_launch_multi(n, m, jobs, stream, done);
 }
 
-hipError_t sweep_launch_multi_gather_try(int n, const DiffMat *const *m, const SweepParams *p, int gjob, const GatherSrc &g, hipStream_t stream, bool *done) {
+hipError_t sweep_launch_multi_gather_try(int n, const DiffMat *const *m, const SweepParams *p, unsigned gmask, const GatherSrc &g, hipStream_t stream, bool *done) {
   *done = false;
   if (n < 2 || n > 9 || opt(OPT_SEPARATE_LAUNCHES) || opt(OPT_GENERAL_KERNELS)) return hipSuccess;
   SweepParams jobs[9];
   for (int j = 0; j < n; j++) { jobs[j] = p[j]; sweep_fill(*m[j], jobs[j]); if (m[j]->KS == 0) return hipSuccess; }
-  return sweep_vec_launch_multi_gather(n, m, jobs, gjob, g, stream, done);
+  return sweep_vec_launch_multi_gather(n, m, jobs, gmask, g, stream, done);
 }
 
 hipError_t sweep_launch_multi(int n, const DiffMat *const *m, const SweepParams *p, hipStream_t stream) {

@@ -577,13 +577,14 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
       // a tile past the workgroup's last re-reads tile 0 (never used); lanes past the last column of the block re-read its last pair
       // (they feed columns that are never stored) -- every address stays inside the arrays
       const u32 tle = valid ? tl : 0u;
+      const u32 gf0 = p.gfield0;
       const u32 o = tle / tpo, q0 = (tle - o * tpo) * NT;
       u32 qq = q0 + 2u * (u32)ld_a; if (qq > qmax - 2u) qq = qmax - 2u;
 #pragma unroll
       for (int s = 0; s < CH; s++) {
         const int sg = chunk * CH + s;
-        rj[s] = *(gd2p)(gb_j[sg] + ((unsigned long long)o * glq_j[sg] + qq) * 8ull);
-        rm[s] = *(gd2p)(gb_m[sg] + ((unsigned long long)o * glq_m[sg] + qq) * 8ull);
+        rj[s] = *(gd2p)(gb_j[sg] + ((unsigned long long)(o + gf0) * glq_j[sg] + qq) * 8ull);
+        rm[s] = *(gd2p)(gb_m[sg] + ((unsigned long long)(o + gf0) * glq_m[sg] + qq) * 8ull);
       }
       return;
     }
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(512, (KS <= 8 ? 4 : 2)) void cheb_sweep_multi_kerne
 // ... with ONE of the jobs reading its lines from the arrays of a GatherSrc (lines of more than 64 points): the three directions of a
 // slab rank's matvec -- the local ones and the pencil direction over the peers' slabs -- as one launch (dist.hip)
 template <int KS>
-__global__ __launch_bounds__(512) void cheb_sweep_multi_gather_kernel(const MultiParams mp, const GatherSrc g, const int gjob) {
+__global__ __launch_bounds__(512) void cheb_sweep_multi_gather_kernel(const MultiParams mp, const GatherSrc g, const unsigned gmask) {
   static_assert(KS >= 16, "the gather loader is part of the long-line kernel");
   constexpr int LDS = vec_lds_doubles<KS, true>() > vec_lds_doubles<KS, false>() ? vec_lds_doubles<KS, true>() : vec_lds_doubles<KS, false>();
   __shared__ double smem[LDS];
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_gather_kernel(const Mult
   while (j + 1 < mp.njobs && blockIdx.x >= mp.bstart[j + 1]) j++;
   const SweepParams &p = mp.job[j];
   const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
-  if (j == gjob) vec4_body<KS, false, 0, 0, 0, true>(p, smem, bid, nblk, &g);
+  if ((gmask >> j) & 1u) vec4_body<KS, false, 0, 0, 0, true>(p, smem, bid, nblk, &g);
   else if (p.inner < 16) vec4_body<KS, true, 0>(p, smem, bid, nblk);
   else vec4_body<KS, false, 0>(p, smem, bid, nblk);
 }
@@ -1149,7 +1150,7 @@ hipError_t sweep_vec_launch_gather(const DiffMat &m, SweepParams p, const Gather
 // n <= MULTI_MAX independent sweeps as ONE launch when they qualify (plain in, STORE out, 16-byte kernel, same KS);
 // *done = false: the caller launches them one by one
 template <int KS>
-static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done, const GatherSrc *g = nullptr, int gjob = -1) {
+static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, bool *done, const GatherSrc *g = nullptr, unsigned gmask = 0) {
   if (g && KS < 16) { *done = false; return hipSuccess; }
   for (int j = 0; j < n; j++) if (jobs[j].raw || jobs[j].in_mode == IN_MUL) { *done = false; return hipSuccess; }
   bool sum3 = jobs[0].in_mode == IN_SUM3;                  // all jobs or none (stokes.hip: the three sweeps of grad div v)
@@ -1236,7 +1237,7 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
     if (sum3) hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS, true>), dim3(b), dim3(512), 0, stream, mp);
     else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
   } else {
-    if (g) hipLaunchKernelGGL((cheb_sweep_multi_gather_kernel<KS>), dim3(b), dim3(512), 0, stream, mp, *g, gjob);
+    if (g) hipLaunchKernelGGL((cheb_sweep_multi_gather_kernel<KS>), dim3(b), dim3(512), 0, stream, mp, *g, gmask);
     else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
   }
   sweep_note_launch();
@@ -1259,17 +1260,17 @@ hipError_t sweep_vec_launch_multi(int n, const DiffMat *const *m, SweepParams *j
   }
 }
 
-// ... job `gjob` reading its lines from the arrays of g (all jobs lines of more than 64 points, the same KS)
-hipError_t sweep_vec_launch_multi_gather(int n, const DiffMat *const *m, SweepParams *jobs, int gjob, const GatherSrc &g, hipStream_t stream, bool *done) {
+// ... the jobs of gmask reading their lines from the arrays of g (all jobs lines of more than 64 points, the same KS)
+hipError_t sweep_vec_launch_multi_gather(int n, const DiffMat *const *m, SweepParams *jobs, unsigned gmask, const GatherSrc &g, hipStream_t stream, bool *done) {
   *done = false;
-  if (n < 2 || n > MULTI_MAX || gjob < 0 || gjob >= n) return hipSuccess;
+  if (n < 2 || n > MULTI_MAX || gmask == 0 || (gmask >> n) != 0) return hipSuccess;
   for (int j = 0; j < n; j++) {
     if (m[j]->KS != m[0]->KS || jobs[j].out_mode != OUT_STORE) return hipSuccess;
-    if (j == gjob ? !gather_ok(*m[j], jobs[j], g) : !sweep_vec_eligible(*m[j], jobs[j])) return hipSuccess;
+    if (((gmask >> j) & 1u) ? !gather_ok(*m[j], jobs[j], g) : !sweep_vec_eligible(*m[j], jobs[j])) return hipSuccess;
   }
   switch (m[0]->KS) {
-    case 16: return launch_multi_t<16>(n, jobs, stream, done, &g, gjob);
-    case 32: return launch_multi_t<32>(n, jobs, stream, done, &g, gjob);
+    case 16: return launch_multi_t<16>(n, jobs, stream, done, &g, gmask);
+    case 32: return launch_multi_t<32>(n, jobs, stream, done, &g, gmask);
     default: return hipSuccess;
   }
 }

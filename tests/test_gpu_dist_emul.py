@@ -269,6 +269,27 @@ def test_stokes_thread_ranks_small(G, dims):
     assert relerr(yf, ref_f) < 1e-10 and relerr(ym, ref_m) < 1e-10
 
 
+@pytest.mark.parametrize("G", [3, 4])
+def test_stokes_thread_ranks_read_the_peers_fields_in_place(G):
+    """Round 6: on a direct transport the dimension-0 sweeps of the slab-mode Stokes callbacks read the peers' slab fields in place (gather
+    loader, lines of more than 64 points) and the unpack reads the peers' pencil results in place.  70 x 68 x 66 over 3 (uneven: 24 / 23 / 23
+    planes, 23 / 23 / 22 columns) and 4 ranks, power law: against the oracle, and against the pack / segment-exchange / unpack route
+    (`dist_packed_exchange` = 1, read when the driver is created) to rounding."""
+    sp = ge.load()
+    dims = (70, 68, 66)
+    x, dv, force, w = stokes_inputs(dims)
+    yf, ym = stokes_ranks(dims, G, x, dv, force, w, POWER)
+    sp.set_option("dist_packed_exchange", 1)
+    try:
+        yf_p, ym_p = stokes_ranks(dims, G, x, dv, force, w, POWER)
+    finally:
+        sp.set_option("dist_packed_exchange", 0)
+    assert relerr(yf, yf_p) < 1e-13 and relerr(ym, ym_p) < 1e-13
+    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=orc.FAST, nthreads=8)
+    ref_m = orc.stokes_mult(dims, w, eta, deta, strain, mode=orc.FAST, nthreads=8)
+    assert relerr(yf, ref_f) < 1e-10 and relerr(ym, ref_m) < 1e-10
+
+
 def test_stokes_128_power_law_over_8_ranks():
     """BASELINE config 5: -dim 128,128,128 -rheology 1 on 8 slabs of 16 planes: StokesFunction and the Newton-linearised
     StokesMatMult against the serial handle (and through it, tests/test_gpu_stokes.py, the oracle)."""
