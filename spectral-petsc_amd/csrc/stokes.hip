@@ -945,6 +945,10 @@ struct stokes_op {
   // slab mode (multi-GPU): the handle owns the planes [lo, lo + dims[0]) of a grid whose dimension 0 has
   // gP0 points; everything along dimension 0 (sweeps, x-line pressure extrapolation) goes through `dim0`
   bool slab = false;
+  // slab mode on a direct transport (slabx.hip): independent local sweeps parked here by a callback ride in the launch of the dimension-0
+  // sweep it calls next (stokes_pencil_gather_try), so that the d directions of a gradient / divergence are ONE launch; what the driver
+  // did not take is launched by st_flush_pending
+  int npend = 0; const DiffMat *pend_m[8] = {}; SweepParams pend_sp[8] = {};
   int gP0 = 0, lo = 0;
   stokes_dim0_fn dim0 = nullptr;
   void *dim0_ctx = nullptr;
@@ -1277,8 +1281,14 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
 
 // d independent plain sweeps y[k] = alpha * D_k x[k] (DV: vec, d stacked fields; DP: scalar) as ONE launch where the
 // kernels allow it (sweep_launch_multi), else one launch each.  Serial handles only.
+static int st_flush_pending(stokes_op *op, hipStream_t st) {
+  if (op->npend <= 0) return 0;
+  const int n = op->npend; op->npend = 0;
+  SHIPCHK(sweep_launch_multi(n, op->pend_m, op->pend_sp, st));
+  return 0;
+}
 static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x, double *const *y, double alpha, hipStream_t st, bool spaced = false,
-                        bool pext = false, int k1 = -1) {   // pext: the matrices with the end-point extrapolation of the pressure folded in; directions k0 .. k1 - 1
+                        bool pext = false, int k1 = -1, bool park = false) {   // pext: the matrices with the end-point extrapolation of the pressure folded in; directions k0 .. k1 - 1; park: see stokes_op::npend
   const DiffMat *m[3]; SweepParams sp[3];
   int n = 0;
   if (k1 < 0) k1 = op->d;
@@ -1292,6 +1302,7 @@ static int sweeps_multi(stokes_op *op, bool vec, int k0, const double *const *x,
     sp[n].in0 = x[k]; sp[n].in_mode = IN_PLAIN; sp[n].out = y[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = alpha;
     m[n] = pext ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
   }
+  if (park && op->npend + n <= 8) { for (int j = 0; j < n; j++) { op->pend_m[op->npend] = m[j]; op->pend_sp[op->npend++] = sp[j]; } return 0; }
   SHIPCHK(sweep_launch_multi(n, m, sp, st));
   return 0;
 }
@@ -1304,9 +1315,12 @@ static int st_div_stress(stokes_op *op, hipStream_t st, bool from_T = false) {
     // dimension 0 through the driver (pencils), the local directions as ONE launch into arrays of their own; the final scatter
     // adds the terms in the order j = 0, 1, 2 as on one GPU (the same bits).  (Round 3 ran an accumulating chain of d launches here:
     // at 8 ranks every launch of a 128^3 problem is a 64^3-sized, latency-bound one.)
-    int rc = sweep_plain(op, true, 0, op->V[0], op->yL, OUT_STORE, nullptr, -1.0, st); if (rc) return rc;
+    // (the local jobs are parked first: on a direct transport the driver's dimension-0 launch takes them along)
     const double *x[3] = {op->V[0], op->V[1], op->V[2]};
-    return sweeps_multi(op, true, 1, x, y, -1.0, st);
+    int rc = sweeps_multi(op, true, 1, x, y, -1.0, st, false, false, -1, true); if (rc) return rc;
+    rc = sweep_plain(op, true, 0, op->V[0], op->yL, OUT_STORE, nullptr, -1.0, st);
+    const int rc2 = st_flush_pending(op, st);
+    return rc ? rc : rc2;
   }
   if (from_T) {         // the fields (j,0), (j,1), (j,2) of direction j are slots j, 2j+1, 3j+2 of T: base j N, one field every (j+1) N
     const double *x[3] = {op->T, op->T + op->N, op->T + 2 * op->N};
@@ -1320,8 +1334,10 @@ static int st_div_stress(stokes_op *op, hipStream_t st, bool from_T = false) {
 static int st_gradient(stokes_op *op, double *const *out, hipStream_t st) {
   const double *x[3] = {op->xL, op->xL, op->xL};
   if (op->slab) {                                           // dimension 0 on pencils (the driver), the local directions in one launch
-    int rc = sweep_plain(op, true, 0, op->xL, out[0], OUT_STORE, nullptr, 1.0, st); if (rc) return rc;
-    return sweeps_multi(op, true, 1, x, out, 1.0, st);
+    int rc = sweeps_multi(op, true, 1, x, out, 1.0, st, false, false, -1, true); if (rc) return rc;
+    rc = sweep_plain(op, true, 0, op->xL, out[0], OUT_STORE, nullptr, 1.0, st);
+    const int rc2 = st_flush_pending(op, st);
+    return rc ? rc : rc2;
   }
   return sweeps_multi(op, true, 0, x, out, 1.0, st);
 }
@@ -1354,19 +1370,21 @@ static int st_gradient_and_pressure_gradient_slab(stokes_op *op, double *const *
   const int d = op->d; const long N = op->N;
   if (!op->pext) st_pressure_extrapolate(op, op->pL, st);      // z and y lines (the x lines: on the pencils, stokes_op_pencil_pressure)
   op->gp[0] = out[0] + (size_t)d * N;                          // the (d+1)-th field of the array that receives the gradient
-  int rc = op->dim0(op->dim0_ctx, 2, d + 1, op->xL, nullptr, 1.0, out[0], st); if (rc) return rc;
-  const DiffMat *m[4]; SweepParams sp[4];
-  int n = 0;
+  // the local gradient and pressure-gradient sweeps: parked, so that on a direct transport the driver's dimension-0 launch takes them
+  // along (all 2d sweeps of the callback's first half are then ONE launch); otherwise launched right after it
+  op->npend = 0;
   for (int pass = 0; pass < 2; pass++)
-    for (int k = 1; k < d; k++, n++) {
+    for (int k = 1; k < d; k++) {
       const bool vec = pass == 0;
-      sp[n] = SweepParams{};
-      sp[n].ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; sp[n].inner = op->innerP[k];
-      sp[n].in0 = vec ? op->xL : op->pL; sp[n].in_mode = IN_PLAIN; sp[n].out = vec ? out[k] : op->gp[k]; sp[n].out_mode = OUT_STORE; sp[n].alpha = 1.0;
-      m[n] = (!vec && op->pext) ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
+      SweepParams &q = op->pend_sp[op->npend];
+      q = SweepParams{};
+      q.ncols = vec ? op->ncolsV[k] : op->ncolsP[k]; q.inner = op->innerP[k];
+      q.in0 = vec ? op->xL : op->pL; q.in_mode = IN_PLAIN; q.out = vec ? out[k] : op->gp[k]; q.out_mode = OUT_STORE; q.alpha = 1.0;
+      op->pend_m[op->npend++] = (!vec && op->pext) ? &op->matsP[op->dims[k]] : &op->mats[op->dims[k]];
     }
-  SHIPCHK(sweep_launch_multi(n, m, sp, st));
-  return 0;
+  const int rc = op->dim0(op->dim0_ctx, 2, d + 1, op->xL, nullptr, 1.0, out[0], st);
+  const int rc2 = st_flush_pending(op, st);
+  return rc ? rc : rc2;
 }
 
 // Uniform viscosity, eta' = 0 (linear rheology, stokes.C:470-474; the state after create): the viscous block of the Jacobian,
@@ -1951,21 +1969,35 @@ int stokes_pencil_gather_try(stokes_op *op, int kind, int nf, long ncol, const G
   *done = false;
   if (!op || !out || nf < 1 || ncol <= 0 || !op->pext || kind < 0 || kind > 2 || (kind == 1 && nf != 1) || (kind == 2 && nf < 2)) return 0;
   const size_t Np = (size_t)op->gP0 * (size_t)ncol;
+  const DiffMat *m[9]; SweepParams sp[9];
+  int ng = 0;
   if (kind != 2) {
-    SweepParams sp = {};
-    sp.ncols = (unsigned)(nf * ncol); sp.inner = (unsigned)ncol;
-    sp.in_mode = IN_PLAIN; sp.out = out; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
-    SHIPCHK(sweep_launch_gather(kind == 1 ? op->matsP[op->gP0] : op->mats[op->gP0], sp, g, st, done));
-    return 0;
+    sp[0] = SweepParams{};
+    sp[0].ncols = (unsigned)(nf * ncol); sp[0].inner = (unsigned)ncol;
+    sp[0].in_mode = IN_PLAIN; sp[0].out = out; sp[0].out_mode = OUT_STORE; sp[0].alpha = 1.0;
+    m[0] = kind == 1 ? &op->matsP[op->gP0] : &op->mats[op->gP0];
+    ng = 1;
+  } else {
+    const int nvel = nf - 1;
+    m[0] = &op->mats[op->gP0]; m[1] = &op->matsP[op->gP0];
+    sp[0] = SweepParams{}; sp[1] = SweepParams{};
+    sp[0].ncols = (unsigned)(nvel * ncol); sp[0].inner = (unsigned)ncol;
+    sp[0].in_mode = IN_PLAIN; sp[0].out = out; sp[0].out_mode = OUT_STORE; sp[0].alpha = 1.0;
+    sp[1].ncols = (unsigned)ncol; sp[1].inner = (unsigned)ncol; sp[1].gfield0 = (unsigned)nvel;
+    sp[1].in_mode = IN_PLAIN; sp[1].out = out + (size_t)nvel * Np; sp[1].out_mode = OUT_STORE; sp[1].alpha = 1.0;
+    ng = 2;
   }
-  const int nvel = nf - 1;
-  const DiffMat *m[2] = {&op->mats[op->gP0], &op->matsP[op->gP0]};
-  SweepParams sp[2] = {};
-  sp[0].ncols = (unsigned)(nvel * ncol); sp[0].inner = (unsigned)ncol;
-  sp[0].in_mode = IN_PLAIN; sp[0].out = out; sp[0].out_mode = OUT_STORE; sp[0].alpha = 1.0;
-  sp[1].ncols = (unsigned)ncol; sp[1].inner = (unsigned)ncol; sp[1].gfield0 = (unsigned)nvel;
-  sp[1].in_mode = IN_PLAIN; sp[1].out = out + (size_t)nvel * Np; sp[1].out_mode = OUT_STORE; sp[1].alpha = 1.0;
-  SHIPCHK(sweep_launch_multi_gather_try(2, m, sp, 3u, g, st, done));
+  const unsigned gmask = (1u << ng) - 1u;
+  // the callback's parked local sweeps (stokes_op::npend) ride in the same launch when the jobs can share one
+  if (op->npend > 0 && ng + op->npend <= 9) {
+    int n = ng;
+    for (int j = 0; j < op->npend; j++, n++) { m[n] = op->pend_m[j]; sp[n] = op->pend_sp[j]; }
+    bool all = false;
+    SHIPCHK(sweep_launch_multi_gather_try(n, m, sp, gmask, g, st, &all));
+    if (all) { op->npend = 0; *done = true; return 0; }
+  }
+  if (ng == 1) { SHIPCHK(sweep_launch_gather(*m[0], sp[0], g, st, done)); }
+  else { SHIPCHK(sweep_launch_multi_gather_try(2, m, sp, gmask, g, st, done)); }
   return 0;
 }
 }  // namespace chebhip
