@@ -27,9 +27,20 @@ def serial_newton_converges(dims):
     op = sp.EllipticOp(dims); op.set_dirichlet(dv)
     b = torch.from_numpy(u2.copy()).cuda(); x = torch.zeros_like(b)
     G = int(np.prod([v - 2 for v in dims]))
-    its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-11, ksp_rtol=1e-12, ksp_restart=min(256, G), ksp_max_it=20000, snes_max_it=100)
+    # Round 6: on such a grid the serial outcome itself flips with the rounding of the Krylov solves ((11, 5): stalls with the three-launch
+    # Gram-Schmidt step, converges with the one-reduction step, and the 2- and 4-rank runs stall: tools/r06_case_11_5.py) -- the draw is kept
+    # only if the serial Newton converges with BOTH steps
+    ok = True
+    for exact in (0, 1):
+        sp.set_option("krylov_exact_norm", exact)
+        try:
+            x.zero_()
+            its, kits, fn = solve.newton_krylov(sp, op, b, x, 4.0, 2.0, snes_rtol=1e-11, ksp_rtol=1e-12, ksp_restart=min(256, G), ksp_max_it=20000, snes_max_it=100)
+        finally:
+            sp.set_option("krylov_exact_norm", 0)
+        ok = ok and fn <= 1e-9 * float(np.linalg.norm(u2))
     op.destroy()
-    return fn <= 1e-9 * float(np.linalg.norm(u2))
+    return ok
 
 
 def main():
