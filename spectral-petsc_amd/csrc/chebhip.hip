@@ -746,6 +746,24 @@ extern "C" int ell_op_pencil_sweep(ell_op *op, long ncol, const double *in, doub
   return 0;
 }
 
+// The same with the pencil's planes read in place from the ranks' slab fields (sweep.h GatherSrc; slabx.hip, direct transports)
+namespace chebhip {
+bool ell_pencil_gather_supported(const ell_op *op) {
+  if (!op || opt(OPT_GENERAL_KERNELS) || opt(OPT_SEPARATE_LAUNCHES)) return false;
+  auto a = op->mats.find(op->gP0);
+  return a != op->mats.end() && a->second.KS >= 16;
+}
+int ell_pencil_gather_try(ell_op *op, long ncol, const GatherSrc &g, double *out, hipStream_t st, bool *done) {
+  *done = false;
+  if (!op || !out || ncol <= 0) return 0;
+  SweepParams sp = {};
+  sp.ncols = (unsigned)ncol; sp.inner = (unsigned)ncol;
+  sp.in_mode = IN_PLAIN; sp.out = out; sp.out_mode = OUT_STORE; sp.alpha = 1.0;
+  HIPCHK(sweep_launch_gather(op->mats[op->gP0], sp, g, st, done));
+  return 0;
+}
+}  // namespace chebhip
+
 extern "C" int ell_op_destroy(ell_op *op) {
   if (!op) return 0;
   for (auto &kv : op->mats) diffmat_destroy(&kv.second);

@@ -347,7 +347,7 @@ extern "C" int chebhip_dist_stokes_ranges(const chebhip_dist_stokes *D, long *ra
 }
 
 // ---- general-coefficient elliptic operator -----------------------------------------------------------------------
-struct chebhip_dist_ell { SlabX x; ell_op *op = nullptr; SlabX *xi = nullptr; chebhip_fdpc *pc = nullptr; };
+struct chebhip_dist_ell { SlabX x; ell_op *op = nullptr; SlabX *xi = nullptr; chebhip_fdpc *pc = nullptr; bool direct = false; };
 static int dell_pc_dim0(void *ctx, int backward, int nf, const double *in, double *out, void *stream) {
   chebhip_dist_ell *D = (chebhip_dist_ell *)ctx;
   return pc_dim0(D->xi, D->pc, backward, nf, in, out, stream);
@@ -357,6 +357,16 @@ static int dell_dim0(void *ctx, int kind, int nf, const double *in, const double
   chebhip_dist_ell *D = (chebhip_dist_ell *)ctx;
   (void)kind;
   hipStream_t st = (hipStream_t)stream;
+  if (D->direct && nf == 1) {                  // direct transports: the pencil sweep reads the ranks' slab field in place (see dstokes_dim0)
+    chebhip::GatherSrc g;
+    bool done = false;
+    int rc = D->x.direct_open(in, st, &g);
+    if (!rc) rc = chebhip::ell_pencil_gather_try(D->op, D->x.ncol, g, D->x.pen_out, st, &done);
+    if (!rc && !done) rc = chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: the gather launch refused a geometry the route had accepted");
+    if (!rc) rc = D->x.direct_close(nf, acc, alpha, out, st);
+    if (rc) chebhip::comm_abort(D->x.comm);
+    return rc;
+  }
   int rc = D->x.to_pencil(nf, in, st);
   if (!rc) rc = ell_op_pencil_sweep(D->op, D->x.ncol, D->x.pen_in, D->x.pen_out, stream);                   // D_0 on the pencil
   if (!rc) rc = D->x.to_slab(nf, acc, alpha, out, st);
@@ -366,6 +376,7 @@ static int dell_dim0(void *ctx, int kind, int nf, const double *in, const double
 
 extern "C" int chebhip_dist_ell_destroy(chebhip_dist_ell *D) {
   if (!D) return 0;
+  D->x.direct_quiesce();
   if (D->pc) chebhip_fdpc_destroy(D->pc);
   delete D->xi;
   if (D->op) ell_op_destroy(D->op);
@@ -380,6 +391,7 @@ extern "C" int chebhip_dist_ell_create(int d, const int *dims, chebhip_comm *com
   int rc = D->x.setup(d, dims, comm, 1);
   if (!rc) rc = ell_op_create_slab(d, dims, (int)D->x.s0[D->x.rank], (int)D->x.s0[D->x.rank + 1], dell_dim0, D, &D->op);
   if (rc) { chebhip_dist_ell_destroy(D); return rc; }
+  D->direct = D->x.direct_geometry() && chebhip::ell_pencil_gather_supported(D->op);
   *out = D;
   return 0;
 }

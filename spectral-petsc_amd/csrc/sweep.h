@@ -178,7 +178,11 @@ long sweep_launch_count();
 }  // namespace chebhip
 struct cheb_plan;
 struct stokes_op;
+struct ell_op;
 namespace chebhip {
+// chebhip.hip: ell_op_pencil_sweep with the pencil's planes read in place from the ranks' slab field (slabx.hip)
+bool ell_pencil_gather_supported(const ell_op *op);
+int ell_pencil_gather_try(ell_op *op, long ncol, const GatherSrc &g, double *out, hipStream_t st, bool *done);
 // stokes.hip: the dimension-0 sweeps of a slab-mode Stokes callback (stokes_op_pencil_sweep / _pressure / _sweep_pressure) with the
 // pencil's planes read from the arrays of g (the ranks' slab fields) instead of a materialised pencil; *done = false: not eligible
 int stokes_pencil_gather_try(stokes_op *op, int kind, int nf, long ncol, const GatherSrc &g, double *out, hipStream_t st, bool *done);
