@@ -271,10 +271,16 @@ int chebhip_rccl_reduce(void *nccl_comm, double *vals_dev, int count, void *stre
 /*   _create_rccl      one process per GPU; each exchange is one grouped       */
 /*                     ncclSend/ncclRecv launch over xGMI (rccl.h:700,722,923) */
 /*   _create_local     ranks are host threads of ONE process, one stream (and, */
-/*                     on a multi-GPU node, one device) each; exchanges are    */
-/*                     event-ordered device copies between the ranks' buffers  */
-/*                     (peer access).  Every rank must make the same sequence  */
-/*                     of collective calls from its own thread.                */
+/*                     on a multi-GPU node, one device) each, peer access      */
+/*                     between the devices.  A DIRECT transport: the slab      */
+/*                     drivers read the peers' arrays in place (no pack, no    */
+/*                     messages; two thread rendezvous per round trip), other  */
+/*                     exchanges are event-ordered device copies.  Every rank  */
+/*                     must make the same sequence of collective calls from    */
+/*                     its own thread -- INCLUDING the destroy of a driver     */
+/*                     that has run on it (chebhip_dist_destroy,               */
+/*                     chebhip_dist_stokes_destroy, chebhip_dist_ell_destroy:  */
+/*                     nothing is freed while a peer may still read it).       */
 /*   _create_callback  any other transport (the gloo staging of the tests)     */
 /* ------------------------------------------------------------------------- */
 typedef struct chebhip_comm chebhip_comm;
@@ -290,7 +296,8 @@ int chebhip_local_group_destroy(chebhip_local_group *g);   /* after every rank t
 int chebhip_local_group_abort(chebhip_local_group *g);   /* a failing rank releases the ranks waiting for it: their calls return an error */
 int chebhip_comm_create_local(chebhip_local_group *g, int rank, chebhip_comm **out);          /* call with the rank's device current */
 int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn, chebhip_reduce_fn rfn, void *ctx, chebhip_comm **out);
-/* No wire: own blocks only.  For timing the compute side of one rank of an N-rank partition on one GPU; results are meaningless. */
+/* No wire: every "peer" is the rank itself (the kernels of the direct route with every byte read locally).  For timing the compute
+ * side of one rank of an N-rank partition on one GPU; results are meaningless for N > 1. */
 int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out);
 int chebhip_comm_destroy(chebhip_comm *c);
 int chebhip_comm_size(const chebhip_comm *c);
