@@ -1257,7 +1257,11 @@ static void st_out_full(stokes_op *op, const double *force, double *out, hipStre
                         const double *y2 = nullptr, const double *G = nullptr, const double *p3 = nullptr, bool no_gp = false) {      // p3: three stacked terms of the pressure rows instead of p2
   const int d = op->d;                                      // no_gp: grad p is inside the y terms (the folded pressure route: pair kernel only)
   if (p3) {                                                 // (the caller has checked st_out_pairs)
-    hipLaunchKernelGGL((k_st_out4p<2>), dim3(ugrid(op->N >> 1, 2)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
+    // one pair per thread here too (round 6; rounds 4-5: two): at 64^3 the launch is 256 workgroups either way
+#ifndef ST_OUT_P3_UN
+#define ST_OUT_P3_UN 1
+#endif
+    hipLaunchKernelGGL((k_st_out4p<ST_OUT_P3_UN>), dim3(ugrid(op->N >> 1, ST_OUT_P3_UN)), dim3(256), 0, st, op->N, (const int *)op->ixL, y0, y1, y2,
                        (const double *)op->gp[0], (const double *)op->gp[1], (const double *)op->gp[2], p3, force, out, G, p3 + op->N, p3 + 2 * op->N, st_grid(op));
     return;
   }
