@@ -298,19 +298,25 @@ def extras(sp, torch):
 
     def t_us(fn, reps):
         # untimed calls first: at least ~20 ms of this very load (the clocks of a GPU that has idled through the CPU baseline take that
-        # long to settle: the first timed loop of a callback otherwise reads 3 % high), then the timed loop
+        # long to settle: the first timed loop of a callback otherwise reads 3 % high), then the `reps` timed calls as THREE loops, of
+        # which the median is reported (one record run of round 6 read FormFunction at 1 068 us where every other run reads 504-535:
+        # a single disturbed loop must not stand for the callback)
         t0 = time.perf_counter(); n = 0
         while n < max(reps // 4, 5) or (time.perf_counter() - t0 < 0.02 and n < 2000):
             fn(); n += 1
             if n % 16 == 0:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / reps
+        per = max(reps // 3, 3)
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / per)
+        return sorted(ts)[1]
     out = {}
     rnd = lambda n: torch.randn(n, dtype=torch.float64, device="cuda")
     # (the Stokes handles first: their ~30 work arrays then come from a fresh allocator state -- handles made after gigabytes have been
