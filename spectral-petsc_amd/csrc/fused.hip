@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void cheb_fused_kernel(const SweepParams p) {
   constexpr int HP = 4 * KS;
   constexpr int NSUB = (KS >= 16) ? 2 : 1;
   constexpr int NT = 16 * NG * NSUB;
-  constexpr int LDJ = HP + 2;
+  constexpr int LDJ = HP + 1;   // odd pitch: conflict-free operand reads (sweep_vec.hip V_LDJ_PAD; this kernel's LDS accesses are all 8-byte)
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
   constexpr int ITEMS = HP * NT / 512;
   constexpr int CH = ITEMS / NSUB;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_kernel(const SweepParams p) {
   constexpr int HP = 4 * KS;                       // padded half length
   constexpr int NSUB = (KS >= 16) ? 2 : 1;         // 16-line sub-tiles per wave per tile
   constexpr int NT = 16 * NG * NSUB;               // lines per tile: 32, 64, 64, 128
-  constexpr int LDJ = HP + 2;                      // JFAST row pitch: == 2 (mod 32) -> conflict-free b64 reads
+  constexpr int LDJ = HP + 1;                      // JFAST row pitch: ODD -> conflict-free operand reads (round 6: tools/lds_probe.hip; == 2 mod 32 was a 2-way conflict)
   constexpr int LDS_ELEMS = JFAST ? NT * LDJ : HP * NT;
   constexpr int ITEMS = HP * NT / 512;             // (j-pair, line) slots per thread per tile
   constexpr int CH = ITEMS / NSUB;                 // slots per chunk (one chunk rides under one sub-tile)

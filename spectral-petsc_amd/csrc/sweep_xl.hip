@@ -28,6 +28,7 @@ typedef unsigned u32;
 
 constexpr int XL_MB = 8;           // waves per workgroup as launched (the kernel takes 4..8); each owns one or two m-tiles (of 16 rows)
 constexpr int XL_KC = 128;         // points of the half per image chunk (32 k-steps)
+constexpr int XL_LDJ_PAD = 1;   // pitch of a JFAST image line beyond XL_KC doubles (odd; the kernel's LDS accesses are all 8-byte)
 
 // NT2: 16-line tiles per workgroup (1 or 2); MT2: m-tiles per wave (1 or 2: wave w owns m-tiles w and w + 8 of the
 // workgroup's 16 -- every fragment still feeds NT2 MFMAs, every image operand now MT2 of them, and a tile is read by half
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_xl_kernel   // (4 waves per
 (const SweepParams p) {
   extern __shared__ double smem[];
   constexpr int NL = 16 * NT2;                   // lines per tile
-  constexpr int LDJ = XL_KC + 2;                 // JFAST image pitch: = 2 (mod 32) doubles -> conflict-free ds_read_b64
+  constexpr int LDJ = XL_KC + XL_LDJ_PAD;        // JFAST image pitch: ODD -> conflict-free operand reads (round 6: tools/lds_probe.hip)
   constexpr int IMG = JFAST ? NL * LDJ : XL_KC * NL;
   constexpr int HIT = 4;                         // image elements a thread has in flight
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -174,7 +175,7 @@ bool sweep_xl_eligible(const DiffMat &m, const SweepParams &p) {
 
 template <bool JFAST, int NT2, int MT2, int PF>
 static hipError_t xl_launch_t(const SweepParams &p, dim3 grid, unsigned waves, hipStream_t stream) {
-  const size_t lds = (size_t)2 * (JFAST ? 16 * NT2 * (XL_KC + 2) : XL_KC * 16 * NT2) * sizeof(double);
+  const size_t lds = (size_t)2 * (JFAST ? 16 * NT2 * (XL_KC + XL_LDJ_PAD) : XL_KC * 16 * NT2) * sizeof(double);
   if (lds > 64 * 1024) {                         // (more than 64 KiB of dynamic LDS needs the attribute, once per device)
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
