@@ -668,7 +668,9 @@ def local_threads_main(args):
     if not par["rel_l2_vs_oracle"] <= par["tolerance"]:
         raise SystemExit("parity failure: %d-rank %d^3 matvec differs from the oracle by %.3e" % (G, par["P"], par["rel_l2_vs_oracle"]))
     wall = max(walls)
-    launches = 4 if box["local_size"] < 6000000 else 5
+    # direct route (csrc/dist.hip): up to 12 M values per rank the three directions are ONE launch (two local jobs + the pencil job reading the
+    # peers' slabs in place), then the final sum reading the peers' pencil results: two kernels; above: two local launches + the pencil launch + the sum
+    launches = 2 if box["local_size"] < 12000000 else 4
     out = {
         "metric": "spectral matvecs/s and GB/s vs HBM roofline, 3D P^3 grid",
         "value": args.steps / wall, "unit": "matvecs/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "spinup": args.spinup,
@@ -681,7 +683,12 @@ def local_threads_main(args):
         "device_ms_per_step": max(devms) / args.steps,
         "parity": par,
     }
-    out["roofline"]["kernel"] = "slab route, whole step of one GPU: k_pull_pack (reads the peers' slabs in place), cheb_sweep_multi_kernel (local directions), cheb_sweep_vec4_kernel (pencil), k_pull_combine (reads the peers' pencil results in place); 2 rendezvous, no messages"
+    out["roofline"]["kernel"] = ("slab route (direct transport), whole step of one GPU: " +
+                                 ("cheb_sweep_multi_gather_kernel (ONE launch: the local directions + the pencil direction reading the peers' slabs in place)" if launches == 2 else
+                                  "the local directions, cheb_sweep_vec4_gather_kernel (the pencil direction reading the peers' slabs in place)") +
+                                 ", k_pull_combine (the final sum reading the peers' pencil results in place); 2 rendezvous, no messages")
+    out["roofline"]["exchanges_per_step"] = 0
+    out["roofline"]["rendezvous_per_step"] = 2
     print(json.dumps(out), flush=True)
     return 0
 
