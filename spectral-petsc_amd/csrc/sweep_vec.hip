@@ -552,18 +552,32 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   unsigned long long gb_j[GATH ? ITEMS : 1], gb_m[GATH ? ITEMS : 1];
   u32 glq_j[GATH ? ITEMS : 1], glq_m[GATH ? ITEMS : 1];
   if constexpr (GATH) {
-    auto locate = [&](int i, unsigned long long &b, u32 &lq) {
-      int s_ = 0;
-      while (s_ + 1 < gs->G && i >= gs->s0[s_ + 1]) s_++;
-      int pl = i - gs->s0[s_]; if (pl > gs->pmax[s_] - 1) pl = gs->pmax[s_] - 1; if (pl < 0) pl = 0;
-      b = (unsigned long long)gs->p[s_] + ((unsigned long long)pl * gs->rowlen + gs->col0) * 8ull;
-      lq = gs->lq[s_];
-    };
+    // A table BY ROW in LDS (the second operand image, first written a whole tile later): thread i < P finds the owner of row i once,
+    // without a search loop and without per-lane loads of the kernel argument -- the plane ranges are compared as scalars (uniform
+    // indices: s_load) and the owner's entries selected on the way (ranges ascend: the last hit wins) -- then every thread looks its
+    // eight rows up.  History (tools/stamp_probe_rank.py, profiles/r06_dist/rank_stamps.txt; the local jobs of the same launch reach
+    // their first tile after 8.7 k cycles): a while loop over the ranges per row 15.0 k, eight compare chains with per-lane loads of
+    // the owner's entries 12.1 k, with an LDS copy of the kernel argument's table 10.6 k.
+    unsigned long long *gRB = (unsigned long long *)(smem + 2 * LDS_ELEMS);
+    u32 *gRL = (u32 *)(gRB + 2 * HP);
+    if (tid <= nn) {
+      const int gG = gs->G;
+      unsigned long long pb = (unsigned long long)gs->p[0]; u32 lq = gs->lq[0]; int s0v = gs->s0[0], pmv = gs->pmax[0];
+#pragma unroll
+      for (int k = 1; k < GATHER_MAX; k++) {
+        const bool c = (k < gG) && (tid >= gs->s0[k]);
+        pb = c ? (unsigned long long)gs->p[k] : pb; lq = c ? gs->lq[k] : lq; s0v = c ? gs->s0[k] : s0v; pmv = c ? gs->pmax[k] : pmv;
+      }
+      int pl = tid - s0v; if (pl > pmv - 1) pl = pmv - 1; if (pl < 0) pl = 0;
+      gRB[tid] = pb + ((unsigned long long)pl * gs->rowlen + gs->col0) * 8ull;
+      gRL[tid] = lq;
+    }
+    __syncthreads();
 #pragma unroll
     for (int sg = 0; sg < ITEMS; sg++) {
       int row = ld_b + sg * QSTEP; if (row > nn) row = nn;       // (rows past the half meet zero columns of the matrix; they stay inside the line)
-      locate(row, gb_j[sg], glq_j[sg]);
-      locate(nn - row, gb_m[sg], glq_m[sg]);
+      gb_j[sg] = gRB[row]; glq_j[sg] = gRL[row];
+      gb_m[sg] = gRB[nn - row]; glq_m[sg] = gRL[nn - row];
     }
   }
   d2 rjA[CH], rmA[CH], rjB[CH], rmB[CH];
