@@ -282,9 +282,23 @@ int chebhip_rccl_reduce(void *nccl_comm, double *vals_dev, int count, void *stre
 /*                     chebhip_dist_stokes_destroy, chebhip_dist_ell_destroy:  */
 /*                     nothing is freed while a peer may still read it).       */
 /*   _create_callback  any other transport (the gloo staging of the tests)     */
+/*   _create_ipc       ranks are PROCESSES of one node (a launcher's one       */
+/*                     process per GPU): the direct route of _create_local     */
+/*                     across address spaces -- pointers travel as             */
+/*                     (hipIpcMemHandle_t, offset) through a shared-memory     */
+/*                     segment, "my arrays are complete" as sequence numbers   */
+/*                     in it (hipStreamWriteValue64, one polling launch),      */
+/*                     layered over a message transport (_create_rccl, a       */
+/*                     callback) that carries the segment exchanges and the    */
+/*                     reductions.  The same collective rules as _create_local */
+/*                     (destroys included).  Vectors handed to a driver on it  */
+/*                     must come from hipMalloc (not from a virtual-memory     */
+/*                     allocator) and stay allocated between calls, or         */
+/*                     chebhip_ipc_group_forget is called after freeing them.  */
 /* ------------------------------------------------------------------------- */
 typedef struct chebhip_comm chebhip_comm;
 typedef struct chebhip_local_group chebhip_local_group;
+typedef struct chebhip_ipc_group chebhip_ipc_group;
 /* One exchange: segment i sends send_counts[i] doubles at send_dev[i] to peers[i] and receives recv_counts[i] doubles
  * from it into recv_dev[i]; the k-th segment a rank addresses to peer s meets the k-th segment s addresses to that
  * rank.  The rank's own segments are not passed (device copies inside the library).  Ordered on `stream`. */
@@ -299,6 +313,15 @@ int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn,
 /* No wire: every "peer" is the rank itself (the kernels of the direct route with every byte read locally).  For timing the compute
  * side of one rank of an N-rank partition on one GPU; results are meaningless for N > 1. */
 int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out);
+/* Process ranks.  _open is collective: `name` is a POSIX shared-memory name ("/chebhip-<unique per group>") that rank 0 creates
+ * and unlinks again once every rank holds the mapping; call it with the rank's device current.  `inner` (not owned, may be NULL
+ * for one rank): a communicator of the same ranks on a message transport.  _close after the communicators and drivers made on
+ * the group are gone; _abort releases ranks waiting in a rendezvous (their calls fail). */
+int chebhip_ipc_group_open(const char *name, int nranks, int rank, chebhip_ipc_group **out);
+int chebhip_ipc_group_close(chebhip_ipc_group *g);
+int chebhip_ipc_group_abort(chebhip_ipc_group *g);
+int chebhip_ipc_group_forget(chebhip_ipc_group *g);
+int chebhip_comm_create_ipc(chebhip_ipc_group *g, chebhip_comm *inner, chebhip_comm **out);
 int chebhip_comm_destroy(chebhip_comm *c);
 int chebhip_comm_size(const chebhip_comm *c);
 int chebhip_comm_rank(const chebhip_comm *c);

@@ -10,15 +10,30 @@
 //             device copies: every rank PULLS its segments out of its peers' send buffers.  On one device this is the
 //             full-size rehearsal of an N-rank run (tests/test_gpu_dist_emul.py).
 //   CALLBACK  anything else (the gloo staging of the tests).
+//   IPC       ranks are PROCESSES of one node (the launcher's one process per GPU): the LOCAL transport's rendezvous across address
+//             spaces.  Pointers travel as (hipIpcMemHandle_t of the allocation, offset) through a POSIX shared-memory segment, the
+//             "my arrays are complete here" events are sequence numbers in that segment written by hipStreamWriteValue64 and awaited
+//             by ONE polling launch per rendezvous (interprocess hipEvents fail after 32 records on this runtime: tools/ipc_probe.hip),
+//             the barrier is a counter in it.  A DIRECT transport layered over a message transport (RCCL, a callback) that carries the
+//             segment exchanges and the reductions.
 #include "comm.h"
 #include "sweep.h"
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
@@ -74,7 +89,7 @@ int rccl_fail(const char *what, int rc) {
   return chebhip_fail(CHEBHIP_ERR_DEVICE, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
 }
 
-enum { KIND_RCCL = 1, KIND_LOCAL = 2, KIND_CALLBACK = 3, KIND_NULL = 4 };
+enum { KIND_RCCL = 1, KIND_LOCAL = 2, KIND_CALLBACK = 3, KIND_NULL = 4, KIND_IPC = 5 };
 constexpr int MAXR = 64;
 
 // sum of the G posted vectors, taken in rank order on every rank: all ranks get the same bits
@@ -114,12 +129,193 @@ struct chebhip_local_group {
   void abort() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
 };
 
+
+// ---- ranks as processes of one node ------------------------------------------------------------------------------
+namespace {
+struct IpcPtr { hipIpcMemHandle_t h; unsigned long long off; int valid; int pad_; };
+struct IpcSlot {
+  int bound, pid; char bus[32];                                          // bus: PCI id of the rank's device ("do the ranks share a device?")
+  unsigned long long seq;                                                // posts (of any event slot) ENQUEUED so far, and ...
+  unsigned long long posted[chebhip::COMM_NEV];                          // ... the number the latest post of each slot got (written by the owning rank only)
+  unsigned long long rdv;                                                // rendezvous this rank has made
+  IpcPtr xptr[2][chebhip::COMM_NPTR];                                    // alternating tables, as in the LOCAL group
+  unsigned long long want[2];                                            // ... with the number the peers wait for: the later of `slot`'s and `wait_slot`'s post
+  alignas(64) unsigned long long flag;                                   // posts EXECUTED by the rank's stream (device-written, in stream order)
+};
+struct IpcShared {
+  std::atomic<unsigned> magic; int G;
+  std::atomic<int> aborted;
+  alignas(64) std::atomic<unsigned> bar_count;
+  alignas(64) std::atomic<unsigned> bar_gen;
+  IpcSlot slot[MAXR];
+};
+constexpr unsigned IPC_MAGIC = 0x43484950u;
+
+// One launch instead of 2 (G - 1) hipStreamWaitValue64 calls of 2.5 us each (at G = 8 the host would spend 70 us per matvec
+// enqueueing waits): lane r polls the sequence number of rank r until it reaches what that rank announced.  Every lane leaves
+// after `limit` ticks of the 100-MHz clock at the latest and then marks the group aborted (the ranks' next barrier fails) -- no
+// wave waits forever for a peer that died.
+struct IpcWait { const unsigned long long *flag[MAXR]; unsigned long long want[MAXR]; };
+__global__ __launch_bounds__(64) void k_ipc_wait(IpcWait a, int G, int me, unsigned long long limit, int *aborted) {
+  const int r = threadIdx.x;
+  if (r >= G || r == me || a.want[r] == 0) return;
+  const unsigned long long want = a.want[r], t0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(a.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > limit) { __hip_atomic_store(aborted, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+static_assert(std::atomic<unsigned>::is_always_lock_free, "the barrier of the IPC group lives in memory shared between processes");
+}  // namespace
+
+struct chebhip_ipc_group {
+  IpcShared *S = nullptr; char *dS = nullptr;                             // the segment, and its device view (hipHostRegister)
+  size_t bytes = 0; int G = 0, rank = -1; bool registered = false;
+  double timeout_s = 120.0;
+  hipEvent_t fence = nullptr;                                             // recorded in front of every post: a system-scope release of what the stream wrote
+  bool pending = false; hipStream_t pending_st = nullptr;                 // a mark whose number has not been written yet (ipc_post)
+  std::map<std::string, void *> opened;                                   // peers' allocations mapped here, by handle bytes
+  struct Mine { size_t size; hipIpcMemHandle_t h; };
+  std::map<void *, Mine> mine;                                            // my allocations whose handle has been taken, by base
+
+  unsigned long long *dflag(int r) const { return (unsigned long long *)(dS + ((char *)&S->slot[r].flag - (char *)S)); }
+  int barrier() {
+    if (S->aborted.load()) return chebhip_fail(CHEBHIP_ERR_DEVICE, "ipc group: aborted by another rank");
+    const unsigned gen = S->bar_gen.load(std::memory_order_acquire);
+    if (S->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (unsigned)G) {
+      S->bar_count.store(0, std::memory_order_relaxed);
+      S->bar_gen.fetch_add(1, std::memory_order_release);
+      return 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0; S->bar_gen.load(std::memory_order_acquire) == gen; spins++) {
+      if (S->aborted.load(std::memory_order_relaxed)) return chebhip_fail(CHEBHIP_ERR_DEVICE, "ipc group: aborted by another rank");
+      if ((spins & 1023) == 1023) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+          S->aborted.store(1);
+          return chebhip_fail(CHEBHIP_ERR_DEVICE, "ipc group: a rank did not arrive within %.0f s", timeout_s);
+        }
+        if (spins > (1ul << 16)) sched_yield();                           // a late peer: stop burning the core it may need
+      }
+    }
+    return 0;
+  }
+  // (handle of the allocation that holds p, offset of p in it).  The handle is taken once per allocation (2.8 us per call) and kept
+  // while hipMemGetAddressRange (0.1 us) reports the same base and size: an allocation that is freed and made again at the same
+  // address with the same size between two calls is NOT noticed -- vectors handed to a driver on this transport must stay allocated
+  // (a caching allocator's blocks do) or be announced with chebhip_ipc_group_forget.
+  int publish(const double *p, IpcPtr *out) {
+    out->valid = 0;
+    if (!p) return 0;
+    void *base = nullptr; size_t size = 0;
+    hipError_t e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p);
+    if (e != hipSuccess || !base) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_ARG, "ipc transport: %p is not inside a device allocation (%s)", (const void *)p, hipGetErrorString(e)); }
+    auto it = mine.find(base);
+    if (it == mine.end() || it->second.size != size) {
+      Mine m; m.size = size;
+      e = hipIpcGetMemHandle(&m.h, base);
+      if (e != hipSuccess) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipIpcGetMemHandle: %s (allocations of a virtual-memory allocator cannot be shared)", hipGetErrorString(e)); }
+      mine[base] = m; it = mine.find(base);
+    }
+    out->h = it->second.h; out->off = (unsigned long long)((const char *)p - (const char *)base); out->valid = 1;
+    return 0;
+  }
+  int translate(const IpcPtr &q, const double **out) {
+    *out = nullptr;
+    if (!q.valid) return 0;
+    const std::string key((const char *)&q.h, sizeof q.h);
+    auto it = opened.find(key);
+    if (it == opened.end()) {
+      void *m = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&m, q.h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess || !m) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipIpcOpenMemHandle: %s", hipGetErrorString(e)); }
+      it = opened.emplace(key, m).first;
+    }
+    *out = (const double *)((const char *)it->second + q.off);
+    return 0;
+  }
+};
+
+// Collective among the G processes.  `name`: a POSIX shared-memory name ("/chebhip-<unique>") that rank 0 creates and unlinks again as
+// soon as everybody holds the mapping (a crash later leaves nothing behind); it must be unique per group -- a stale segment of the
+// same name would be taken for the new one.  Call with the rank's device current.
+extern "C" int chebhip_ipc_group_open(const char *name, int nranks, int rank, chebhip_ipc_group **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!name || name[0] != '/' || nranks < 1 || nranks > MAXR || rank < 0 || rank >= nranks) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
+  chebhip_ipc_group *g = new (std::nothrow) chebhip_ipc_group;
+  if (!g) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  g->G = nranks; g->rank = rank;
+  { const int t = chebhip::opt(chebhip::OPT_LOCAL_TIMEOUT_S); if (t > 0) g->timeout_s = (double)t; }
+  const long page = sysconf(_SC_PAGESIZE);
+  g->bytes = (sizeof(IpcShared) + (size_t)page - 1) / (size_t)page * (size_t)page;
+  auto fail = [&](int code, const char *what, const char *why) { chebhip_ipc_group_close(g); return chebhip_fail(code, "ipc group %s: %s: %s", name, what, why); };
+  int fd = -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g->timeout_s; };
+  if (rank == 0) {
+    (void)shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fail(CHEBHIP_ERR_DEVICE, "shm_open", strerror(errno));
+    if (ftruncate(fd, (off_t)g->bytes) != 0) { close(fd); (void)shm_unlink(name); return fail(CHEBHIP_ERR_DEVICE, "ftruncate", strerror(errno)); }
+  } else {
+    for (;;) {                                                            // until rank 0 has made it and given it its size
+      fd = shm_open(name, O_RDWR, 0600);
+      struct stat sb;
+      if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= g->bytes) break;
+      if (fd >= 0) { close(fd); fd = -1; }
+      if (late()) return fail(CHEBHIP_ERR_DEVICE, "shm_open", "rank 0 did not create the segment in time");
+      usleep(1000);
+    }
+  }
+  void *m = mmap(nullptr, g->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { if (rank == 0) (void)shm_unlink(name); return fail(CHEBHIP_ERR_DEVICE, "mmap", strerror(errno)); }
+  g->S = (IpcShared *)m;
+  if (rank == 0) {                                                        // (a fresh segment is zero-filled)
+    g->S->G = nranks;
+    g->S->magic.store(IPC_MAGIC, std::memory_order_release);
+  } else {
+    while (g->S->magic.load(std::memory_order_acquire) != IPC_MAGIC) { if (late()) return fail(CHEBHIP_ERR_DEVICE, "attach", "rank 0 did not initialise the segment in time"); usleep(200); }
+    if (g->S->G != nranks) return fail(CHEBHIP_ERR_ARG, "attach", "the segment belongs to a group of another size");
+  }
+  hipError_t e = hipHostRegister(m, g->bytes, hipHostRegisterMapped);
+  if (e == hipSuccess) { g->registered = true; e = hipHostGetDevicePointer((void **)&g->dS, m, 0); }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&g->fence, hipEventDisableTiming);
+  int dev = 0;
+  if (e == hipSuccess) e = hipGetDevice(&dev);
+  IpcSlot &me = g->S->slot[rank];
+  if (e == hipSuccess) e = hipDeviceGetPCIBusId(me.bus, (int)sizeof me.bus, dev);
+  if (e != hipSuccess) { (void)hipGetLastError(); g->S->aborted.store(1); if (rank == 0) (void)shm_unlink(name); return fail(CHEBHIP_ERR_DEVICE, "device setup", hipGetErrorString(e)); }
+  me.pid = (int)getpid(); me.bound = 1;
+  int rc = g->barrier();                                                  // everybody holds the mapping and has filled its slot
+  if (rank == 0) (void)shm_unlink(name);
+  if (rc) { chebhip_ipc_group_close(g); return rc; }
+  *out = g;
+  return 0;
+}
+extern "C" int chebhip_ipc_group_close(chebhip_ipc_group *g) {
+  if (!g) return 0;
+  for (auto &kv : g->opened) (void)hipIpcCloseMemHandle(kv.second);
+  if (g->fence) (void)hipEventDestroy(g->fence);
+  if (g->registered) (void)hipHostUnregister((void *)g->S);
+  if (g->S) (void)munmap((void *)g->S, g->bytes);
+  (void)hipGetLastError();
+  delete g;
+  return 0;
+}
+extern "C" int chebhip_ipc_group_abort(chebhip_ipc_group *g) { if (g && g->S) g->S->aborted.store(1); return 0; }
+// forget the handles taken for this rank's allocations (after freeing vectors that were handed to a driver on this transport)
+extern "C" int chebhip_ipc_group_forget(chebhip_ipc_group *g) { if (g) g->mine.clear(); return 0; }
+
 struct chebhip_comm {
   int kind = 0, G = 1, rank = 0;
   void *nccl = nullptr;                         // RCCL communicator (not owned)
   chebhip_exchangev_fn xfn = nullptr; chebhip_reduce_fn rfn = nullptr; void *ctx = nullptr;
   chebhip_local_group *lg = nullptr;
   double *scratch = nullptr;                    // LOCAL: the reduction's private result (MAXR doubles)
+  chebhip_ipc_group *ig = nullptr;              // IPC: the process group (not owned) ...
+  chebhip_comm *inner = nullptr;                // ... and the message transport under it (not owned): segment exchanges, reductions
 };
 
 extern "C" int chebhip_local_group_create(int nranks, chebhip_local_group **out) {
@@ -228,6 +424,21 @@ extern "C" int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out
   return 0;
 }
 
+// The direct route for one process per GPU: rendezvous through `g`, everything else through `inner` (a communicator of the same
+// ranks on a message transport; NULL is allowed for one rank).
+extern "C" int chebhip_comm_create_ipc(chebhip_ipc_group *g, chebhip_comm *inner, chebhip_comm **out) {
+  if (!out) return chebhip_fail(CHEBHIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!g || !g->S) return chebhip_fail(CHEBHIP_ERR_ARG, "bad group");
+  if (inner ? (inner->G != g->G || inner->rank != g->rank || inner->kind == KIND_IPC) : g->G > 1)
+    return chebhip_fail(CHEBHIP_ERR_ARG, "the message transport under an IPC communicator must be a communicator of the same ranks");
+  chebhip_comm *c = new (std::nothrow) chebhip_comm;
+  if (!c) return chebhip_fail(CHEBHIP_ERR_MEMORY, "out of host memory");
+  c->kind = KIND_IPC; c->G = g->G; c->rank = g->rank; c->ig = g; c->inner = inner;
+  *out = c;
+  return 0;
+}
+
 extern "C" int chebhip_comm_destroy(chebhip_comm *c) {
   if (!c) return 0;
   if (c->kind == KIND_LOCAL && c->lg) {
@@ -244,23 +455,59 @@ extern "C" int chebhip_comm_rank(const chebhip_comm *c) { return c ? c->rank : -
 namespace chebhip {
 int comm_size(const chebhip_comm *c) { return c ? c->G : 1; }
 int comm_rank(const chebhip_comm *c) { return c ? c->rank : 0; }
-void comm_abort(chebhip_comm *c) { if (c && c->kind == KIND_LOCAL && c->lg) c->lg->abort(); }
+void comm_abort(chebhip_comm *c) {
+  if (c && c->kind == KIND_LOCAL && c->lg) c->lg->abort();
+  if (c && c->kind == KIND_IPC && c->ig) c->ig->S->aborted.store(1);
+}
 
-bool comm_direct(const chebhip_comm *c) { return c && (c->kind == KIND_LOCAL || c->kind == KIND_NULL); }
+bool comm_direct(const chebhip_comm *c) { return c && (c->kind == KIND_LOCAL || c->kind == KIND_NULL || c->kind == KIND_IPC); }
 bool comm_is_null(const chebhip_comm *c) { return c && c->kind == KIND_NULL; }
 bool comm_overlap_pays(const chebhip_comm *c) {
   if (!c || c->G == 1 || c->kind == KIND_NULL) return false;
+  if (c->kind == KIND_IPC) {
+    const IpcShared *S = c->ig->S;
+    for (int r = 0; r < c->G; r++) if (strncmp(S->slot[r].bus, S->slot[c->rank].bus, sizeof S->slot[r].bus) != 0) return true;
+    return false;                                 // every process drives the same device (the rehearsal on one GPU)
+  }
   if (c->kind != KIND_LOCAL) return true;
   std::lock_guard<std::mutex> lk(c->lg->mu);
   const int dev = c->lg->slot[c->rank].device;
   for (int r = 0; r < c->G; r++) if (c->lg->slot[r].bound && c->lg->slot[r].device != dev) return true;
   return false;                                   // every rank of the group drives the same device: a side stream only adds dependencies
 }
-int comm_group_barrier(chebhip_comm *c) { return (c && c->kind == KIND_LOCAL) ? c->lg->barrier() : 0; }
+int comm_group_barrier(chebhip_comm *c) { return (c && c->kind == KIND_LOCAL) ? c->lg->barrier() : (c && c->kind == KIND_IPC) ? c->ig->barrier() : 0; }
+
+// IPC: "everything this stream has done so far is complete" as a number the peers' streams can wait for.  ONE counter per rank for
+// all event slots: the stream writes the numbers in order, so "the counter has reached the number of slot k's latest post" says that
+// post has executed.  The event in front of the write is recorded for its system-scope release (hipEventRecord without
+// hipEventDisableSystemFence): what the stream's kernels wrote is visible to other devices before the number is.
+// A MARK ("my reads of the peers' arrays end here") only takes its number; the stream write (3.8 us of host time for the pair of
+// calls) is left to the next post on the same stream, which is the next thing a driver does or the first thing of its next call --
+// no peer waits for a mark before this rank has passed the barrier of a later rendezvous, whose post writes a larger number.
+static int ipc_flush(chebhip_ipc_group *g, hipStream_t st, unsigned long long seq) {
+  hipError_t e = hipEventRecord(g->fence, st);
+  if (e == hipSuccess) e = hipStreamWriteValue64(st, g->dflag(g->rank), (uint64_t)seq, 0);
+  if (e != hipSuccess) { g->S->aborted.store(1); return chebhip_fail(CHEBHIP_ERR_DEVICE, "ipc post: %s", hipGetErrorString(e)); }
+  return 0;
+}
+static int ipc_post(chebhip_ipc_group *g, int slot, hipStream_t st, bool mark) {
+  IpcSlot &me = g->S->slot[g->rank];
+  if (g->pending && g->pending_st != st) {
+    // the pending mark belongs to another stream: written there, and waited for, so that the counter never runs backwards (rare path)
+    int rc = ipc_flush(g, g->pending_st, me.seq); if (rc) return rc;
+    if (hipStreamSynchronize(g->pending_st) != hipSuccess) { g->S->aborted.store(1); return chebhip_fail(CHEBHIP_ERR_DEVICE, "ipc post: stream synchronisation failed"); }
+    g->pending = false;
+  }
+  me.posted[slot] = ++me.seq;
+  if (mark) { g->pending = true; g->pending_st = st; return 0; }
+  g->pending = false;
+  return ipc_flush(g, st, me.seq);
+}
 
 int comm_mark(chebhip_comm *c, int slot, hipStream_t st) {
-  if (!c || c->kind != KIND_LOCAL) return 0;
+  if (!c || (c->kind != KIND_LOCAL && c->kind != KIND_IPC)) return 0;
   if (slot < 0 || slot >= COMM_NEV) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_mark: bad slot");
+  if (c->kind == KIND_IPC) return ipc_post(c->ig, slot, st, true);
   hipError_t e = hipEventRecord(c->lg->slot[c->rank].xev[slot], st);
   if (e != hipSuccess) { c->lg->abort(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(e)); }
   return 0;
@@ -270,6 +517,33 @@ int comm_rendezvous(chebhip_comm *c, const double *const *ptrs, int n, int slot,
   if (!c || !out || n < 0 || n > COMM_NPTR || slot < 0 || slot >= COMM_NEV || wait_slot >= COMM_NEV) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_rendezvous: bad argument");
   if (c->kind == KIND_NULL) {                    // one rank stands for all of them: every peer's arrays are this rank's own
     for (int r = 0; r < c->G; r++) for (int k = 0; k < COMM_NPTR; k++) out->ptr[r][k] = k < n ? ptrs[k] : nullptr;
+    return 0;
+  }
+  if (c->kind == KIND_IPC) {
+    chebhip_ipc_group *g = c->ig;
+    IpcShared *S = g->S;
+    IpcSlot &me = S->slot[c->rank];
+    int rc = ipc_post(g, slot, st, false); if (rc) return rc;            // my arrays are complete at this point of my stream
+    const int tb = (int)(me.rdv++ & 1);                                  // (alternating tables: see the LOCAL rendezvous below)
+    for (int k = 0; k < COMM_NPTR && !rc; k++) rc = g->publish(k < n ? ptrs[k] : nullptr, &me.xptr[tb][k]);
+    me.want[tb] = me.posted[slot];                                       // (the post above is this rank's latest: wait_slot's number is smaller)
+    if (rc) { S->aborted.store(1); return rc; }
+    if ((rc = g->barrier())) return rc;                                  // every rank has posted and published
+    IpcWait wa;
+    for (int r = 0; r < MAXR; r++) { wa.flag[r] = nullptr; wa.want[r] = 0; }
+    for (int r = 0; r < c->G; r++) {
+      if (r == c->rank) { for (int k = 0; k < COMM_NPTR; k++) out->ptr[r][k] = k < n ? ptrs[k] : nullptr; continue; }
+      const IpcSlot &ps = S->slot[r];
+      for (int k = 0; k < COMM_NPTR && !rc; k++) rc = g->translate(ps.xptr[tb][k], &out->ptr[r][k]);
+      if (rc) { S->aborted.store(1); return rc; }
+      wa.flag[r] = g->dflag(r); wa.want[r] = ps.want[tb];
+    }
+    if (c->G > 1) {
+      int *dab = (int *)(g->dS + ((char *)&S->aborted - (char *)S));
+      hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, st, wa, c->G, c->rank, (unsigned long long)(g->timeout_s * 1e8), dab);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { S->aborted.store(1); return chebhip_fail(CHEBHIP_ERR_DEVICE, "k_ipc_wait: %s", hipGetErrorString(e)); }
+    }
     return 0;
   }
   if (c->kind != KIND_LOCAL) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_rendezvous: the transport has no directly addressable peers");
@@ -376,6 +650,7 @@ int comm_exchange(chebhip_comm *c, const XSeg *segs, int nseg, hipStream_t st) {
     case KIND_LOCAL: return exchange_local(c, segs, nseg, st);
     case KIND_CALLBACK: return exchange_callback(c, segs, nseg, st);
     case KIND_NULL: return self_copies(c, segs, nseg, st);
+    case KIND_IPC: return comm_exchange(c->inner, segs, nseg, st);      // (inner == NULL: one rank, own blocks only)
   }
   return chebhip_fail(CHEBHIP_ERR_ARG, "exchange: bad communicator");
 }
@@ -387,6 +662,7 @@ extern "C" int chebhip_comm_reduce(void *comm, double *vals_dev, int count, void
   chebhip_comm *c = (chebhip_comm *)comm;
   if (!c || !vals_dev || count < 0) return chebhip_fail(CHEBHIP_ERR_ARG, "bad argument");
   if (count == 0 || c->G == 1 || c->kind == KIND_NULL) return 0;
+  if (c->kind == KIND_IPC) return chebhip_comm_reduce(c->inner, vals_dev, count, stream);
   hipStream_t st = (hipStream_t)stream;
   if (c->kind == KIND_RCCL) {
     int rc = g_rccl.AllReduce(vals_dev, vals_dev, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->nccl, st);

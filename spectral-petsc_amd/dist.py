@@ -171,8 +171,9 @@ class DistPoissonC:
     a transport -- an RCCL communicator made from a unique id that rank 0 broadcasts through the process group
     (backend "nccl"), or, for rehearsals on one GPU under gloo, a callback that stages the exchange through the host."""
 
-    def __init__(self, dims, sp, group=None, comm=None, force_a2a=False, legacy_exchange=False):
-        """comm: a Comm (e.g. one rank of a LocalGroup) instead of the process group's transport; force_a2a: go through
+    def __init__(self, dims, sp, group=None, comm=None, force_a2a=False, legacy_exchange=False, ipc=False):
+        """ipc: the direct route among the processes of one node on top of the group's transport (Comm(ipc=True); `transport`
+        tells whether the node granted it).  comm: a Comm (e.g. one rank of a LocalGroup) instead of the process group's transport; force_a2a: go through
         the transport even with one rank (one-rank rehearsals of the real backend); legacy_exchange: under gloo, plug the
         host staging in as a chebhip_exchange_fn (chebhip_dist_set_exchange: one vector per exchange, every block moved)
         instead of a chebhip_comm callback transport (which also carries chebhip_dist_mult_batch)."""
@@ -194,9 +195,15 @@ class DistPoissonC:
         self._cb = None
         self._own_comm = None
         forced = bool(force_a2a) and dist.is_initialized()
+        self.transport = comm.transport if comm is not None else "none"
         if comm is not None:
             sp._chk(L.chebhip_dist_use_comm(h, comm._h))
+        elif self.G > 1 and ipc and not legacy_exchange:
+            self._own_comm = Comm(sp, group=group, ipc=True)
+            self.transport = self._own_comm.transport
+            sp._chk(L.chebhip_dist_use_comm(h, self._own_comm._h))
         elif self.G > 1 or forced:
+            self.transport = "rccl" if dist.get_backend(group) == "nccl" else "callback"
             if dist.get_backend(group) == "nccl":
                 idbuf = C.create_string_buffer(128)
                 if self.rank == 0:
@@ -263,6 +270,8 @@ class DistPoissonC:
         import ctypes as C
         if self._comm is not None:
             return C.cast(self.sp.lib().chebhip_rccl_reduce, C.c_void_p), self._comm
+        if self._own_comm is not None and self._own_comm.transport.endswith("rccl"):
+            return self._own_comm.reduce_fn()
         return None, None
 
     def destroy(self):
@@ -510,9 +519,12 @@ def _exchangev_type():
 class Comm:
     """chebhip_comm: from a torch.distributed process group (backend "nccl": an RCCL communicator made from a unique
     id that rank 0 broadcasts; backend "gloo": the rehearsal transport, staged through the host), or one rank of a
-    LocalGroup."""
+    LocalGroup.  ipc=True (process groups of one node): the direct route on top of that transport -- the slab drivers read
+    the peers' arrays in place through IPC mappings (chebhip_comm_create_ipc), the process group's transport keeps the
+    segment exchanges and the reductions.  Falls back to the plain transport (on every rank alike) when the node
+    refuses; `transport` says what was made."""
 
-    def __init__(self, sp, group=None, local=None, null=None):
+    def __init__(self, sp, group=None, local=None, null=None, ipc=False):
         """null = (nranks, rank): no wire at all (chebhip_comm_create_null) -- times one rank's compute side alone."""
         import ctypes as C
         self.sp = sp
@@ -520,13 +532,18 @@ class Comm:
         h = C.c_void_p()
         self._nccl = None
         self._cbs = None
+        self._ipc = None
+        self._inner = None
+        self.ipc_error = None
         if null is not None:
             self.G, self.rank = int(null[0]), int(null[1])
             sp._chk(L.chebhip_comm_create_null(self.G, self.rank, C.byref(h)))
+            self.transport = "null"
         elif local is not None:
             lg, rank = local
             self.G, self.rank = lg.G, int(rank)
             sp._chk(L.chebhip_comm_create_local(lg._h, self.rank, C.byref(h)))
+            self.transport = "local"
         else:
             self.G = dist.get_world_size(group) if dist.is_initialized() else 1
             self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -540,13 +557,46 @@ class Comm:
                 sp._chk(L.chebhip_rccl_comm_create(self.G, self.rank, C.create_string_buffer(box[0], 128), C.byref(comm)))
                 self._nccl = comm
                 sp._chk(L.chebhip_comm_create_rccl(comm, self.G, self.rank, C.byref(h)))
+                self.transport = "rccl"
             else:
                 xfn = _exchangev_type()(self._host_exchangev(group))
                 rfn = sp.allreduce_trampoline(group) if self.G > 1 else None
                 self._cbs = (xfn, rfn)
                 sp._chk(L.chebhip_comm_create_callback(self.G, self.rank, C.cast(xfn, C.c_void_p),
                                                        C.cast(rfn, C.c_void_p) if rfn is not None else None, None, C.byref(h)))
+                self.transport = "callback"
         self._h = h
+        if ipc and null is None and local is None and self.G > 1:
+            self._wrap_ipc(group)
+
+    def _wrap_ipc(self, group):
+        """Collective: a shared-memory group under a name rank 0 draws, the IPC communicator over this one.  Every rank ends with the
+        same kind: if any of them could not set it up, all keep the message transport."""
+        import ctypes as C
+        import uuid
+        sp, L = self.sp, self.sp.lib()
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        box = ["/chebhip-%s" % uuid.uuid4().hex[:24]]
+        dist.broadcast_object_list(box, src=src, group=group)
+        g, h2 = C.c_void_p(), C.c_void_p()
+        rc = L.chebhip_ipc_group_open(box[0].encode(), self.G, self.rank, C.byref(g))
+        if rc == 0:
+            rc = L.chebhip_comm_create_ipc(g, self._h, C.byref(h2))
+        if rc != 0:
+            self.ipc_error = L.chebhip_last_error().decode()
+        on_gpu = dist.get_backend(group) == "nccl"
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            self._ipc, self._inner, self._h = g, self._h, h2
+            self.transport = "ipc+" + self.transport
+            return
+        if h2:
+            L.chebhip_comm_destroy(h2)
+        if g:
+            L.chebhip_ipc_group_close(g)
+        if self.ipc_error is None:
+            self.ipc_error = "another rank could not set the IPC group up"
 
     def _host_exchangev(self, group):
         """chebhip_exchangev_fn under gloo: device -> host, batched isend / irecv, host -> device, ordered on `stream`."""
@@ -597,6 +647,12 @@ class Comm:
         if getattr(self, "_h", None):
             self.sp.lib().chebhip_comm_destroy(self._h)
             self._h = None
+        if getattr(self, "_inner", None):
+            self.sp.lib().chebhip_comm_destroy(self._inner)
+            self._inner = None
+        if getattr(self, "_ipc", None):
+            self.sp.lib().chebhip_ipc_group_close(self._ipc)
+            self._ipc = None
         if getattr(self, "_nccl", None):
             self.sp.lib().chebhip_rccl_comm_destroy(self._nccl)
             self._nccl = None

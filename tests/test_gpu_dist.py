@@ -292,7 +292,7 @@ def test_dist_c_single_rank(dims):
     par.destroy(); ser.destroy()
 
 
-def _distc_worker(rank, world, port, dims, q, backend, legacy=False):
+def _distc_worker(rank, world, port, dims, q, backend, legacy=False, ipc=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     if backend == "nccl":
@@ -303,7 +303,11 @@ def _distc_worker(rank, world, port, dims, q, backend, legacy=False):
         sp = ge.load(); dsp = ge.load_dist()
         if backend == "nccl":
             sp.set_option("rccl_self_messages", 1)              # one rank on the real transport: its own block through ncclSend / ncclRecv
-        op = dsp.DistPoissonC(dims, sp, force_a2a=(backend == "nccl"), legacy_exchange=legacy)
+        op = dsp.DistPoissonC(dims, sp, force_a2a=(backend == "nccl"), legacy_exchange=legacy, ipc=ipc)
+        if ipc:
+            # process ranks reading each other's arrays in place (chebhip_comm_create_ipc over the gloo callback transport): the node
+            # must grant it -- a silent fall-back to the message route would leave the direct route untested
+            assert op.transport == "ipc+callback", (op.transport, op._own_comm.ipc_error)
         G = int(np.prod([v - 2 for v in dims]))
         U = np.random.default_rng(SEED).standard_normal(G)
         lo, n = op.slab_offset, op.local_size
@@ -320,6 +324,11 @@ def _distc_worker(rank, world, port, dims, q, backend, legacy=False):
             for q_, f in enumerate((1.0, 2.0, -1.0)):
                 assert float((Vb[q_] - f * Vl).abs().max()) <= 1e-12 * float(Vl.abs().max()), q_
         # Krylov on slabs with the C-side reduction where there is one (RCCL), else torch's
+        if G > 20000:                            # (the unpreconditioned solve is for the small grids)
+            torch.cuda.synchronize()
+            q.put((rank, lo, Vl.cpu().numpy(), None, 2))
+            op.destroy()
+            return
         b = torch.from_numpy(np.random.default_rng(SEED + 1).standard_normal(G)[lo:lo + n].copy()).cuda(); x = torch.empty_like(b)
         ks = sp.Fgmres(n, restart=60, rtol=1e-11, max_it=3000)
         fn, ctx = op.reduce_fn()
@@ -335,7 +344,8 @@ def _distc_worker(rank, world, port, dims, q, backend, legacy=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (3, (9, 8, 7), "gloo"), (2, (10, 9, 8), "gloo-legacy"), (1, (20, 18, 16), "nccl")], ids=str)
+@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (3, (9, 8, 7), "gloo"), (2, (10, 9, 8), "gloo-legacy"), (1, (20, 18, 16), "nccl"),
+                                                (2, (10, 9, 8), "gloo-ipc"), (3, (13, 12), "gloo-ipc"), (3, (70, 68, 66), "gloo-ipc"), (4, (34, 72, 40), "gloo-ipc")], ids=str)
 def test_dist_c_ranks_match_oracle(world, dims, backend):
     """2-3 ranks sharing the box's one GPU (exchange callback through gloo) and one rank on the REAL transport
     (process group "nccl", unique-id bootstrap, ncclSend / ncclRecv of the own block, ncclAllReduce in the solver):
@@ -344,7 +354,8 @@ def test_dist_c_ranks_match_oracle(world, dims, backend):
     q = ctx.Queue()
     port = _free_port()
     legacy = backend.endswith("-legacy")                    # chebhip_dist_set_exchange (the older callback contract) instead of a chebhip_comm
-    procs = [ctx.Process(target=_distc_worker, args=(r, world, port, dims, q, backend.split("-")[0], legacy)) for r in range(world)]
+    ipc = backend.endswith("-ipc")                          # process ranks on the direct route (IPC mappings; gloo carries the reductions)
+    procs = [ctx.Process(target=_distc_worker, args=(r, world, port, dims, q, backend.split("-")[0], legacy, ipc)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -352,12 +363,14 @@ def test_dist_c_ranks_match_oracle(world, dims, backend):
         p.join(timeout=120)
         assert p.exitcode == 0
     res.sort(key=lambda t: t[1])
-    V = np.concatenate([r[2] for r in res]); x = np.concatenate([r[3] for r in res])
+    V = np.concatenate([r[2] for r in res])
     G = V.size
     U = np.random.default_rng(SEED).standard_normal(G); b = np.random.default_rng(SEED + 1).standard_normal(G)
-    assert relerr(V, orc.elliptic_mult(dims, U, mode=orc.DIRECT)) < TOL
+    assert relerr(V, orc.elliptic_mult(dims, U, mode=orc.DIRECT if G <= 20000 else orc.FAST, nthreads=8)) < TOL
     assert all(r[4] == 2 for r in res)
-    assert np.linalg.norm(b - orc.elliptic_mult(dims, x, mode=orc.DIRECT)) <= 1e-9 * np.linalg.norm(b)
+    if res[0][3] is not None:
+        x = np.concatenate([r[3] for r in res])
+        assert np.linalg.norm(b - orc.elliptic_mult(dims, x, mode=orc.DIRECT)) <= 1e-9 * np.linalg.norm(b)
 
 
 
