@@ -250,10 +250,11 @@ def _all_ok(ok, dist, torch, backend):
     return bool(t.item())
 
 
-def dist_parity_check(make, dist, torch, rank, world, backend, P=34):
+def dist_parity_check(make, dist, torch, rank, world, backend, P=34, fatal=True):
     """N > 1: the slab-partitioned matvec at a reduced size (P^3) against the oracle's serial matvec, checked on rank 0.
     Returns ({"rel_l2_vs_oracle": .., "P": ..}, None), or (None, reason) when the implementation could not be set up or
-    run on some rank (every rank then gets the same answer); a numerical mismatch aborts the bench."""
+    run on some rank (every rank then gets the same answer); a numerical mismatch aborts the bench -- or, with fatal=False
+    (a route that has a fall-back), comes back as a reason on every rank."""
     import numpy as np
     op, U, V, why = None, None, None, None
     try:
@@ -285,8 +286,13 @@ def dist_parity_check(make, dist, torch, rank, world, backend, P=34):
         ref = orc.elliptic_mult((P, P, P), Ufull, mode=orc.FAST, nthreads=4)
         err = float(np.linalg.norm(np.concatenate(pieces) - ref) / np.linalg.norm(ref))
         out = {"rel_l2_vs_oracle": err, "tolerance": 1e-10, "P": P, "ranks": world}
-        if not err <= 1e-10:
+        if not err <= 1e-10 and fatal:
             raise SystemExit("parity failure: %d-rank %d^3 matvec differs from the oracle by %.3e" % (world, P, err))
+    if not fatal:
+        box = [None if out is None or out["rel_l2_vs_oracle"] <= 1e-10 else "parity: the %d^3 matvec differs from the oracle by %.3e" % (P, out["rel_l2_vs_oracle"])]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is not None:
+            return None, box[0]
     return out, None
 
 
@@ -753,7 +759,40 @@ def main():
         make_c = lambda dm: dsp.DistPoissonC(dm, sp)
         make_py = lambda dm: dsp.DistPoissonOp(dm, backend=dsp.HipBackend(sp))
         make = make_c if impl == "c" else make_py
-        dist_parity, why = dist_parity_check(make, dist, torch, rank, world, backend)   # reduced size, against the oracle on rank 0
+        # BENCH_DIST_TRANSPORT (launcher runs, C host): "auto" (default) tries the DIRECT route among the processes of the node
+        # (csrc/comm.hip IPC transport over the group's own: the ranks' kernels read each other's slabs in place, no pack, no
+        # messages) and keeps it only if the node grants the shared mappings AND the matvec equals the oracle's at two reduced sizes
+        # (34^3: pull route; 130^3: gather loader and the one-launch form, the kernels of the full size) -- otherwise the message
+        # route (RCCL grouped send / recv), said in config.ipc_fallback.  "messages": the message route; "ipc": the direct route or fail.
+        want_tr = os.environ.get("BENCH_DIST_TRANSPORT", "auto")
+        if want_tr not in ("auto", "ipc", "messages"):
+            raise SystemExit("BENCH_DIST_TRANSPORT must be auto, ipc, messages (launcher runs) or local (one process, thread ranks)")
+        ipc_note = None
+        dist_parity, why = None, None
+        used_ipc = False
+        if impl == "c" and want_tr in ("auto", "ipc"):
+            def make_ipc(dm):
+                o = dsp.DistPoissonC(dm, sp, ipc=True)
+                if not o.transport.startswith("ipc"):
+                    msg = o._own_comm.ipc_error if o._own_comm is not None else "no communicator"
+                    o.destroy()
+                    raise RuntimeError("the node did not grant the IPC group: %s" % msg)
+                return o
+            par_small, why_ipc = dist_parity_check(make_ipc, dist, torch, rank, world, backend, fatal=False)
+            if why_ipc is None:
+                dist_parity, why_ipc = dist_parity_check(make_ipc, dist, torch, rank, world, backend, P=130, fatal=False)
+            if why_ipc is None:
+                make, used_ipc = make_ipc, True
+                if rank == 0:
+                    dist_parity["also"] = par_small
+            elif want_tr == "ipc":
+                raise SystemExit("BENCH_DIST_TRANSPORT=ipc: %s" % why_ipc)
+            else:
+                ipc_note = why_ipc
+                if rank == 0:
+                    print("bench.py: the direct (IPC) route is not used (%s); timing the message route" % why_ipc, file=sys.stderr, flush=True)
+        if not used_ipc:
+            dist_parity, why = dist_parity_check(make, dist, torch, rank, world, backend)   # reduced size, against the oracle on rank 0
         dist_fallback = None
         if dist_parity is None and why is not None and impl == "c" and os.environ.get("BENCH_DIST_STRICT", "0") != "1":
             # The C-side host could not run on this node (its RCCL peer path has never met more than one rank on hardware: no
@@ -773,6 +812,11 @@ def main():
         # pack, the local directions (ONE launch of d - 1 jobs on a slab of fewer than 6 M values, csrc/dist.hip), the pencil launch, the final sum
         launches_per_step = 4 if getattr(op, "local_size", 0) < 6000000 else 5
         parallelism = "slab%d+all2all(%s, %s)" % (world, "C host" if impl == "c" else "python host", backend)
+        if used_ipc:
+            # the three directions in one launch + the final sum (csrc/dist.hip FUSE3_MAX), else local launch(es), pencil launch, sum;
+            # each of the two rendezvous adds one 64-thread polling launch, not counted
+            launches_per_step = 2 if op.local_size < 12000000 else 4
+            parallelism = "slab%d+direct-pull(IPC transport: one process per GPU, peers' slabs read in place; reductions and segment exchanges over %s)" % (world, backend)
         wd.enter("spin-up, warm-up and the %d timed steps of the %d-rank matvec" % (args.steps, world), wd_s)
 
     def barrier():
@@ -831,8 +875,16 @@ def main():
         }
         if world > 1:
             out["parity"] = dist_parity
+            if used_ipc:
+                out["roofline"]["kernel"] = ("slab route (direct transport among processes), whole step of one GPU: " +
+                                             ("cheb_sweep_multi_gather_kernel (ONE launch: the local directions + the pencil direction reading the peers' slabs in place)" if launches_per_step == 2 else
+                                              "the local directions, cheb_sweep_vec4_gather_kernel (the pencil direction reading the peers' slabs in place)") +
+                                             ", k_pull_combine (reads the peers' pencil results in place); 2 rendezvous (one 64-thread polling launch each), no messages")
+                out["roofline"]["exchanges_per_step"] = 0
             if dist_fallback:
                 out["config"]["c_host_fallback"] = dist_fallback
+            if ipc_note:
+                out["config"]["ipc_fallback"] = ipc_note[:300]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 Uh, Vh = U.cpu().numpy(), V.cpu().numpy()

@@ -688,13 +688,13 @@ class DistStokesC(_DistC):
     """The Stokes callbacks on slabs with the host in C++ (csrc/slabx.hip: chebhip_dist_stokes_*): partition, pack, the
     grouped exchanges, pencil launches and the AXPY-fused unpack are behind the ABI; `op` is the slab-mode StokesOp."""
 
-    def __init__(self, dims, sp, comm=None, group=None):
+    def __init__(self, dims, sp, comm=None, group=None, ipc=False):
         import ctypes as C
         self.sp = sp
         self.dims = tuple(int(v) for v in dims)
         self._own_comm = None
         if comm is None and dist.is_initialized() and dist.get_world_size(group) > 1:
-            comm = self._own_comm = Comm(sp, group=group)
+            comm = self._own_comm = Comm(sp, group=group, ipc=ipc)    # ipc: the direct route among the processes of one node
         self.comm = comm
         L = sp.lib()
         h = C.c_void_p()
@@ -732,13 +732,13 @@ class DistStokesC(_DistC):
 class DistEllipticC(_DistC):
     """MatMult_Elliptic / FormFunction for any coefficient state on slabs, host in C++ (chebhip_dist_ell_*)."""
 
-    def __init__(self, dims, sp, comm=None, group=None):
+    def __init__(self, dims, sp, comm=None, group=None, ipc=False):
         import ctypes as C
         self.sp = sp
         self.dims = tuple(int(v) for v in dims)
         self._own_comm = None
         if comm is None and dist.is_initialized() and dist.get_world_size(group) > 1:
-            comm = self._own_comm = Comm(sp, group=group)
+            comm = self._own_comm = Comm(sp, group=group, ipc=ipc)    # ipc: the direct route among the processes of one node
         self.comm = comm
         L = sp.lib()
         h = C.c_void_p()

@@ -88,7 +88,7 @@ def test_roofline_object_of_the_multi_gpu_line_prices_the_step_not_a_launch():
 def test_bench_gpus_2_batched_leg_runs_under_the_gloo_rehearsal():
     """BENCH_BATCHED=1: the informational 4-vectors-per-exchange leg through the chebhip_comm callback transport (it used to need RCCL)."""
     r = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--spinup", "2", "--size", "40"],
-                  {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1", "BENCH_BATCHED": "1"}, 900)
+                  {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1", "BENCH_BATCHED": "1", "BENCH_DIST_TRANSPORT": "messages"}, 900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(json_lines(r.stdout)) == 1
     info = [ln for ln in r.stderr.splitlines() if "vectors per exchange" in ln]
@@ -118,9 +118,29 @@ def test_local_transport_refuses_a_process_launcher():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_takes_the_direct_route_among_processes_by_default():
+    """Round 6: under a launcher (here: bench.py's own ranks, gloo, sharing the box's GPU) the default transport is the IPC direct
+    route -- kept only after the node granted the mappings and two reduced-size matvecs equalled the oracle's; the batched leg runs on it."""
+    r = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "2", "--size", "64"],
+                  {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1", "BENCH_BATCHED": "1"}, 900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    rec = lines[0]
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert "direct-pull(IPC transport: one process per GPU" in rec["config"]["parallelism"] and "ipc_fallback" not in rec["config"]
+    assert rec["parity"]["rel_l2_vs_oracle"] <= 1e-10 and rec["parity"]["P"] == 130 and rec["parity"]["also"]["P"] == 34
+    assert rec["roofline"]["exchanges_per_step"] == 0 and rec["config"]["launches_per_step"] == 2
+    info = [ln for ln in r.stderr.splitlines() if "vectors per exchange" in ln]
+    assert len(info) == 1, r.stderr[-2000:]
+    brec = json.loads(info[0].split("exchange: ", 1)[1])
+    assert brec.get("nrhs") == 4 and brec.get("vectors_agree") is True, brec
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_as_typed_prints_one_parsed_line():
     r = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "2", "--size", "64"],
-                  {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1"}, 900)
+                  {"BENCH_DIST_BACKEND": "gloo", "BENCH_DIST_STRICT": "1", "BENCH_DIST_TRANSPORT": "messages"}, 900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = json_lines(r.stdout)
     assert len(lines) == 1, r.stdout

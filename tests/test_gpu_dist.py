@@ -378,7 +378,7 @@ def test_dist_c_ranks_match_oracle(world, dims, backend):
 def _slabx_worker(rank, world, port, dims, q, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    if backend == "nccl":
+    if backend.split("-")[0] == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -387,7 +387,10 @@ def _slabx_worker(rank, world, port, dims, q, backend):
         if backend == "nccl":
             sp.set_option("rccl_self_messages", 1)              # one rank on the real transport: its own block through ncclSend / ncclRecv
         d = len(dims)
-        comm = dsp.Comm(sp) if world > 1 else None
+        ipc = backend.endswith("-ipc"); backend = backend.split("-")[0]
+        comm = dsp.Comm(sp, ipc=ipc) if world > 1 else None
+        if ipc:                                                # process ranks on the direct route; gloo carries segments and reductions
+            assert comm.transport == "ipc+callback", (comm.transport, comm.ipc_error)
         if backend == "nccl":                                  # world == 1: make the RCCL communicator by hand
             import ctypes as C
             L = sp.lib()
@@ -422,11 +425,14 @@ def _slabx_worker(rank, world, port, dims, q, backend):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (1, (10, 9, 8), "nccl")], ids=str)
+@pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (1, (10, 9, 8), "nccl"),
+                                                (2, (10, 9, 8), "gloo-ipc"), (3, (70, 68, 66), "gloo-ipc")], ids=str)
 def test_slabx_c_drivers_over_process_group(world, dims, backend):
     """chebhip_dist_stokes_* / chebhip_dist_ell_* with the transports a multi-process run uses: the callback transport
-    staged through gloo (2-3 ranks sharing the box's GPU), and ONE rank on the real RCCL transport (grouped ncclSend /
-    ncclRecv of its own blocks, every field of a call in one group) -- against the oracle."""
+    staged through gloo (2-3 ranks sharing the box's GPU), ONE rank on the real RCCL transport (grouped ncclSend /
+    ncclRecv of its own blocks, every field of a call in one group), and process ranks on the IPC direct route (the
+    pencil sweeps read the ranks' slab fields in place at 70 x 68 x 66; at 10 x 9 x 8 the geometry keeps the segment
+    route, which the IPC communicator hands to the transport under it) -- against the oracle."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -442,9 +448,10 @@ def test_slabx_c_drivers_over_process_group(world, dims, backend):
     rng = np.random.default_rng(SEED)
     N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
     x = rng.standard_normal(g); dv = rng.standard_normal(ndv); force = rng.standard_normal(g); w = rng.standard_normal(g)
-    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=orc.DIRECT)
-    assert relerr(yf, ref_f) < TOL and relerr(ym, orc.stokes_mult(dims, w, eta, deta, strain, mode=orc.DIRECT)) < TOL
+    mode = orc.DIRECT if N <= 20000 else orc.FAST
+    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=mode)
+    assert relerr(yf, ref_f) < TOL and relerr(ym, orc.stokes_mult(dims, w, eta, deta, strain, mode=mode)) < TOL
     n, ge_, nd = orc.sizes(dims)
     U = rng.random(ge_) + 0.5; b = rng.standard_normal(ge_); dirv = rng.standard_normal(nd); X = rng.standard_normal(ge_)
-    ref_r, eta, deta, gradu = orc.elliptic_function(dims, U, b, dirv, gamma=4.0, exponent=2.0, mode=orc.DIRECT)
-    assert relerr(R, ref_r) < TOL and relerr(V, orc.elliptic_mult(dims, X, eta, deta, gradu, mode=orc.DIRECT)) < TOL
+    ref_r, eta, deta, gradu = orc.elliptic_function(dims, U, b, dirv, gamma=4.0, exponent=2.0, mode=mode)
+    assert relerr(R, ref_r) < TOL and relerr(V, orc.elliptic_mult(dims, X, eta, deta, gradu, mode=mode)) < TOL
