@@ -266,8 +266,12 @@ def dist_parity_check(make, dist, torch, rank, world, backend, P=34, fatal=True)
             op.destroy()
         return None, why or "setup failed on another rank"
     try:
-        U = op.random_input(SEED + 1)
+        # two calls on the SAME arrays with different contents, the second one checked: a direct route that served a peer's previous
+        # values from a cache (the peers rewrite the same addresses call after call) would pass a single call
+        U = op.random_input(SEED + 7)
         V = torch.empty_like(U)
+        op.mult(U, V)
+        U.copy_(op.random_input(SEED + 1))
         op.mult(U, V)
         torch.cuda.synchronize()
     except Exception as e:

@@ -144,7 +144,7 @@ struct IpcSlot {
 };
 struct IpcShared {
   std::atomic<unsigned> magic; int G;
-  std::atomic<int> aborted;
+  std::atomic<int> aborted, attached;                                     // attached: ranks that hold the mapping (rank 0 unlinks the name after the last)
   alignas(64) std::atomic<unsigned> bar_count;
   alignas(64) std::atomic<unsigned> bar_gen;
   IpcSlot slot[MAXR];
@@ -155,15 +155,23 @@ constexpr unsigned IPC_MAGIC = 0x43484950u;
 // enqueueing waits): lane r polls the sequence number of rank r until it reaches what that rank announced.  Every lane leaves
 // after `limit` ticks of the 100-MHz clock at the latest and then marks the group aborted (the ranks' next barrier fails) -- no
 // wave waits forever for a peer that died.
+// EIGHT workgroups, one per XCD (workgroups are dealt to the XCDs round-robin), each ending with a system-scope acquire: what this
+// XCD's L2 still holds of the peers' arrays -- they rewrite the same addresses call after call -- is dropped before the kernels
+// behind this one read them.  (Between LOCAL thread ranks the runtime's cross-device event wait does that for the whole device;
+// here the dispatches that follow carry agent-scope acquires only.  The same fence as the first statement of every wave of the
+// reading kernels cost the G = 8 rank 31 us of 45: once per XCD and rendezvous is what is needed.)
 struct IpcWait { const unsigned long long *flag[MAXR]; unsigned long long want[MAXR]; };
 __global__ __launch_bounds__(64) void k_ipc_wait(IpcWait a, int G, int me, unsigned long long limit, int *aborted) {
   const int r = threadIdx.x;
-  if (r >= G || r == me || a.want[r] == 0) return;
-  const unsigned long long want = a.want[r], t0 = __builtin_amdgcn_s_memrealtime();
-  while (__hip_atomic_load(a.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    if (__builtin_amdgcn_s_memrealtime() - t0 > limit) { __hip_atomic_store(aborted, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
-    __builtin_amdgcn_s_sleep(4);
+  if (r < G && r != me && a.want[r] != 0) {
+    const unsigned long long want = a.want[r], t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(a.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      if (__hip_atomic_load(aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;     // a rank gave up: its number will not come
+      if (__builtin_amdgcn_s_memrealtime() - t0 > limit) { __hip_atomic_store(aborted, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 static_assert(std::atomic<unsigned>::is_always_lock_free, "the barrier of the IPC group lives in memory shared between processes");
 }  // namespace
@@ -253,6 +261,13 @@ extern "C" int chebhip_ipc_group_open(const char *name, int nranks, int rank, ch
   int fd = -1;
   const auto t0 = std::chrono::steady_clock::now();
   auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g->timeout_s; };
+  // rank 0 takes the name away again -- at once when everybody holds the mapping; after a failure of its own only when the others
+  // have found the segment (and its abort mark: they fail at once instead of searching a vanished name), or after 5 s
+  auto unlink_when_attached = [&] {
+    const auto u0 = std::chrono::steady_clock::now();
+    while (g->S && g->S->attached.load() < nranks && std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count() < 5.0) usleep(500);
+    (void)shm_unlink(name);
+  };
   if (rank == 0) {
     (void)shm_unlink(name);
     fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -279,6 +294,8 @@ extern "C" int chebhip_ipc_group_open(const char *name, int nranks, int rank, ch
     while (g->S->magic.load(std::memory_order_acquire) != IPC_MAGIC) { if (late()) return fail(CHEBHIP_ERR_DEVICE, "attach", "rank 0 did not initialise the segment in time"); usleep(200); }
     if (g->S->G != nranks) return fail(CHEBHIP_ERR_ARG, "attach", "the segment belongs to a group of another size");
   }
+  g->S->attached.fetch_add(1);
+  if (g->S->aborted.load()) { if (rank == 0) unlink_when_attached(); return fail(CHEBHIP_ERR_DEVICE, "attach", "another rank could not set the group up"); }
   hipError_t e = hipHostRegister(m, g->bytes, hipHostRegisterMapped);
   if (e == hipSuccess) { g->registered = true; e = hipHostGetDevicePointer((void **)&g->dS, m, 0); }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&g->fence, hipEventDisableTiming);
@@ -286,10 +303,10 @@ extern "C" int chebhip_ipc_group_open(const char *name, int nranks, int rank, ch
   if (e == hipSuccess) e = hipGetDevice(&dev);
   IpcSlot &me = g->S->slot[rank];
   if (e == hipSuccess) e = hipDeviceGetPCIBusId(me.bus, (int)sizeof me.bus, dev);
-  if (e != hipSuccess) { (void)hipGetLastError(); g->S->aborted.store(1); if (rank == 0) (void)shm_unlink(name); return fail(CHEBHIP_ERR_DEVICE, "device setup", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipGetLastError(); g->S->aborted.store(1); if (rank == 0) unlink_when_attached(); return fail(CHEBHIP_ERR_DEVICE, "device setup", hipGetErrorString(e)); }
   me.pid = (int)getpid(); me.bound = 1;
   int rc = g->barrier();                                                  // everybody holds the mapping and has filled its slot
-  if (rank == 0) (void)shm_unlink(name);
+  if (rank == 0) { if (rc) unlink_when_attached(); else (void)shm_unlink(name); }
   if (rc) { chebhip_ipc_group_close(g); return rc; }
   *out = g;
   return 0;
@@ -540,7 +557,7 @@ int comm_rendezvous(chebhip_comm *c, const double *const *ptrs, int n, int slot,
     }
     if (c->G > 1) {
       int *dab = (int *)(g->dS + ((char *)&S->aborted - (char *)S));
-      hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, st, wa, c->G, c->rank, (unsigned long long)(g->timeout_s * 1e8), dab);
+      hipLaunchKernelGGL(k_ipc_wait, dim3(8), dim3(64), 0, st, wa, c->G, c->rank, (unsigned long long)(g->timeout_s * 1e8), dab);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) { S->aborted.store(1); return chebhip_fail(CHEBHIP_ERR_DEVICE, "k_ipc_wait: %s", hipGetErrorString(e)); }
     }

@@ -191,3 +191,40 @@ def test_slab_pencil_round_trip(world, dims, nf):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] and r[2] for r in res), res
+
+
+# ---- the IPC transport's refusal path (csrc/comm.hip): no GPU here, so the shared segment cannot be registered with a device ----
+def _ipc_refusal_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        sp = ge.load(); dsp = ge.load_dist()
+        t0 = time.perf_counter()
+        comm = dsp.Comm(sp, ipc=True)
+        q.put((rank, comm.transport, comm.ipc_error, time.perf_counter() - t0, os.path.exists("/dev/shm") and [f for f in os.listdir("/dev/shm") if f.startswith("chebhip-")]))
+        comm.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ipc_transport_falls_back_on_every_rank_alike_when_the_node_refuses(world):
+    """Comm(ipc=True) where the direct route cannot be had (here: no device to register the shared segment with): every rank keeps the
+    message transport, says why, does so within seconds (a rank that fails marks the segment, the others do not search a vanished
+    name until their time limit), and the shared-memory name is gone afterwards."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the node grants the IPC group (tests/test_gpu_dist.py covers that side)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipc_refusal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] == "callback" and r[2] for r in res), res
+    assert max(r[3] for r in res) < 30.0, res
+    assert not any(r[4] for r in res), res
