@@ -324,7 +324,7 @@ def _distc_worker(rank, world, port, dims, q, backend, legacy=False, ipc=False):
             for q_, f in enumerate((1.0, 2.0, -1.0)):
                 assert float((Vb[q_] - f * Vl).abs().max()) <= 1e-12 * float(Vl.abs().max()), q_
         # Krylov on slabs with the C-side reduction where there is one (RCCL), else torch's
-        if G > 20000:                            # (the unpreconditioned solve is for the small grids)
+        if G > 20000 or max(dims) > 24:          # (the unpreconditioned solve is for the small grids: cond(L) grows like n^4)
             torch.cuda.synchronize()
             q.put((rank, lo, Vl.cpu().numpy(), None, 2))
             op.destroy()
