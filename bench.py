@@ -775,6 +775,10 @@ def main():
         dist_parity, why = None, None
         used_ipc = False
         if impl == "c" and want_tr in ("auto", "ipc"):
+            # the ranks of a bench run arrive at every rendezvous within milliseconds: a peer that has not come after 30 s will not come
+            # (this bounds what a node on which the direct route does not work costs before the fall-back: one time limit, not the default 120 s)
+            sp.set_option("local_timeout_s", int(os.environ.get("BENCH_IPC_TIMEOUT_S", "30")))
+
             def make_ipc(dm):
                 o = dsp.DistPoissonC(dm, sp, ipc=True)
                 if not o.transport.startswith("ipc"):

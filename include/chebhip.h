@@ -470,7 +470,7 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *   eta_from_memory       1: FormFunction reads eta instead of forming 1 + gamma u^2 on chip (exponent 2)
  *   gather_pass           1: FormFunction always runs its gather pass, also for homogeneous Dirichlet rows
  *   rccl_self_messages    1: a rank's own block of an exchange goes through ncclSend / ncclRecv too (one-rank smoke runs)
- *   local_timeout_s       seconds a thread rank waits for its peers before the group is aborted (default 120)
+ *   local_timeout_s       seconds a thread rank (LOCAL) or process rank (IPC: barrier and polling launch) waits for its peers before the group is aborted (default 120)
  *   dist_single_stream    chebhip_dist_mult's local sweeps: 0 (default) = by transport -- on a side stream (they overlap both exchanges) when
  *                            data leaves the device (RCCL, a callback transport, thread ranks on several devices), on the caller's stream
  *                            when it does not (one rank, the NULL transport, thread ranks sharing one device: there the side stream only

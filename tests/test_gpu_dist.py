@@ -455,3 +455,50 @@ def test_slabx_c_drivers_over_process_group(world, dims, backend):
     U = rng.random(ge_) + 0.5; b = rng.standard_normal(ge_); dirv = rng.standard_normal(nd); X = rng.standard_normal(ge_)
     ref_r, eta, deta, gradu = orc.elliptic_function(dims, U, b, dirv, gamma=4.0, exponent=2.0, mode=mode)
     assert relerr(R, ref_r) < TOL and relerr(V, orc.elliptic_mult(dims, X, eta, deta, gradu, mode=mode)) < TOL
+
+
+# ---- IPC process ranks: a rank that does not come releases the others with an error, not a hang ------------------------------------
+def _ipc_absent_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        sp = ge.load(); dsp = ge.load_dist()
+        sp.set_option("local_timeout_s", 4)
+        op = dsp.DistPoissonC((20, 18, 16), sp, ipc=True)
+        assert op.transport == "ipc+callback", op.transport
+        U = torch.randn(op.local_size, dtype=torch.float64, device="cuda"); V = torch.empty_like(U)
+        op.mult(U, V)                               # one collective call that works
+        torch.cuda.synchronize()
+        err, t0 = None, time.perf_counter()
+        if rank != 1:                               # rank 1 never makes the second call
+            try:
+                op.mult(U, V)
+                torch.cuda.synchronize()
+            except Exception as e:                  # noqa: BLE001
+                err = repr(e)
+        q.put((rank, err, time.perf_counter() - t0))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ipc_rank_that_never_arrives_fails_its_peers_within_the_time_limit():
+    """The rendezvous of the IPC transport is a barrier in shared memory with a time limit (option local_timeout_s): a process rank whose
+    peer does not make the collective call gets an error naming that after the limit -- it neither hangs nor reads the absent peer's arrays."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipc_absent_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1][1] is None
+    for r in (0, 2):
+        assert res[r][1] is not None and ("did not arrive" in res[r][1] or "aborted" in res[r][1]), res
+        assert res[r][2] < 30.0, res
