@@ -292,9 +292,8 @@ int chebhip_rccl_reduce(void *nccl_comm, double *vals_dev, int count, void *stre
 /*                     callback) that carries the segment exchanges and the    */
 /*                     reductions.  The same collective rules as _create_local */
 /*                     (destroys included).  Vectors handed to a driver on it  */
-/*                     must come from hipMalloc (not from a virtual-memory     */
-/*                     allocator) and stay allocated between calls, or         */
-/*                     chebhip_ipc_group_forget is called after freeing them.  */
+/*                     must come from hipMalloc (a caching allocator's blocks  */
+/*                     qualify, a virtual-memory allocator's do not).          */
 /* ------------------------------------------------------------------------- */
 typedef struct chebhip_comm chebhip_comm;
 typedef struct chebhip_local_group chebhip_local_group;
@@ -320,7 +319,6 @@ int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out);
 int chebhip_ipc_group_open(const char *name, int nranks, int rank, chebhip_ipc_group **out);
 int chebhip_ipc_group_close(chebhip_ipc_group *g);
 int chebhip_ipc_group_abort(chebhip_ipc_group *g);
-int chebhip_ipc_group_forget(chebhip_ipc_group *g);
 int chebhip_comm_create_ipc(chebhip_ipc_group *g, chebhip_comm *inner, chebhip_comm **out);
 int chebhip_comm_destroy(chebhip_comm *c);
 int chebhip_comm_size(const chebhip_comm *c);

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "chebhip_rccl_unique_id", "chebhip_rccl_comm_create", "chebhip_rccl_comm_destroy", "chebhip_rccl_reduce",
     "chebhip_comm_create_rccl", "chebhip_local_group_create", "chebhip_local_group_destroy", "chebhip_local_group_abort",
     "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_create_null", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
-    "chebhip_ipc_group_open", "chebhip_ipc_group_close", "chebhip_ipc_group_abort", "chebhip_ipc_group_forget", "chebhip_comm_create_ipc",
+    "chebhip_ipc_group_open", "chebhip_ipc_group_close", "chebhip_ipc_group_abort", "chebhip_comm_create_ipc",
     "chebhip_comm_reduce", "chebhip_dist_use_comm",
     "chebhip_dist_stokes_create", "chebhip_dist_stokes_destroy", "chebhip_dist_stokes_op", "chebhip_dist_stokes_ranges",
     "chebhip_dist_ell_create", "chebhip_dist_ell_destroy", "chebhip_dist_ell_op", "chebhip_dist_ell_ranges",
@@ -196,7 +196,6 @@ def lib():
         L.chebhip_ipc_group_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.chebhip_ipc_group_close.argtypes = [vp]
         L.chebhip_ipc_group_abort.argtypes = [vp]
-        L.chebhip_ipc_group_forget.argtypes = [vp]
         L.chebhip_comm_create_ipc.argtypes = [vp, vp, C.POINTER(vp)]
         L.chebhip_comm_size.argtypes = [vp]
         L.chebhip_comm_rank.argtypes = [vp]

@@ -34,6 +34,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 int chebhip_fail(int code, const char *fmt, ...);   // chebhip.hip
@@ -132,7 +133,7 @@ struct chebhip_local_group {
 
 // ---- ranks as processes of one node ------------------------------------------------------------------------------
 namespace {
-struct IpcPtr { hipIpcMemHandle_t h; unsigned long long off; int valid; int pad_; };
+struct IpcPtr { hipIpcMemHandle_t h; unsigned long long base, off; int valid; int pad_; };     // base: the allocation's address in its owner's space
 struct IpcSlot {
   int bound, pid; char bus[32];                                          // bus: PCI id of the rank's device ("do the ranks share a device?")
   unsigned long long seq;                                                // posts (of any event slot) ENQUEUED so far, and ...
@@ -182,9 +183,9 @@ struct chebhip_ipc_group {
   double timeout_s = 120.0;
   hipEvent_t fence = nullptr;                                             // recorded in front of every post: a system-scope release of what the stream wrote
   bool pending = false; hipStream_t pending_st = nullptr;                 // a mark whose number has not been written yet (ipc_post)
-  std::map<std::string, void *> opened;                                   // peers' allocations mapped here, by handle bytes
-  struct Mine { size_t size; hipIpcMemHandle_t h; };
-  std::map<void *, Mine> mine;                                            // my allocations whose handle has been taken, by base
+  struct Opened { hipIpcMemHandle_t h; void *mapped; };
+  std::map<std::pair<int, unsigned long long>, Opened> opened;            // peers' allocations mapped here, by (rank, base in its space)
+  std::vector<void *> retired;                                            // mappings of allocations their owner has replaced: closed with the group
 
   unsigned long long *dflag(int r) const { return (unsigned long long *)(dS + ((char *)&S->slot[r].flag - (char *)S)); }
   int barrier() {
@@ -208,38 +209,39 @@ struct chebhip_ipc_group {
     }
     return 0;
   }
-  // (handle of the allocation that holds p, offset of p in it).  The handle is taken once per allocation (2.8 us per call) and kept
-  // while hipMemGetAddressRange (0.1 us) reports the same base and size: an allocation that is freed and made again at the same
-  // address with the same size between two calls is NOT noticed -- vectors handed to a driver on this transport must stay allocated
-  // (a caching allocator's blocks do) or be announced with chebhip_ipc_group_forget.
+  // (handle of the allocation that holds p, its base, offset of p in it).  The handle is taken at EVERY call (hipMemGetAddressRange
+  // 0.1 us + hipIpcGetMemHandle 2.8 us, tools/ipc_probe.hip): an allocation that was freed and made again at the same address has a
+  // new handle, and the peers then map the new memory instead of reading the old one through a mapping that keeps it alive.
   int publish(const double *p, IpcPtr *out) {
     out->valid = 0;
     if (!p) return 0;
     void *base = nullptr; size_t size = 0;
     hipError_t e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p);
     if (e != hipSuccess || !base) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_ARG, "ipc transport: %p is not inside a device allocation (%s)", (const void *)p, hipGetErrorString(e)); }
-    auto it = mine.find(base);
-    if (it == mine.end() || it->second.size != size) {
-      Mine m; m.size = size;
-      e = hipIpcGetMemHandle(&m.h, base);
-      if (e != hipSuccess) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipIpcGetMemHandle: %s (allocations of a virtual-memory allocator cannot be shared)", hipGetErrorString(e)); }
-      mine[base] = m; it = mine.find(base);
-    }
-    out->h = it->second.h; out->off = (unsigned long long)((const char *)p - (const char *)base); out->valid = 1;
+    e = hipIpcGetMemHandle(&out->h, base);
+    if (e != hipSuccess) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipIpcGetMemHandle: %s (allocations of a virtual-memory allocator cannot be shared)", hipGetErrorString(e)); }
+    out->base = (unsigned long long)base; out->off = (unsigned long long)((const char *)p - (const char *)base); out->valid = 1;
     return 0;
   }
-  int translate(const IpcPtr &q, const double **out) {
+  // rank r's pointer in this process: its allocation is mapped once and the mapping kept while r publishes the same handle for that
+  // base; a new handle (r freed the allocation and got the address again) replaces the mapping (the old one is closed with the group:
+  // rare, and nothing has to be proved about kernels still in flight)
+  int translate(int r, const IpcPtr &q, const double **out) {
     *out = nullptr;
     if (!q.valid) return 0;
-    const std::string key((const char *)&q.h, sizeof q.h);
+    const auto key = std::make_pair(r, q.base);
     auto it = opened.find(key);
+    if (it != opened.end() && memcmp(&it->second.h, &q.h, sizeof q.h) != 0) {
+      retired.push_back(it->second.mapped);
+      opened.erase(it); it = opened.end();
+    }
     if (it == opened.end()) {
       void *m = nullptr;
       hipError_t e = hipIpcOpenMemHandle(&m, q.h, hipIpcMemLazyEnablePeerAccess);
       if (e != hipSuccess || !m) { (void)hipGetLastError(); return chebhip_fail(CHEBHIP_ERR_DEVICE, "hipIpcOpenMemHandle: %s", hipGetErrorString(e)); }
-      it = opened.emplace(key, m).first;
+      it = opened.emplace(key, Opened{q.h, m}).first;
     }
-    *out = (const double *)((const char *)it->second + q.off);
+    *out = (const double *)((const char *)it->second.mapped + q.off);
     return 0;
   }
 };
@@ -313,7 +315,8 @@ extern "C" int chebhip_ipc_group_open(const char *name, int nranks, int rank, ch
 }
 extern "C" int chebhip_ipc_group_close(chebhip_ipc_group *g) {
   if (!g) return 0;
-  for (auto &kv : g->opened) (void)hipIpcCloseMemHandle(kv.second);
+  for (auto &kv : g->opened) (void)hipIpcCloseMemHandle(kv.second.mapped);
+  for (void *m : g->retired) (void)hipIpcCloseMemHandle(m);
   if (g->fence) (void)hipEventDestroy(g->fence);
   if (g->registered) (void)hipHostUnregister((void *)g->S);
   if (g->S) (void)munmap((void *)g->S, g->bytes);
@@ -322,8 +325,6 @@ extern "C" int chebhip_ipc_group_close(chebhip_ipc_group *g) {
   return 0;
 }
 extern "C" int chebhip_ipc_group_abort(chebhip_ipc_group *g) { if (g && g->S) g->S->aborted.store(1); return 0; }
-// forget the handles taken for this rank's allocations (after freeing vectors that were handed to a driver on this transport)
-extern "C" int chebhip_ipc_group_forget(chebhip_ipc_group *g) { if (g) g->mine.clear(); return 0; }
 
 struct chebhip_comm {
   int kind = 0, G = 1, rank = 0;
@@ -551,7 +552,7 @@ int comm_rendezvous(chebhip_comm *c, const double *const *ptrs, int n, int slot,
     for (int r = 0; r < c->G; r++) {
       if (r == c->rank) { for (int k = 0; k < COMM_NPTR; k++) out->ptr[r][k] = k < n ? ptrs[k] : nullptr; continue; }
       const IpcSlot &ps = S->slot[r];
-      for (int k = 0; k < COMM_NPTR && !rc; k++) rc = g->translate(ps.xptr[tb][k], &out->ptr[r][k]);
+      for (int k = 0; k < COMM_NPTR && !rc; k++) rc = g->translate(r, ps.xptr[tb][k], &out->ptr[r][k]);
       if (rc) { S->aborted.store(1); return rc; }
       wa.flag[r] = g->dflag(r); wa.want[r] = ps.want[tb];
     }
