@@ -502,3 +502,60 @@ def test_ipc_rank_that_never_arrives_fails_its_peers_within_the_time_limit():
     for r in (0, 2):
         assert res[r][1] is not None and ("did not arrive" in res[r][1] or "aborted" in res[r][1]), res
         assert res[r][2] < 30.0, res
+
+
+# ---- config 5's solve phase on PROCESS ranks (IPC direct route over gloo): Newton / continuation, block preconditioner ---------------
+def _ipc_solve_worker(rank, world, port, dims, kw, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        import test_gpu_dist_emul as em
+        sp = ge.load(); dsp = ge.load_dist()
+        solve = importlib.import_module(sp.__name__ + ".solve")
+        d = len(dims)
+        U, F, dv = em._exact2(dims)
+        comm = dsp.Comm(sp, ipc=True)
+        assert comm.transport == "ipc+callback", (comm.transport, comm.ipc_error)
+        D = dsp.DistStokesC(dims, sp, comm=comm)
+        (n0, n1), (b0, b1) = D.serial_ranges()
+        D.op.set_dirichlet(dv[b0 * d:b1 * d]); D.op.set_force(F[n0 * (d + 1):n1 * (d + 1)])
+        x = torch.zeros(D.global_size, dtype=torch.float64, device="cuda")
+        log = solve.stokes_solve(sp, D.op, x, dist=D, **kw)
+        torch.cuda.synchronize()
+        q.put((rank, n0, x.cpu().numpy(), [tuple(s[2:4]) for s in log]))
+        D.destroy(); comm.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,rheology", [(2, (16, 16, 16), "power"), (3, (68, 12, 10), "linear")], ids=str)
+def test_continuation_over_ipc_process_ranks(world, dims, rheology):
+    """./stokes -exact 2 with the block preconditioner over process ranks on the IPC direct route reproduces the one-GPU solve: the
+    slab callbacks' round trips through the shared-memory rendezvous (in-place pencil sweeps at 68 x 12 x 10; the segment route of
+    the small grid and of the preconditioner's transforms, and every reduction, through the gloo transport under the IPC
+    communicator), the same Newton steps, Krylov counts within a step or two, the same solution."""
+    import test_gpu_dist_emul as em
+    kw = dict(rheology=em.PL2 if rheology == "power" else em.LINEAR, cont0=0, cont=2 if rheology == "power" else 1, snes_rtol=1e-8, ksp_rtol=1e-5,
+              ksp_restart=60, ksp_max_it=200, max_linear_fail=3, snes_max_it=20)
+    if rheology == "linear":
+        kw.update(ksp_rtol=1e-9, snes_rtol=1e-7, ksp_max_it=400)
+    xs, logs = em._continuation(dims, 1, **{k: v for k, v in kw.items() if k not in ("cont0", "max_linear_fail", "snes_max_it", "ksp_restart")})
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipc_solve_worker, args=(r, world, port, dims, kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[1])
+    assert all(r[3] == res[0][3] for r in res)                                      # the same Newton / Krylov counts on every rank
+    logd = res[0][3]
+    assert [s[0] for s in logd] == [s[2] for s in logs], (logd, logs)
+    assert all(abs(a[1] - b[3]) <= max(2, 0.15 * b[3]) for a, b in zip(logd, logs)), (logd, logs)
+    xd = np.concatenate([r[2] for r in res])
+    assert relerr(xd, xs) < (1e-8 if rheology == "power" else 1e-6)
