@@ -696,7 +696,7 @@ def local_threads_main(args):
     out["roofline"]["kernel"] = ("slab route (direct transport), whole step of one GPU: " +
                                  ("cheb_sweep_multi_gather_kernel (ONE launch: the local directions + the pencil direction reading the peers' slabs in place)" if launches == 2 else
                                   "the local directions, cheb_sweep_vec4_gather_kernel (the pencil direction reading the peers' slabs in place)") +
-                                 ", k_pull_combine (the final sum reading the peers' pencil results in place); 2 rendezvous, no messages")
+                                 " storing its rows into the owners' result arrays, k_pull_combine (the final sum, local reads); 2 rendezvous, no messages")
     out["roofline"]["exchanges_per_step"] = 0
     out["roofline"]["rendezvous_per_step"] = 2
     print(json.dumps(out), flush=True)
@@ -887,7 +887,7 @@ def main():
                 out["roofline"]["kernel"] = ("slab route (direct transport among processes), whole step of one GPU: " +
                                              ("cheb_sweep_multi_gather_kernel (ONE launch: the local directions + the pencil direction reading the peers' slabs in place)" if launches_per_step == 2 else
                                               "the local directions, cheb_sweep_vec4_gather_kernel (the pencil direction reading the peers' slabs in place)") +
-                                             ", k_pull_combine (reads the peers' pencil results in place); 2 rendezvous (one 64-thread polling launch each), no messages")
+                                             " storing its rows into the owners' result arrays, k_pull_combine (the final sum, local reads); 2 rendezvous (one 8 x 64-thread polling launch each), no messages")
                 out["roofline"]["exchanges_per_step"] = 0
             if dist_fallback:
                 out["config"]["c_host_fallback"] = dist_fallback

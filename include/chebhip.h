@@ -477,7 +477,9 @@ int stokes_saddle_iterations(const stokes_saddle *s, int which);
  *                            as on RCCL instead of reading the peers' slabs and pencil results in place; 2: in place, but the pencil is
  *                            filled by a copy launch first instead of the pencil sweep reading the peers' slabs itself; 3: the pencil
  *                            sweep reads the peers' slabs but stays a launch of its own (default on a small slab: one launch of the three
- *                            directions) (A/B and tests; set it before the first matvec of a handle, on every rank)
+ *                            directions); 4: the pencil results stay where they are computed and the final sum reads the peers' (default:
+ *                            the pencil sweep stores every output row into the result array of the rank that owns the plane, the final
+ *                            sum reads local memory) (A/B and tests; set it before the first matvec of a handle, on every rank)
  *   long_lines_gemm       1: lines of 257 .. 1024 points go to rocBLAS instead of the library's own matrix-core kernel (A/B)
  *   pressure_passes       1: Stokes handles run the three boundary-extrapolation passes of StokesPressureReduceOrder before the
  *                            pressure gradient instead of folding each direction's extrapolation into its matrix (read at create)

@@ -108,6 +108,22 @@ __global__ __launch_bounds__(256) void k_pull_pack(PullSrc src, int G, long M1, 
   if (V2) { for (long t = t0; t < (len >> 1); t += T) ((double2 *)dst)[t] = ((const double2 *)from)[t]; }
   else { for (long t = t0; t < len; t += T) dst[t] = from[t]; }
 }
+// Push mode, a rank whose pencil sweep could not store into the owners' arrays itself (geometry the gather kernels do not take): row i
+// of its pencil result TT (w R doubles) goes to plane i - s0[s] of the owner's result array, columns c1r .. c1r + w -- k_pull_pack backwards.
+struct PushDst { double *p[64]; long s0[65]; long lq[64]; long pmax[64]; };
+template <bool V2>
+__global__ __launch_bounds__(256) void k_push_unpack(PushDst dst, int G, long M1, long R, long c1r, long w, const double *__restrict__ TT, long pq) {
+  const long i = blockIdx.x, q = blockIdx.z;
+  int s = 0;
+  while (s + 1 < G && i >= dst.s0[s + 1]) s++;
+  long pl = i - dst.s0[s]; if (pl > dst.pmax[s] - 1) pl = dst.pmax[s] - 1;
+  const long len = w * R;
+  double *to = dst.p[s] + q * dst.lq[s] + (pl * M1 + c1r) * R;
+  const double *from = TT + q * pq + i * len;
+  const long T = (long)blockDim.x * gridDim.y, t0 = (long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (V2) { for (long t = t0; t < (len >> 1); t += T) ((double2 *)to)[t] = ((const double2 *)from)[t]; }
+  else { for (long t = t0; t < len; t += T) to[t] = from[t]; }
+}
 // Backward: V = ((T + A_1) + A_2) + ... with T read straight from the peers' pencil results -- exchange and final sum in ONE launch.
 // One workgroup per (own plane i0, peer s): the run of w_s R doubles at row s0r + i0 of TT_s (row pitch src.pitch[s] doubles).
 template <bool V2>
@@ -152,6 +168,7 @@ struct chebhip_dist {
     cheb_plan *pencil_plan = nullptr;         // direction 0 on the pencil(s)
     std::vector<double *> A;                  // d-1 local contributions
     double *sendbuf = nullptr, *recvbuf = nullptr, *UT = nullptr, *TT = nullptr;
+    double *Tin = nullptr;                    // direct transports, push mode: -L_0 U on this rank's slab, written by the ranks that own the columns
   };
   std::map<int, Work *> w;
   hipStream_t side = nullptr;
@@ -168,7 +185,7 @@ static void dist_work_free(chebhip_dist::Work *W) {
   for (auto p : W->slab_plan) if (p) cheb_plan_destroy(p);
   if (W->pencil_plan) cheb_plan_destroy(W->pencil_plan);
   for (auto p : W->A) if (p) (void)hipFree(p);
-  double *all[] = {W->sendbuf, W->recvbuf, W->UT, W->TT};
+  double *all[] = {W->sendbuf, W->recvbuf, W->UT, W->TT, W->Tin};
   for (double *p : all) if (p) (void)hipFree(p);
   delete W;
 }
@@ -211,6 +228,8 @@ static int dist_work_build(chebhip_dist *D, int nrhs, chebhip_dist::Work *W) {
   for (int k = 0; k < d - 1; k++) DHIPCHK(hipMalloc((void **)&W->A[k], lb));
   DHIPCHK(hipMalloc((void **)&W->sendbuf, lb)); DHIPCHK(hipMalloc((void **)&W->recvbuf, lb));
   DHIPCHK(hipMalloc((void **)&W->UT, pb)); DHIPCHK(hipMalloc((void **)&W->TT, pb));
+  DHIPCHK(hipMalloc((void **)&W->Tin, lb + 16384));
+  DHIPCHK(hipMemset(W->Tin, 0, lb + 16384));     // (the NULL transport sums blocks of it that nobody writes)
   return 0;
 }
 
@@ -357,9 +376,16 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
     const bool null = chebhip::comm_is_null(D->comm);
     chebhip::PeerView pv;
     PullSrc ps;
-    const double *post[1] = {U};
-    // slot 0: "my U is complete"; wait for the peers' slot 3 of the previous matvec: they have finished reading my TT, which is rewritten below
-    rc = chebhip::comm_rendezvous(D->comm, post, 1, 0, 3, st, &pv);
+    // PUSH (default): every rank also posts its result array Tin, and the pencil sweeps store each output row into the array of the
+    // rank that owns the plane -- remote stores in the same launch as the remote loads, both directions of every link at once -- so
+    // that the final sum reads local memory only.  dist_packed_exchange = 4: the pull form (pencil results stay where they are
+    // computed, the final sum reads the peers' TT), kept for A/B and tests.  The choice depends on nothing a rank knows alone.
+    const bool push = pk != 4;
+    const double *post[2] = {U, push ? W->Tin : nullptr};
+    // slot 0: "my U is complete"; wait for the peers' slot 3 of the previous matvec: they have finished reading my TT / my own final
+    // sum has finished reading my Tin (push: the peers' stores of THIS matvec land in it), both rewritten below
+    rc = chebhip::comm_rendezvous(D->comm, post, 2, 0, 3, st, &pv);
+    if (!rc && push) for (int s = 0; s < D->G; s++) if (!pv.ptr[s][1]) rc = chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_dist_mult: rank %d posted no result array (the ranks disagree on dist_packed_exchange)", s);
     // The pencil direction reads the peers' slabs IN PLACE where it can (strided lines of 66 .. 256 points, 16-byte geometry, at most
     // GATHER_MAX ranks): the loader slots of a thread are fixed rows = fixed planes of fixed peers, so the pencil is never materialised.
     // On a small slab it is one more job of the local directions' launch: the THREE directions of the matvec are then ONE launch
@@ -374,8 +400,10 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
         const long lqs = null ? lq : D->m0[s] * M1 * R;
         gfits = gfits && lqs < 0x7fffffffL;
         gsrc.p[s] = pv.ptr[s][0]; gsrc.s0[s] = (int)D->s0[s]; gsrc.lq[s] = (unsigned)lqs; gsrc.pmax[s] = (int)(null ? (m0 > 0 ? m0 : 1) : D->m0[s]);
+        gsrc.dp[s] = push ? (double *)pv.ptr[s][1] : nullptr;
       }
       gsrc.s0[D->G] = (int)D->s0[D->G];
+      gsrc.push = push ? 1 : 0;
     }
     // (the one-launch form pays up to about 12 M values per rank and batch -- 8 B/point more in the final sum for two launches less;
     // measured at G = 2 and at four vectors per exchange over 8 ranks, profiles/r06_dist/fused_threshold.txt)
@@ -401,9 +429,23 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
       if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_pull_pack launch failed");
       if (!rc) rc = cheb_apply_lap1d(W->pencil_plan, W->UT, nullptr, -1.0, W->TT, st);                                    // TT = -L_0 UT
     }
+    if (!rc && push && D->pencil > 0 && !gathered) {                                                                      // ... and its rows to their owners
+      PushDst pd;
+      for (int s = 0; s < D->G; s++) { pd.p[s] = (double *)pv.ptr[s][1]; pd.s0[s] = D->s0[s]; pd.lq[s] = null ? lq : D->m0[s] * M1 * R; pd.pmax[s] = null ? (m0 > 0 ? m0 : 1) : D->m0[s]; }
+      pd.s0[D->G] = D->s0[D->G];
+      const long wr = D->m1[r]; const long len = wr * R;
+      unsigned gyp = (unsigned)((len + 2047) / 2048); if (gyp < 1) gyp = 1; if (gyp > 64) gyp = 64;
+      const dim3 gridp((unsigned)D->M[0], gyp, (unsigned)nrhs);
+      bool v2p = (((R & 1) == 0) || ((M1 & 1) == 0 && (D->s1[r] & 1) == 0 && (wr & 1) == 0)) && (nrhs == 1 || (pq & 1) == 0);
+      for (int s = 0; s < D->G && v2p; s++) v2p = ((size_t)pd.p[s] & 15) == 0 && (nrhs == 1 || (pd.lq[s] & 1) == 0);
+      if (v2p) hipLaunchKernelGGL((k_push_unpack<true>), gridp, dim3(256), 0, st, pd, D->G, M1, R, D->s1[r], wr, (const double *)W->TT, pq);
+      else hipLaunchKernelGGL((k_push_unpack<false>), gridp, dim3(256), 0, st, pd, D->G, M1, R, D->s1[r], wr, (const double *)W->TT, pq);
+      if (hipGetLastError() != hipSuccess) rc = chebhip_fail(CHEBHIP_ERR_DEVICE, "k_push_unpack launch failed");
+    }
     if (!rc) rc = chebhip::comm_mark(D->comm, 2, st);                                                                     // my reads of the peers' U end here
-    post[0] = W->TT;
-    // slot 1: "my TT is complete"; wait for the peers' slot 2: they have finished reading my U (the caller may rewrite it after this call)
+    post[0] = push ? nullptr : W->TT; post[1] = nullptr;
+    // slot 1: "my TT is complete" / push: "my stores into your Tin have landed"; wait for the peers' slot 2: they have finished reading
+    // my U (the caller may rewrite it after this call)
     if (!rc) rc = chebhip::comm_rendezvous(D->comm, post, 1, 1, 2, st, &pv);
     hipError_t e2 = (one_stream || fused) ? hipSuccess : hipStreamWaitEvent(st, D->ev_out, 0);
     if (rc) { chebhip::comm_abort(D->comm); return rc; }
@@ -412,12 +454,14 @@ static int dist_mult(chebhip_dist *D, chebhip_dist::Work *W, const double *U, do
       for (int s = 0; s < D->G; s++) {
         const long m1s = null ? D->m1[r] : D->m1[s];
         ps.p[s] = pv.ptr[s][0]; ps.pitch[s] = m1s * R; ps.lq[s] = null ? pq : D->M[0] * D->m1[s] * R;
+        if (push) { ps.p[s] = W->Tin + D->s1[s] * R; ps.pitch[s] = M1 * R; ps.lq[s] = lq; }         // the slab-shaped local array, segment s of a plane
       }
       APtrs A; A.n = exact ? d - 1 : 1; for (int k = 0; k < 9; k++) A.p[k] = k < A.n ? W->A[k] : nullptr;
       bool v2c = v2;
       for (int s = 0; s < D->G && v2c; s++) v2c = ((size_t)ps.p[s] & 15) == 0 && (ps.pitch[s] & 1) == 0 && (nrhs == 1 || (ps.lq[s] & 1) == 0);
-      if (v2c) hipLaunchKernelGGL((k_pull_combine<true>), dim3(grid), dim3(256), 0, st, D->split, ps, D->s0[r], M1, R, A, V, lq);
-      else hipLaunchKernelGGL((k_pull_combine<false>), dim3(grid), dim3(256), 0, st, D->split, ps, D->s0[r], M1, R, A, V, lq);
+      const long s0r = push ? 0 : D->s0[r];
+      if (v2c) hipLaunchKernelGGL((k_pull_combine<true>), dim3(grid), dim3(256), 0, st, D->split, ps, s0r, M1, R, A, V, lq);
+      else hipLaunchKernelGGL((k_pull_combine<false>), dim3(grid), dim3(256), 0, st, D->split, ps, s0r, M1, R, A, V, lq);
     }
     DHIPCHK(hipGetLastError());
     return chebhip::comm_mark(D->comm, 3, st);                                                                          // my reads of the peers' TT end here

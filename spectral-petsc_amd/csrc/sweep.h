@@ -160,8 +160,12 @@ hipError_t sweep_vec_launch(const DiffMat &m, SweepParams p, hipStream_t stream)
 // partition read straight from the ranks' slabs, dist.hip): row i of every line is plane i - s0[s] of array p[s] (s: s0[s] <= i <
 // s0[s+1]), the columns [col0, col0 + qmax) of that plane, rowlen doubles per plane; vector o of a batch starts lq[s] doubles further.
 // pmax[s] clamps the plane index (the NULL transport reads one array with every rank's geometry).
+// push != 0: the RESULT goes the same way back -- row i of every output line is stored into array dp[s] of the plane's owner (same
+// geometry as p[s]: plane i - s0[s], columns [col0, col0 + qmax), vectors lq[s] apart) instead of the dense output; `out` of the sweep
+// must still be a valid array of at least 16 KiB (lanes with nothing to store write there).
 constexpr int GATHER_MAX = 16;
-struct GatherSrc { const double *p[GATHER_MAX]; int s0[GATHER_MAX + 1]; unsigned lq[GATHER_MAX]; int pmax[GATHER_MAX]; int G; unsigned rowlen, col0; };
+struct GatherSrc { const double *p[GATHER_MAX]; int s0[GATHER_MAX + 1]; unsigned lq[GATHER_MAX]; int pmax[GATHER_MAX]; int G; unsigned rowlen, col0;
+                   double *dp[GATHER_MAX]; int push; };
 // the launch (plain input, STORE, strided lines of 66 .. 256 points, dense output); *done = false: not eligible, nothing launched
 hipError_t sweep_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done);
 hipError_t sweep_vec_launch_gather(const DiffMat &m, SweepParams p, const GatherSrc &g, hipStream_t stream, bool *done);

@@ -461,9 +461,10 @@ __global__ __launch_bounds__(512, 4) void cheb_sweep_vec_kernel(const SweepParam
 // GATH: the rows of every line come from up to GATHER_MAX different arrays (sweep.h GatherSrc; the pencil of a slab partition read from the
 // ranks' slabs in place, over xGMI for the remote ones): 64-bit global loads from per-thread row bases instead of the buffer loads --
 // COLFAST, plain input, STORE only.  A thread's loader slots are the same rows for every tile, so their bases are found once.
-template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0, bool GATH = false>
+template <int KS, bool JFAST, int MODE, int RAW = 0, int INM = 0, int GATH = 0>
 __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, const u32 BID, const u32 NBLK, const GatherSrc *gs = nullptr) {
   static_assert(!GATH || (!JFAST && MODE == 0 && RAW == 0 && INM == 0), "the gather loader exists for strided lines, plain input, STORE");
+  constexpr bool PUSH = GATH == 2;                     // GATH = 2: the results are stored into the row owners' arrays as well (sweep.h GatherSrc::push)
   constexpr bool ACC = MODE != 0, MUL = MODE == 2, ACC2 = MODE == 3;   // ACC: the operand stream exists; ACC2: two of them, (acc + acc2) + alpha r
   static_assert(!ACC2 || RAW == 0, "OUT_ACC2 has no raw mode");
   // KS = 32 has no registers for a second operand set on top of the X / Y pair (238 VGPRs of 256 in ACC mode).  Its OUT_ACC2 keeps ONE
@@ -551,6 +552,11 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
   typedef const d2 __attribute__((address_space(1))) *gd2p;
   unsigned long long gb_j[GATH ? ITEMS : 1], gb_m[GATH ? ITEMS : 1];
   u32 glq_j[GATH ? ITEMS : 1], glq_m[GATH ? ITEMS : 1];
+  // PUSH: the same for the rows the lane STORES (accumulator rows 2 rp + odd of its 16-row block, and their mirrors), in the owners'
+  // result arrays; psink: where a lane with nothing to store writes (the sweep's own output array: straight-line stores keep the
+  // loop's wait counts exact)
+  unsigned long long pb_hi[2] = {0, 0}, pb_lo[2] = {0, 0}, psink = 0;
+  u32 pl_hi[2] = {0, 0}, pl_lo[2] = {0, 0};
   if constexpr (GATH) {
     // A table BY ROW in LDS (the second operand image, first written a whole tile later): thread i < P finds the owner of row i once,
     // without a search loop and without per-lane loads of the kernel argument -- the plane ranges are compared as scalars (uniform
@@ -560,19 +566,32 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
     // the owner's entries 12.1 k, with an LDS copy of the kernel argument's table 10.6 k.
     unsigned long long *gRB = (unsigned long long *)(smem + 2 * LDS_ELEMS);
     u32 *gRL = (u32 *)(gRB + 2 * HP);
+    unsigned long long *gDB = (unsigned long long *)(gRL + 2 * HP);    // PUSH: the row's place in its owner's result array
     if (tid <= nn) {
       const int gG = gs->G;
-      unsigned long long pb = (unsigned long long)gs->p[0]; u32 lq = gs->lq[0]; int s0v = gs->s0[0], pmv = gs->pmax[0];
+      unsigned long long pb = (unsigned long long)gs->p[0], db = PUSH ? (unsigned long long)gs->dp[0] : 0ull; u32 lq = gs->lq[0]; int s0v = gs->s0[0], pmv = gs->pmax[0];
 #pragma unroll
       for (int k = 1; k < GATHER_MAX; k++) {
         const bool c = (k < gG) && (tid >= gs->s0[k]);
         pb = c ? (unsigned long long)gs->p[k] : pb; lq = c ? gs->lq[k] : lq; s0v = c ? gs->s0[k] : s0v; pmv = c ? gs->pmax[k] : pmv;
+        if constexpr (PUSH) db = c ? (unsigned long long)gs->dp[k] : db;
       }
       int pl = tid - s0v; if (pl > pmv - 1) pl = pmv - 1; if (pl < 0) pl = 0;
-      gRB[tid] = pb + ((unsigned long long)pl * gs->rowlen + gs->col0) * 8ull;
+      const unsigned long long ro = ((unsigned long long)pl * gs->rowlen + gs->col0) * 8ull;
+      gRB[tid] = pb + ro;
       gRL[tid] = lq;
+      if constexpr (PUSH) gDB[tid] = db + ro;
     }
     __syncthreads();
+    if constexpr (PUSH) {
+#pragma unroll
+      for (int rp = 0; rp < 2; rp++) {
+        int i = mt * 16 + kq + 4 * (2 * rp + (odd ? 1 : 0)); if (i > nn) i = nn;       // (rows >= H are never stored: see o_hi / o_lo below)
+        pb_hi[rp] = gDB[i]; pl_hi[rp] = gRL[i];
+        pb_lo[rp] = gDB[nn - i]; pl_lo[rp] = gRL[nn - i];
+      }
+      psink = (unsigned long long)p.out + (unsigned long long)tid * 16ull;
+    }
 #pragma unroll
     for (int sg = 0; sg < ITEMS; sg++) {
       int row = ld_b + sg * QSTEP; if (row > nn) row = nn;       // (rows past the half meet zero columns of the matrix; they stay inside the line)
@@ -852,8 +871,21 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
       else if (ACC) { vh = acc_hi[rp] + alpha * vh; vl = acc_lo[rp] + alpha_lo * vl; }
       else { vh = alpha * vh; vl = alpha_lo * vl; }
       if (JFAST && (H & 1)) { if (fold[rp]) vh = d2{vh.x, vl.y}; }       // (y_ie, y_{n-ie}): adjacent when H is odd
-      st16(r_out, o_hi[rp] + t0v, vh);
-      st16(r_out, o_lo[rp] + t0v, vl);
+      if constexpr (PUSH) {
+        // row i of this output line belongs to the rank that owns plane i: the 16 bytes go into ITS result array, where the row
+        // sits as in the array the line was read from -- remote stores inside the same launch as the remote loads (the two
+        // directions of a link at once); the final sum then reads local memory only (dist.hip)
+        typedef d2 __attribute__((address_space(1))) *gd2w;
+        const u32 o = tl / tpo, q = (tl - o * tpo) * NT + (ng * NSUB + sub) * 16 + l16e;
+        const bool cv = q < qmax;
+        const unsigned long long ah = (cv && o_hi[rp] != INVALID) ? pb_hi[rp] + ((unsigned long long)o * pl_hi[rp] + q) * 8ull : psink;
+        const unsigned long long al = (cv && o_lo[rp] != INVALID) ? pb_lo[rp] + ((unsigned long long)o * pl_lo[rp] + q) * 8ull : psink;
+        *(gd2w)ah = vh;
+        *(gd2w)al = vl;
+      } else {
+        st16(r_out, o_hi[rp] + t0v, vh);
+        st16(r_out, o_lo[rp] + t0v, vl);
+      }
     }
   };
 
@@ -930,10 +962,10 @@ __global__ __launch_bounds__(512) void cheb_sweep_vec4_kernel(const SweepParams 
   vec4_body<KS, JFAST, MODE, RAW, INM>(p, smem, blockIdx.x, gridDim.x);
 }
 
-template <int KS>
+template <int KS, bool PUSH>
 __global__ __launch_bounds__(512) void cheb_sweep_vec4_gather_kernel(const SweepParams p, const GatherSrc g) {
   __shared__ double smem[vec_lds_doubles<KS, false>()];
-  vec4_body<KS, false, 0, 0, 0, true>(p, smem, blockIdx.x, gridDim.x, &g);
+  vec4_body<KS, false, 0, 0, 0, PUSH ? 2 : 1>(p, smem, blockIdx.x, gridDim.x, &g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -962,7 +994,7 @@ __global__ __launch_bounds__(512, (KS <= 8 ? 4 : 2)) void cheb_sweep_multi_kerne
 
 // ... with ONE of the jobs reading its lines from the arrays of a GatherSrc (lines of more than 64 points): the three directions of a
 // slab rank's matvec -- the local ones and the pencil direction over the peers' slabs -- as one launch (dist.hip)
-template <int KS>
+template <int KS, bool PUSH>
 __global__ __launch_bounds__(512) void cheb_sweep_multi_gather_kernel(const MultiParams mp, const GatherSrc g, const unsigned gmask) {
   static_assert(KS >= 16, "the gather loader is part of the long-line kernel");
   constexpr int LDS = vec_lds_doubles<KS, true>() > vec_lds_doubles<KS, false>() ? vec_lds_doubles<KS, true>() : vec_lds_doubles<KS, false>();
@@ -971,7 +1003,7 @@ __global__ __launch_bounds__(512) void cheb_sweep_multi_gather_kernel(const Mult
   while (j + 1 < mp.njobs && blockIdx.x >= mp.bstart[j + 1]) j++;
   const SweepParams &p = mp.job[j];
   const u32 bid = blockIdx.x - mp.bstart[j], nblk = mp.bstart[j + 1] - mp.bstart[j];
-  if ((gmask >> j) & 1u) vec4_body<KS, false, 0, 0, 0, true>(p, smem, bid, nblk, &g);
+  if ((gmask >> j) & 1u) vec4_body<KS, false, 0, 0, 0, PUSH ? 2 : 1>(p, smem, bid, nblk, &g);
   else if (p.inner < 16) vec4_body<KS, true, 0>(p, smem, bid, nblk);
   else vec4_body<KS, false, 0>(p, smem, bid, nblk);
 }
@@ -1136,7 +1168,8 @@ static hipError_t launch_gather_t(SweepParams p, const GatherSrc &g, hipStream_t
   const unsigned grid = p.ntiles < (unsigned)ncu ? p.ntiles : (unsigned)ncu;
   *done = true;
   if (grid == 0) return hipSuccess;
-  hipLaunchKernelGGL((cheb_sweep_vec4_gather_kernel<KS>), dim3(grid), dim3(512), 0, stream, p, g);
+  if (g.push) hipLaunchKernelGGL((cheb_sweep_vec4_gather_kernel<KS, true>), dim3(grid), dim3(512), 0, stream, p, g);
+  else hipLaunchKernelGGL((cheb_sweep_vec4_gather_kernel<KS, false>), dim3(grid), dim3(512), 0, stream, p, g);
   sweep_note_launch();
   return hipGetLastError();
 }
@@ -1147,6 +1180,7 @@ static bool gather_ok(const DiffMat &m, SweepParams &p, const GatherSrc &g) {
   if (m.KS < 16 || p.inner < 16 || (p.inner & 1) || p.in_mode != IN_PLAIN || p.out_mode != OUT_STORE || p.raw || p.in_fblocks || p.qmax || p.in_os) return false;
   if (g.G < 1 || g.G > GATHER_MAX || (g.rowlen & 1) || (g.col0 & 1) || (size_t)g.col0 + p.inner > g.rowlen) return false;
   for (int s = 0; s < g.G; s++) if (!g.p[s] || ((size_t)g.p[s] & 15) || (g.lq[s] & 1) || g.pmax[s] < 1 || g.s0[s + 1] < g.s0[s]) return false;
+  if (g.push) { for (int s = 0; s < g.G; s++) if (!g.dp[s] || ((size_t)g.dp[s] & 15)) return false; if (!p.out) return false; }
   if (g.s0[0] != 0 || g.s0[g.G] != m.P) return false;                    // the planes of the arrays are exactly the rows of a line
   p.in0 = g.p[0];                                                          // (alignment checks and descriptor sizes of the unused buffer path)
   return sweep_vec_eligible(m, p);
@@ -1251,7 +1285,8 @@ static hipError_t launch_multi_t(int n, SweepParams *jobs, hipStream_t stream, b
     if (sum3) hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS, true>), dim3(b), dim3(512), 0, stream, mp);
     else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
   } else {
-    if (g) hipLaunchKernelGGL((cheb_sweep_multi_gather_kernel<KS>), dim3(b), dim3(512), 0, stream, mp, *g, gmask);
+    if (g && g->push) hipLaunchKernelGGL((cheb_sweep_multi_gather_kernel<KS, true>), dim3(b), dim3(512), 0, stream, mp, *g, gmask);
+    else if (g) hipLaunchKernelGGL((cheb_sweep_multi_gather_kernel<KS, false>), dim3(b), dim3(512), 0, stream, mp, *g, gmask);
     else hipLaunchKernelGGL((cheb_sweep_multi_kernel<KS>), dim3(b), dim3(512), 0, stream, mp);
   }
   sweep_note_launch();

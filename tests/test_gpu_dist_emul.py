@@ -71,12 +71,15 @@ def poisson_ranks(dims, G, U):
     return np.concatenate([p[1] for p in parts])
 
 
-@pytest.mark.parametrize("packed", [0, 1], ids=["direct_pull", "packed_exchange"])
-@pytest.mark.parametrize("G,dims", [(2, (12, 11, 10)), (3, (13, 9)), (4, (34, 31, 18)), (8, (66, 40, 12)), (5, (20, 7, 6, 5)), (3, (21, 16, 11)), (8, (70, 68, 66))], ids=str)
+@pytest.mark.parametrize("packed", [0, 4, 2, 1], ids=["direct_push", "direct_pull", "direct_push_after_pull_pack", "packed_exchange"])
+@pytest.mark.parametrize("G,dims", [(2, (12, 11, 10)), (3, (13, 9)), (4, (34, 31, 18)), (8, (66, 40, 12)), (5, (20, 7, 6, 5)), (3, (21, 16, 11)), (8, (70, 68, 66)), (5, (130, 40, 34))], ids=str)
 def test_poisson_thread_ranks_small(G, dims, packed):
-    """Thread ranks on the LOCAL transport.  direct_pull (default, round 6): no pack, no messages -- the launch that fills a rank's
-    pencil reads the peers' slabs in place and the final sum reads the peers' pencil results (two rendezvous per matvec);
-    packed_exchange (option dist_packed_exchange = 1): pack / segment exchange / combine, the sequence the RCCL transport runs.
+    """Thread ranks on the LOCAL transport.  direct_push (default, round 6): no pack, no messages -- the launch that runs a rank's
+    pencil direction reads the peers' slabs in place AND stores every output row into the result array of the rank that owns the
+    plane, the final sum reads local memory (two rendezvous per matvec); direct_pull (option dist_packed_exchange = 4): the pencil
+    results stay where they are computed and the final sum reads the peers'; = 2: the pencil is materialised (k_pull_pack) and its
+    result pushed by a kernel of its own -- what a rank does whose geometry the gather kernels do not take, next to ranks that push
+    from the sweep; packed_exchange (= 1): pack / segment exchange / combine, the sequence the RCCL transport runs.
     Even and odd trailing extents (16-byte and 8-byte runs), uneven splits, d = 2 .. 4."""
     sp = ge.load()
     rng = np.random.default_rng(SEED)
@@ -90,7 +93,7 @@ def test_poisson_thread_ranks_small(G, dims, packed):
 
 
 def test_poisson_direct_pull_equals_packed_exchange_to_the_bit():
-    """The two LOCAL routes run the same kernels on the same values in the same order (the pulls only move them): with
+    """The LOCAL routes (push, pull, packed) run the same kernels on the same values in the same order (only where the values travel differs): with
     dist_exact_order = 1 both reproduce the serial handle's vector to the bit, at a size where 16-byte runs, uneven column blocks
     (68 = 4 x 9 + 4 x 8) and the two-job local launch all occur; several calls in a row (events and pointer tables are reused)."""
     sp = ge.load(); dsp = ge.load_dist()
@@ -102,7 +105,7 @@ def test_poisson_direct_pull_equals_packed_exchange_to_the_bit():
         D = dsp.DistPoissonC(dims, sp, comm=comm)
         o, n = D.slab_offset, D.local_size
         outs = []
-        for packed in (0, 1):
+        for packed in (0, 1, 4):
             sp_local = packed                                   # (the option is process-wide: every rank sets the same value between collectives)
             comm.allreduce_sum(0.0)                             # all ranks have finished the previous leg before the switch
             if r == 0:
@@ -116,14 +119,14 @@ def test_poisson_direct_pull_equals_packed_exchange_to_the_bit():
             torch.cuda.current_stream().synchronize()
             outs.append(torch.stack(Vs).cpu().numpy())
         D.destroy()
-        return (o, outs[0], outs[1])
+        return (o, outs[0], outs[1], outs[2])
     sp.set_option("dist_exact_order", 1)
     try:
         parts = sorted(run_ranks(G, body), key=lambda t: t[0])
     finally:
         sp.set_option("dist_exact_order", 0); sp.set_option("dist_packed_exchange", 0)
-    Vd = np.concatenate([p[1] for p in parts], axis=1); Vp = np.concatenate([p[2] for p in parts], axis=1)
-    assert np.array_equal(Vd, Vp)
+    Vd = np.concatenate([p[1] for p in parts], axis=1); Vp = np.concatenate([p[2] for p in parts], axis=1); Vl = np.concatenate([p[3] for p in parts], axis=1)
+    assert np.array_equal(Vd, Vp) and np.array_equal(Vd, Vl)              # push = packed = pull
     ser = sp.EllipticOp(dims)
     for k in range(3):
         Ud = torch.from_numpy(U[k]).cuda(); Vd_ = torch.empty_like(Ud)
