@@ -206,6 +206,9 @@ struct chebhip_ipc_group {
         }
         if (spins > (1ul << 16)) sched_yield();                           // a late peer: stop burning the core it may need
       }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
     }
     return 0;
   }
