@@ -121,26 +121,35 @@ struct SlabX {
   // Direct transports: can the dimension-0 sweeps read the ranks' slab fields in place?  Decided from what EVERY rank knows (the
   // geometry of all ranks), so that all ranks take the same route: 16-byte rows and column blocks of at least 16 doubles on every rank.
   bool direct_geometry() const {
-    if (!comm || !chebhip::comm_direct(comm) || chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE) || G > chebhip::GATHER_MAX) return false;
+    const int pk = chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE);        // (4: the direct route in its pull form, direct_open)
+    if (!comm || !chebhip::comm_direct(comm) || (pk != 0 && pk != 4) || G > chebhip::GATHER_MAX) return false;
     if (((P1 * R) & 1) || P1 * R >= 0x7fffffffL) return false;
     for (int s = 0; s < G; s++) if (m0[s] < 1 || m1[s] * R < 16 || ((m1[s] * R) & 1) || ((s1[s] * R) & 1) || ((m0[s] * P1 * R) & 1) || m0[s] * P1 * R >= 0x7fffffffL) return false;
     return (Np & 1) == 0;
   }
-  // forward half: rendezvous on `in` (nf slab fields), the GatherSrc of this rank's pencil over the peers' fields
+  // forward half: rendezvous on `in` (nf slab fields), the GatherSrc of this rank's pencil over the peers' fields.  PUSH (default; pull
+  // form with dist_packed_exchange = 4, read at every round trip -- the same on every rank): every rank also posts its receive buffer
+  // (nf slab-shaped fields) and the pencil sweeps store each output row into the buffer of the rank that owns the plane, field by
+  // field where the operand came from -- loads and stores of a round trip in one launch (csrc/dist.hip) -- so the unpack is local.
+  bool push = true;
   int direct_open(const double *in, hipStream_t st, chebhip::GatherSrc *g) {
     used_direct = true;
+    push = chebhip::opt(chebhip::OPT_DIST_PACKED_EXCHANGE) != 4;
     const bool null = chebhip::comm_is_null(comm);
     chebhip::PeerView pv;
-    const double *post[1] = {in};
-    int rc = chebhip::comm_rendezvous(comm, post, 1, 0, 3, st, &pv);          // the peers' fields are complete; they have finished reading my previous pencil result
+    const double *post[2] = {in, push ? recvbuf : nullptr};
+    int rc = chebhip::comm_rendezvous(comm, post, 2, 0, 3, st, &pv);          // the peers' fields are complete; they have finished reading my previous pencil result / their receive buffers
     if (rc) return rc;
     *g = chebhip::GatherSrc{};
     g->G = G; g->rowlen = (unsigned)(P1 * R); g->col0 = (unsigned)(s1[rank] * R);
     for (int s = 0; s < G; s++) {
       if (!pv.ptr[s][0] || ((size_t)pv.ptr[s][0] & 15)) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: rank %d posted an unaligned field array", s);
       g->p[s] = pv.ptr[s][0]; g->s0[s] = (int)s0[s]; g->lq[s] = (unsigned)(null ? Ns : m0[s] * P1 * R); g->pmax[s] = (int)(null ? m0[rank] : m0[s]);
+      if (push && (!pv.ptr[s][1] || ((size_t)pv.ptr[s][1] & 15))) return chebhip_fail(CHEBHIP_ERR_ARG, "slab exchange: rank %d posted no receive buffer (the ranks disagree on dist_packed_exchange)", s);
+      g->dp[s] = push ? (double *)pv.ptr[s][1] : nullptr;
     }
     g->s0[G] = (int)s0[G];
+    g->push = push ? 1 : 0;
     return 0;
   }
   // backward half: my reads of the peers' fields end here; rendezvous on pen_out; out = (acc ? acc : 0) + alpha * (the peers' pencil results)
@@ -148,17 +157,21 @@ struct SlabX {
     const bool null = chebhip::comm_is_null(comm);
     int rc = chebhip::comm_mark(comm, 2, st); if (rc) return rc;
     chebhip::PeerView pv;
-    const double *post[1] = {pen_out};
-    rc = chebhip::comm_rendezvous(comm, post, 1, 1, 2, st, &pv);              // the peers' pencil results are complete; they have finished reading my fields
+    const double *post[1] = {push ? nullptr : pen_out};
+    rc = chebhip::comm_rendezvous(comm, post, 1, 1, 2, st, &pv);              // the peers' pencil results are complete (push: have landed in my receive buffer); they have finished reading my fields
     if (rc) return rc;
     if (Ns > 0) {
       XPull xp;
-      for (int s = 0; s < G; s++) { const long m1s = null ? m1[rank] : m1[s]; xp.p[s] = pv.ptr[s][0]; xp.pitch[s] = m1s * R; xp.fs[s] = P0 * m1s * R; }
+      for (int s = 0; s < G; s++) {
+        const long m1s = null ? m1[rank] : m1[s]; xp.p[s] = pv.ptr[s][0]; xp.pitch[s] = m1s * R; xp.fs[s] = P0 * m1s * R;
+        if (push) { xp.p[s] = recvbuf + s1[s] * R; xp.pitch[s] = P1 * R; xp.fs[s] = Ns; }     // the local slab-shaped fields, segment s of a plane
+      }
       const dim3 grid((unsigned)(m0[rank] * G), (unsigned)nf);
       bool v2 = vec2(out, acc, nullptr);
       for (int s = 0; s < G && v2; s++) v2 = ((size_t)xp.p[s] & 15) == 0 && (xp.pitch[s] & 1) == 0 && (xp.fs[s] & 1) == 0;
-      if (v2) hipLaunchKernelGGL((k_xpull_unpack<true>), grid, dim3(256), 0, st, split, xp, s0[rank], P1, R, Ns, acc, alpha, out);
-      else hipLaunchKernelGGL((k_xpull_unpack<false>), grid, dim3(256), 0, st, split, xp, s0[rank], P1, R, Ns, acc, alpha, out);
+      const long s0r = push ? 0 : s0[rank];
+      if (v2) hipLaunchKernelGGL((k_xpull_unpack<true>), grid, dim3(256), 0, st, split, xp, s0r, P1, R, Ns, acc, alpha, out);
+      else hipLaunchKernelGGL((k_xpull_unpack<false>), grid, dim3(256), 0, st, split, xp, s0r, P1, R, Ns, acc, alpha, out);
       XHIPCHK(hipGetLastError());
     }
     return chebhip::comm_mark(comm, 3, st);                                   // my reads of the peers' pencil results end here

@@ -878,8 +878,9 @@ __device__ __forceinline__ void vec4_body(const SweepParams &p, double *smem, co
         typedef d2 __attribute__((address_space(1))) *gd2w;
         const u32 o = tl / tpo, q = (tl - o * tpo) * NT + (ng * NSUB + sub) * 16 + l16e;
         const bool cv = q < qmax;
-        const unsigned long long ah = (cv && o_hi[rp] != INVALID) ? pb_hi[rp] + ((unsigned long long)o * pl_hi[rp] + q) * 8ull : psink;
-        const unsigned long long al = (cv && o_lo[rp] != INVALID) ? pb_lo[rp] + ((unsigned long long)o * pl_lo[rp] + q) * 8ull : psink;
+        const unsigned long long of = (unsigned long long)(o + p.gfield0);   // (a field keeps its index on the way back: slabx.hip)
+        const unsigned long long ah = (cv && o_hi[rp] != INVALID) ? pb_hi[rp] + (of * pl_hi[rp] + q) * 8ull : psink;
+        const unsigned long long al = (cv && o_lo[rp] != INVALID) ? pb_lo[rp] + (of * pl_lo[rp] + q) * 8ull : psink;
         *(gd2w)ah = vh;
         *(gd2w)al = vl;
       } else {

@@ -288,6 +288,14 @@ def test_stokes_thread_ranks_read_the_peers_fields_in_place(G):
     finally:
         sp.set_option("dist_packed_exchange", 0)
     assert relerr(yf, yf_p) < 1e-13 and relerr(ym, ym_p) < 1e-13
+    # ... and the pull form of the in-place route (= 4: pencil results stay where they are computed, the unpack reads the peers'; default:
+    # the sweeps store each row into the owner's receive buffer, the unpack is local): the same values moved another way -- the same bits
+    sp.set_option("dist_packed_exchange", 4)
+    try:
+        yf_l, ym_l = stokes_ranks(dims, G, x, dv, force, w, POWER)
+    finally:
+        sp.set_option("dist_packed_exchange", 0)
+    assert np.array_equal(yf, yf_l) and np.array_equal(ym, ym_l)
     ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=orc.FAST, nthreads=8)
     ref_m = orc.stokes_mult(dims, w, eta, deta, strain, mode=orc.FAST, nthreads=8)
     assert relerr(yf, ref_f) < 1e-10 and relerr(ym, ref_m) < 1e-10
