@@ -98,4 +98,11 @@ def test_argument_errors_of_the_wider_abi(L):
     assert L.cheb_slab_pack(4, 6, 2, 2, longs([0, 7, 6]), one, one, None) == 4   # not monotone / out of range
     assert L.cheb_slab_pack(4, 6, 2, 0, longs([0]), one, one, None) == 4         # G < 1
     assert L.cheb_slab_unpack_add(4, 6, 2, 2, longs([0, 3, 6]), None, None, 1.0, one, None) == 4
+    # the process-rank (IPC) transport: names, ranks and groups are checked before any shared memory or device is touched
+    assert L.chebhip_ipc_group_open(None, 2, 0, C.byref(h)) == 4
+    assert L.chebhip_ipc_group_open(b"no-leading-slash", 2, 0, C.byref(h)) == 4
+    assert L.chebhip_ipc_group_open(b"/chebhip-test-abi", 2, 2, C.byref(h)) == 4          # rank out of range
+    assert L.chebhip_ipc_group_open(b"/chebhip-test-abi", 65, 0, C.byref(h)) == 4
+    assert L.chebhip_comm_create_ipc(None, None, C.byref(h)) == 4
+    assert L.chebhip_ipc_group_close(None) == 0 and L.chebhip_ipc_group_abort(None) == 0
     assert h.value is None
