@@ -559,3 +559,17 @@ def test_continuation_over_ipc_process_ranks(world, dims, rheology):
     assert all(abs(a[1] - b[3]) <= max(2, 0.15 * b[3]) for a, b in zip(logd, logs)), (logd, logs)
     xd = np.concatenate([r[2] for r in res])
     assert relerr(xd, xs) < (1e-8 if rheology == "power" else 1e-6)
+
+
+def test_ipc_process_ranks_back_to_back_calls_are_bit_stable():
+    """A short run of tools/ipc_soak.py: 3 process ranks issue Poisson matvecs (push form: remote stores into the peers' result arrays)
+    and Stokes Jacobian applies back to back, without host synchronisation, rewriting the inputs in place between calls; every result
+    is compared on the device with the first one for its input.  A missing "your reads of my array have ended" / "my stores into your
+    array have landed" wait shows here as differing bits."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_soak.py"), "3", "12"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("ipc soak")]
+    assert len(lines) == 2 and all(ln.rstrip().endswith(": 0") for ln in lines), lines
+    assert all(int(ln.split(": ")[1].split(" calls")[0]) >= 100 for ln in lines), lines
