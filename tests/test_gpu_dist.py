@@ -345,7 +345,8 @@ def _distc_worker(rank, world, port, dims, q, backend, legacy=False, ipc=False):
 
 
 @pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (3, (9, 8, 7), "gloo"), (2, (10, 9, 8), "gloo-legacy"), (1, (20, 18, 16), "nccl"),
-                                                (2, (10, 9, 8), "gloo-ipc"), (3, (13, 12), "gloo-ipc"), (3, (70, 68, 66), "gloo-ipc"), (4, (34, 72, 40), "gloo-ipc")], ids=str)
+                                                (2, (10, 9, 8), "gloo-ipc"), (3, (13, 12), "gloo-ipc"), (3, (70, 68, 66), "gloo-ipc"), (4, (34, 72, 40), "gloo-ipc"),
+                                                (4, (256, 256, 256), "gloo-ipc")], ids=str)
 def test_dist_c_ranks_match_oracle(world, dims, backend):
     """2-3 ranks sharing the box's one GPU (exchange callback through gloo) and one rank on the REAL transport
     (process group "nccl", unique-id bootstrap, ncclSend / ncclRecv of the own block, ncclAllReduce in the solver):
