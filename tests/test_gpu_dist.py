@@ -427,7 +427,7 @@ def _slabx_worker(rank, world, port, dims, q, backend):
 
 
 @pytest.mark.parametrize("world,dims,backend", [(2, (10, 9, 8), "gloo"), (3, (13, 12), "gloo"), (1, (10, 9, 8), "nccl"),
-                                                (2, (10, 9, 8), "gloo-ipc"), (3, (70, 68, 66), "gloo-ipc")], ids=str)
+                                                (2, (10, 9, 8), "gloo-ipc"), (3, (70, 68, 66), "gloo-ipc"), (4, (128, 128, 128), "gloo-ipc")], ids=str)
 def test_slabx_c_drivers_over_process_group(world, dims, backend):
     """chebhip_dist_stokes_* / chebhip_dist_ell_* with the transports a multi-process run uses: the callback transport
     staged through gloo (2-3 ranks sharing the box's GPU), ONE rank on the real RCCL transport (grouped ncclSend /
@@ -450,12 +450,13 @@ def test_slabx_c_drivers_over_process_group(world, dims, backend):
     N, I, gv, gp, g, ndv = orc.stokes_sizes(dims)
     x = rng.standard_normal(g); dv = rng.standard_normal(ndv); force = rng.standard_normal(g); w = rng.standard_normal(g)
     mode = orc.DIRECT if N <= 20000 else orc.FAST
-    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=mode)
-    assert relerr(yf, ref_f) < TOL and relerr(ym, orc.stokes_mult(dims, w, eta, deta, strain, mode=mode)) < TOL
+    nt = 1 if N <= 20000 else 8
+    ref_f, eta, deta, strain = orc.stokes_function(dims, x, dv, force, rheology=POWER, mode=mode, nthreads=nt)
+    assert relerr(yf, ref_f) < TOL and relerr(ym, orc.stokes_mult(dims, w, eta, deta, strain, mode=mode, nthreads=nt)) < TOL
     n, ge_, nd = orc.sizes(dims)
     U = rng.random(ge_) + 0.5; b = rng.standard_normal(ge_); dirv = rng.standard_normal(nd); X = rng.standard_normal(ge_)
-    ref_r, eta, deta, gradu = orc.elliptic_function(dims, U, b, dirv, gamma=4.0, exponent=2.0, mode=mode)
-    assert relerr(R, ref_r) < TOL and relerr(V, orc.elliptic_mult(dims, X, eta, deta, gradu, mode=mode)) < TOL
+    ref_r, eta, deta, gradu = orc.elliptic_function(dims, U, b, dirv, gamma=4.0, exponent=2.0, mode=mode, nthreads=nt)
+    assert relerr(R, ref_r) < TOL and relerr(V, orc.elliptic_mult(dims, X, eta, deta, gradu, mode=mode, nthreads=nt)) < TOL
 
 
 # ---- IPC process ranks: a rank that does not come releases the others with an error, not a hang ------------------------------------
