@@ -403,7 +403,7 @@ def dist_rank_compute(sp, dsp, torch, t1_us):
             e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3 / reps)
         return sorted(ts)[1]
-    out = {"poisson_256": {"T1_us": t1_us}, "stokes_128_powerlaw": {}, "note": "one rank's kernels alone, no wire: compute-side bound T1 / T_rank; links unmeasured on hardware"}
+    out = {"poisson_256": {"T1_us": t1_us}, "stokes_128_powerlaw": {}, "note": "one rank's kernels alone, no wire: compute-side bound T1 / T_rank; links unmeasured on hardware.  rank_us: every peer's array is the rank's own (the remote rows are cache hits); *_distinct_peer_arrays: G - 1 arrays of their own stand for the peers'"}
     for G in (2, 4, 8):
         comm = dsp.Comm(sp, null=(G, 0))
         D = dsp.DistPoissonC((256, 256, 256), sp, comm=comm)
@@ -425,6 +425,22 @@ def dist_rank_compute(sp, dsp, torch, t1_us):
             rec["nrhs%d_rank_us_per_vector" % nrhs] = tb / nrhs
             del Ub, Vb
         rec["bound_speedup_nrhs4"] = t1_us / rec["nrhs4_rank_us_per_vector"]
+        # ... and with the "peers'" slabs and result arrays as G - 1 arrays of their own (chebhip_comm_null_set_shadow): the pencil job's
+        # rows then come from and go to distinct local memory instead of being re-reads of the rank's own planes that hit the caches --
+        # still no wire, but no free remote memory either: the tighter of the two compute-side bounds
+        try:
+            for nrhs in (1, 4):
+                Ub = torch.randn((nrhs, D.local_size), dtype=torch.float64, device="cuda"); Vb = torch.empty_like(Ub)
+                for k in (0, 1):
+                    comm.set_null_shadow(k, [None] + [torch.randn((nrhs, D.local_size), dtype=torch.float64, device="cuda") for _ in range(G - 1)])
+                td = t_us((lambda: D.mult(Ub[0], Vb[0])) if nrhs == 1 else (lambda: D.mult_batch(Ub, Vb)))
+                rec["rank_us_distinct_peer_arrays" if nrhs == 1 else "nrhs4_rank_us_per_vector_distinct_peer_arrays"] = td / nrhs
+                del Ub, Vb
+            rec["bound_speedup_distinct_peer_arrays"] = t1_us / rec["rank_us_distinct_peer_arrays"]
+            rec["bound_speedup_nrhs4_distinct_peer_arrays"] = t1_us / rec["nrhs4_rank_us_per_vector_distinct_peer_arrays"]
+        finally:
+            for k in (0, 1):
+                comm.set_null_shadow(k, [None] * G)
         out["poisson_256"]["G%d" % G] = rec
         D.destroy(); comm.destroy(); del U, V
     ser = sp.StokesOp((128, 128, 128)); ser.set_rheology(1, 1.0, 3.0, 1e-4, 1.0)

@@ -312,6 +312,11 @@ int chebhip_comm_create_callback(int nranks, int rank, chebhip_exchangev_fn xfn,
 /* No wire: every "peer" is the rank itself (the kernels of the direct route with every byte read locally).  For timing the compute
  * side of one rank of an N-rank partition on one GPU; results are meaningless for N > 1. */
 int chebhip_comm_create_null(int nranks, int rank, chebhip_comm **out);
+/* ... with arrays of their own standing for the peers' k-th posted array (arrays[r], r = 0 .. nranks-1; NULL entries and arrays == NULL:
+ * the rank's own): the kernels then read and write nranks distinct arrays, as among real ranks, instead of finding the "peers'" rows
+ * in the caches because they are the rank's own.  Each array as large as what the driver posts at index k (chebhip_dist_mult: 0 = the
+ * slab vector(s), 1 = the result array of the same size).  Not owned. */
+int chebhip_comm_null_set_shadow(chebhip_comm *c, int k, const double *const *arrays);
 /* Process ranks.  _open is collective: `name` is a POSIX shared-memory name ("/chebhip-<unique per group>") that rank 0 creates
  * and unlinks again once every rank holds the mapping; call it with the rank's device current.  `inner` (not owned, may be NULL
  * for one rank): a communicator of the same ranks on a message transport.  _close after the communicators and drivers made on

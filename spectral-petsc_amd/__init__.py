@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "chebhip_dist_use_rccl", "chebhip_dist_set_exchange", "chebhip_dist_mult", "chebhip_dist_mult_batch",
     "chebhip_rccl_unique_id", "chebhip_rccl_comm_create", "chebhip_rccl_comm_destroy", "chebhip_rccl_reduce",
     "chebhip_comm_create_rccl", "chebhip_local_group_create", "chebhip_local_group_destroy", "chebhip_local_group_abort",
-    "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_create_null", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
+    "chebhip_comm_create_local", "chebhip_comm_create_callback", "chebhip_comm_create_null", "chebhip_comm_null_set_shadow", "chebhip_comm_destroy", "chebhip_comm_size", "chebhip_comm_rank",
     "chebhip_ipc_group_open", "chebhip_ipc_group_close", "chebhip_ipc_group_abort", "chebhip_comm_create_ipc",
     "chebhip_comm_reduce", "chebhip_dist_use_comm",
     "chebhip_dist_stokes_create", "chebhip_dist_stokes_destroy", "chebhip_dist_stokes_op", "chebhip_dist_stokes_ranges",
@@ -193,6 +193,7 @@ def lib():
         L.chebhip_comm_create_callback.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)]
         L.chebhip_comm_destroy.argtypes = [vp]
         L.chebhip_comm_create_null.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+        L.chebhip_comm_null_set_shadow.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.chebhip_ipc_group_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.chebhip_ipc_group_close.argtypes = [vp]
         L.chebhip_ipc_group_abort.argtypes = [vp]

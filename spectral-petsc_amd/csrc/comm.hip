@@ -335,6 +335,7 @@ struct chebhip_comm {
   chebhip_exchangev_fn xfn = nullptr; chebhip_reduce_fn rfn = nullptr; void *ctx = nullptr;
   chebhip_local_group *lg = nullptr;
   double *scratch = nullptr;                    // LOCAL: the reduction's private result (MAXR doubles)
+  const double *shadow[chebhip::COMM_NPTR][MAXR] = {};   // NULL: arrays that stand for the peers' (chebhip_comm_null_set_shadow; not owned)
   chebhip_ipc_group *ig = nullptr;              // IPC: the process group (not owned) ...
   chebhip_comm *inner = nullptr;                // ... and the message transport under it (not owned): segment exchanges, reductions
 };
@@ -460,6 +461,16 @@ extern "C" int chebhip_comm_create_ipc(chebhip_ipc_group *g, chebhip_comm *inner
   return 0;
 }
 
+// NULL transport only: from now on peer r's k-th posted array is arrays[r] (NULL entries: the rank's own, as before) instead of the
+// rank's own array -- the kernels of the direct route then read and write G distinct arrays, as among real ranks, instead of finding
+// the "peers'" rows in the caches because they are its own.  The arrays must be as large as what the drivers post at that index
+// (chebhip_dist_mult: k = 0 the slab vector(s), k = 1 the result array of the same size); contents are the caller's business.
+extern "C" int chebhip_comm_null_set_shadow(chebhip_comm *c, int k, const double *const *arrays) {
+  if (!c || c->kind != KIND_NULL || k < 0 || k >= chebhip::COMM_NPTR) return chebhip_fail(CHEBHIP_ERR_ARG, "chebhip_comm_null_set_shadow: a NULL-transport communicator and k = 0 .. %d", chebhip::COMM_NPTR - 1);
+  for (int r = 0; r < c->G; r++) c->shadow[k][r] = arrays ? arrays[r] : nullptr;
+  return 0;
+}
+
 extern "C" int chebhip_comm_destroy(chebhip_comm *c) {
   if (!c) return 0;
   if (c->kind == KIND_LOCAL && c->lg) {
@@ -536,8 +547,11 @@ int comm_mark(chebhip_comm *c, int slot, hipStream_t st) {
 
 int comm_rendezvous(chebhip_comm *c, const double *const *ptrs, int n, int slot, int wait_slot, hipStream_t st, PeerView *out) {
   if (!c || !out || n < 0 || n > COMM_NPTR || slot < 0 || slot >= COMM_NEV || wait_slot >= COMM_NEV) return chebhip_fail(CHEBHIP_ERR_ARG, "comm_rendezvous: bad argument");
-  if (c->kind == KIND_NULL) {                    // one rank stands for all of them: every peer's arrays are this rank's own
-    for (int r = 0; r < c->G; r++) for (int k = 0; k < COMM_NPTR; k++) out->ptr[r][k] = k < n ? ptrs[k] : nullptr;
+  if (c->kind == KIND_NULL) {                    // one rank stands for all of them: every peer's arrays are this rank's own ...
+    for (int r = 0; r < c->G; r++) for (int k = 0; k < COMM_NPTR; k++) {
+      out->ptr[r][k] = k < n ? ptrs[k] : nullptr;
+      if (r != c->rank && out->ptr[r][k] && c->shadow[k][r]) out->ptr[r][k] = c->shadow[k][r];   // ... or arrays of their own that the host set aside
+    }
     return 0;
   }
   if (c->kind == KIND_IPC) {

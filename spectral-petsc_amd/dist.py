@@ -628,6 +628,14 @@ class Comm:
                 return 5
         return xfn
 
+    def set_null_shadow(self, k, tensors):
+        """NULL transport: tensors[r] (None = the rank's own) stands for peer r's k-th posted array (chebhip_comm_null_set_shadow) --
+        the direct route's kernels then touch G distinct arrays.  The tensors are kept alive by this object."""
+        import ctypes as C
+        arr = (C.c_void_p * self.G)(*[(t.data_ptr() if t is not None else None) for t in tensors])
+        self.sp._chk(self.sp.lib().chebhip_comm_null_set_shadow(self._h, int(k), arr))
+        self._shadow = getattr(self, "_shadow", {}); self._shadow[int(k)] = list(tensors)
+
     def allreduce_sum(self, value):
         """Sum of one float over the ranks (chebhip_comm_reduce on a device scalar, on torch's current stream)."""
         t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")

@@ -105,4 +105,9 @@ def test_argument_errors_of_the_wider_abi(L):
     assert L.chebhip_ipc_group_open(b"/chebhip-test-abi", 65, 0, C.byref(h)) == 4
     assert L.chebhip_comm_create_ipc(None, None, C.byref(h)) == 4
     assert L.chebhip_ipc_group_close(None) == 0 and L.chebhip_ipc_group_abort(None) == 0
+    assert L.chebhip_comm_null_set_shadow(None, 0, None) == 4                               # not a NULL-transport communicator
+    c = C.c_void_p()
+    assert L.chebhip_comm_create_null(4, 1, C.byref(c)) == 0 and c.value
+    assert L.chebhip_comm_null_set_shadow(c, 2, None) == 4 and L.chebhip_comm_null_set_shadow(c, 0, None) == 0
+    assert L.chebhip_comm_destroy(c) == 0
     assert h.value is None

@@ -588,3 +588,30 @@ def test_config5_continuation_128_over_8_ranks():
     assert relerr(xd, xs) < 1e-6, (relerr(xd, xs), summary)
     assert logd[-1][4] < 2.0 * logs[-1][4] + 1e-12, summary                   # final residual norms alike
     print("config 5 over 8 thread ranks: (Newton, Krylov) per stage %r; one GPU %r; rel. difference of the solutions %.2e" % (summary[0], summary[1], relerr(xd, xs)))
+
+
+def test_null_transport_with_arrays_standing_for_the_peers():
+    """chebhip_comm_null_set_shadow (bench.py dist_rank_compute: *_distinct_peer_arrays): one rank of 4 on the NULL transport with three
+    arrays of its own standing for the peers' slabs and three for their result arrays.  Without them every "peer" is the rank itself and
+    the rows it computes for the other owners land on top of each other in its own result array (timing only); with them each owner's
+    rows go to that owner's array: the peers' arrays receive rows, and the rank's own column block is reproducible to the bit."""
+    sp = ge.load(); dsp = ge.load_dist()
+    dims, G = (70, 70, 66), 4
+    comm = dsp.Comm(sp, null=(G, 0))
+    D = dsp.DistPoissonC(dims, sp, comm=comm)
+    n = D.local_size
+    U = torch.randn(n, dtype=torch.float64, device="cuda"); V1 = torch.empty_like(U); V2 = torch.empty_like(U)
+    shadow_u = [None] + [torch.randn(n, dtype=torch.float64, device="cuda") for _ in range(G - 1)]
+    shadow_t = [None] + [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(G - 1)]
+    comm.set_null_shadow(0, shadow_u); comm.set_null_shadow(1, shadow_t)
+    D.mult(U, V1)
+    D.mult(U, V2)
+    torch.cuda.synchronize()
+    M0, M1, R = (d - 2 for d in dims)
+    w = M1 // G                                         # 68 = 4 x 17: the rank's own column block is columns 0 .. 17 of every plane
+    a = V1.cpu().numpy().reshape(-1, M1, R); b = V2.cpu().numpy().reshape(-1, M1, R)
+    assert np.isfinite(a[:, :w, :]).all() and np.array_equal(a[:, :w, :], b[:, :w, :])
+    assert all(float(t.abs().max()) > 0 for t in shadow_t[1:])          # the peers' result arrays got the rows computed for them
+    comm.set_null_shadow(0, [None] * G); comm.set_null_shadow(1, [None] * G)
+    D.mult(U, V2); torch.cuda.synchronize()                             # back to the rank's own arrays: runs as before
+    D.destroy(); comm.destroy()
